@@ -1,0 +1,82 @@
+"""ctypes binding of libhexgnn.so (C ABI: include/hexgnn.h).
+
+There is NO fallback: if the shared library is missing or a call fails, this raises.
+torch is imported first on purpose: libhexgnn.so links libamdhip64.so.7 by soname, and loading
+torch first makes the dynamic loader hand it the HIP runtime torch already uses, so streams and
+device pointers are shared with torch's allocator.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
+_lib = None
+
+vp = C.c_void_p
+ci = C.c_int
+sz = C.c_size_t
+
+_SIGS = {
+    "hexgnn_abi_version": (ci, []),
+    "hexgnn_strerror": (C.c_char_p, [ci]),
+    "hexgnn_last_hip_error": (ci, []),
+    "hexgnn_padded_width": (ci, [ci]),
+    "hexgnn_csr_workspace_bytes": (sz, [ci, ci]),
+    "hexgnn_csr_build": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "hexgnn_graph_ptr": (ci, [ci, ci, vp, vp, vp]),
+    "hexgnn_sage_stack_pack_bytes": (sz, [ci, ci, ci]),
+    "hexgnn_sage_stack_saved_bytes": (sz, [ci, ci, ci, ci]),
+    "hexgnn_sage_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "hexgnn_sage_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
+    "hexgnn_sage_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
+                                        vp, vp, vp, vp, sz, vp]),
+    "hexgnn_head_saved_bytes": (sz, [ci, ci, ci]),
+    "hexgnn_head_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),
+    "hexgnn_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                  vp, sz, vp]),
+    "hexgnn_pad_rows": (ci, [ci, ci, vp, ci, vp, vp]),
+    "hexgnn_unpad_rows": (ci, [ci, ci, vp, vp, ci, vp]),
+}
+
+
+class HexGnnError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libhexgnn.so once; raise loudly when it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise HexGnnError(
+                "libhexgnn.so not found at %s -- build it with `make -C gnn_hex_amd/csrc` "
+                "(or `python -c 'import __graft_entry__ as g; g.build()'`). "
+                "gnn_hex_amd has no CPU/PyTorch fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)
+            fn.restype = res
+            fn.argtypes = args
+        if L.hexgnn_abi_version() != 1:
+            raise HexGnnError("libhexgnn.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        L = lib()
+        msg = L.hexgnn_strerror(rc).decode()
+        if rc == -4:
+            msg += " (hipError_t %d)" % L.hexgnn_last_hip_error()
+        raise HexGnnError("%s failed: %s" % (what or "hexgnn call", msg))
+
+
+def exported_symbols():
+    """Names every entry point include/hexgnn.h declares (used by the CPU-side ABI test)."""
+    return sorted(_SIGS)

@@ -1,0 +1,189 @@
+// Graph-structure kernels: COO -> sorted CSR (+ transpose), batch vector -> graph ptr,
+// padded-layout copies.  Integer work, HBM/L2 bound; no MFMA.
+//
+// Replaces the per-layer edge_index indexing of torch_geometric's propagate (GN0/models.py:276)
+// and torch_geometric Batch.ptr / torch_scatter's segment lookup (GN0/models.py:381,578).
+#include "hexgnn_common.h"
+
+namespace hexgnn {
+
+thread_local int g_last_hip_error = 0;
+
+// ---- 1. degree histogram (int atomics, L2-resident) ---------------------------------------------
+__global__ void csr_count_kernel(int n, int e, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                 int* __restrict__ rowptr, int* __restrict__ rowptr_t, int* __restrict__ status) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const int64_t s = src[i], d = dst[i];
+    if (s < 0 || s >= n || d < 0 || d >= n) { atomicOr(status, 1); return; }
+    atomicAdd(&rowptr[d + 1], 1);
+    atomicAdd(&rowptr_t[s + 1], 1);
+}
+
+// ---- 2. in-place inclusive scan of m ints, one 1024-thread workgroup per array -------------------
+__global__ __launch_bounds__(1024) void csr_scan_kernel(int m, int* __restrict__ a0, int* __restrict__ a1) {
+    int* a = blockIdx.x == 0 ? a0 : a1;
+    __shared__ int wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = (m + 1023) / 1024;
+    const int beg = tid * per, end = min(beg + per, m);
+    int sum = 0;
+    for (int i = beg; i < end; ++i) sum += a[i];
+    // wave inclusive scan of the per-thread sums
+    int inc = sum;
+    for (int off = 1; off < 64; off <<= 1) {
+        int v = __shfl_up(inc, off);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    if (tid == 0) {
+        int c = 0;
+        for (int w = 0; w < 16; ++w) { int t = wsum[w]; wsum[w] = c; c += t; }
+    }
+    __syncthreads();
+    int run = wsum[wave] + inc - sum;  // exclusive prefix of this thread's chunk
+    for (int i = beg; i < end; ++i) { run += a[i]; a[i] = run; }
+}
+
+// ---- 3. fill (arrival order within a row is arbitrary; step 4 sorts every row) -------------------
+__global__ void csr_fill_kernel(int n, int e, const int64_t* __restrict__ src, const int64_t* __restrict__ dst,
+                                const int* __restrict__ rowptr, const int* __restrict__ rowptr_t,
+                                int* __restrict__ cur, int* __restrict__ cur_t,
+                                int* __restrict__ col, int* __restrict__ col_t) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= e) return;
+    const int64_t s = src[i], d = dst[i];
+    if (s < 0 || s >= n || d < 0 || d >= n) return;
+    const int p = atomicAdd(&cur[d], 1);
+    col[rowptr[d] + p] = (int)s;
+    const int q = atomicAdd(&cur_t[s], 1);
+    col_t[rowptr_t[s] + q] = (int)d;
+}
+
+// ---- 4. sort every row ascending (deterministic CSR), write 1/max(deg,1) --------------------------
+__global__ void csr_sort_rows_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ rowptr_t,
+                                     int* __restrict__ col, int* __restrict__ col_t, float* __restrict__ invdeg) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 2 * n) return;
+    const bool tr = i >= n;
+    const int r = tr ? i - n : i;
+    const int* rp = tr ? rowptr_t : rowptr;
+    int* c = tr ? col_t : col;
+    const int b = rp[r], e = rp[r + 1];
+    for (int k = b + 1; k < e; ++k) {
+        const int v = c[k];
+        int j = k - 1;
+        while (j >= b && c[j] > v) { c[j + 1] = c[j]; --j; }
+        c[j + 1] = v;
+    }
+    if (!tr) invdeg[r] = 1.0f / (float)max(e - b, 1);
+}
+
+__global__ void graph_ptr_kernel(int n, int b, const int64_t* __restrict__ batch, int* __restrict__ gptr) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n == 0) { if (i <= b) gptr[i] = 0; return; }
+    if (i >= n) return;
+    const int cur = (int)min((int64_t)b - 1, max((int64_t)0, batch[i]));
+    const int prev = i > 0 ? (int)min((int64_t)b - 1, max((int64_t)0, batch[i - 1])) : -1;
+    for (int g = prev + 1; g <= cur; ++g) gptr[g] = i;
+    if (i == n - 1) for (int g = cur + 1; g <= b; ++g) gptr[g] = n;
+}
+
+__global__ void pad_rows_kernel(int n, int hidden, int hp, const float* __restrict__ src, int src_stride,
+                                float* __restrict__ dst) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * hp) return;
+    const int r = (int)(i / hp), c = (int)(i % hp);
+    dst[i] = c < hidden ? src[(int64_t)r * src_stride + c] : 0.f;
+}
+
+__global__ void unpad_rows_kernel(int n, int hidden, int hp, const float* __restrict__ src,
+                                  float* __restrict__ dst, int dst_stride) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * hidden) return;
+    const int r = (int)(i / hidden), c = (int)(i % hidden);
+    dst[(int64_t)r * dst_stride + c] = src[(int64_t)r * hp + c];
+}
+
+}  // namespace hexgnn
+
+using namespace hexgnn;
+
+extern "C" {
+
+int hexgnn_abi_version(void) { return HEXGNN_ABI_VERSION; }
+
+const char* hexgnn_strerror(int code) {
+    switch (code) {
+        case HEXGNN_OK: return "ok";
+        case HEXGNN_EINVAL: return "invalid argument";
+        case HEXGNN_EUNSUPPORTED: return "shape not supported by the compiled kernels";
+        case HEXGNN_EWORKSPACE: return "workspace too small";
+        case HEXGNN_EHIP: return "HIP runtime error at launch";
+        default: return "unknown hexgnn error";
+    }
+}
+
+int hexgnn_last_hip_error(void) { return g_last_hip_error; }
+
+int hexgnn_padded_width(int hidden) { return padded_width(hidden); }
+
+size_t hexgnn_csr_workspace_bytes(int n, int e) {
+    (void)e;
+    if (n < 0) return 0;
+    return align_up(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1), 256);
+}
+
+int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* rowptr, int* col,
+                     int* rowptr_t, int* col_t, float* invdeg, int* status, void* workspace,
+                     size_t workspace_bytes, hexgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || e < 0 || !rowptr || !rowptr_t || !status || (n > 0 && !invdeg)) return HEXGNN_EINVAL;
+    if (e > 0 && (!src || !dst || !col || !col_t)) return HEXGNN_EINVAL;
+    if (workspace_bytes < hexgnn_csr_workspace_bytes(n, e) || !workspace) return HEXGNN_EWORKSPACE;
+    int* cur = (int*)workspace;
+    int* cur_t = cur + n;
+    (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(n + 1), stream);
+    (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
+    (void)hipMemsetAsync(status, 0, sizeof(int), stream);
+    if (n > 0) (void)hipMemsetAsync(cur, 0, sizeof(int) * 2 * (size_t)n, stream);
+    if (e > 0)
+        csr_count_kernel<<<(e + 255) / 256, 256, 0, stream>>>(n, e, src, dst, rowptr, rowptr_t, status);
+    csr_scan_kernel<<<2, 1024, 0, stream>>>(n + 1, rowptr, rowptr_t);
+    if (e > 0)
+        csr_fill_kernel<<<(e + 255) / 256, 256, 0, stream>>>(n, e, src, dst, rowptr, rowptr_t, cur, cur_t, col, col_t);
+    if (n > 0)
+        csr_sort_rows_kernel<<<(2 * n + 255) / 256, 256, 0, stream>>>(n, rowptr, rowptr_t, col, col_t, invdeg);
+    return check_launch();
+}
+
+int hexgnn_graph_ptr(int n, int b, const int64_t* batch, int* gptr, hexgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || b < 0 || !gptr || (n > 0 && !batch)) return HEXGNN_EINVAL;
+    const int work = n > 0 ? n : b + 1;
+    graph_ptr_kernel<<<(work + 255) / 256, 256, 0, stream>>>(n, b, batch, gptr);
+    return check_launch();
+}
+
+int hexgnn_pad_rows(int n, int hidden, const float* src, int src_stride, float* dst, hexgnn_stream_t stream_) {
+    const int hp = padded_width(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    if (n < 0 || (n > 0 && (!src || !dst)) || src_stride < hidden) return HEXGNN_EINVAL;
+    if (n == 0) return HEXGNN_OK;
+    const int64_t tot = (int64_t)n * hp;
+    pad_rows_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream_>>>(n, hidden, hp, src, src_stride, dst);
+    return check_launch();
+}
+
+int hexgnn_unpad_rows(int n, int hidden, const float* src, float* dst, int dst_stride, hexgnn_stream_t stream_) {
+    const int hp = padded_width(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    if (n < 0 || (n > 0 && (!src || !dst)) || dst_stride < hidden) return HEXGNN_EINVAL;
+    if (n == 0) return HEXGNN_OK;
+    const int64_t tot = (int64_t)n * hidden;
+    unpad_rows_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream_>>>(n, hidden, hp, src, dst, dst_stride);
+    return check_launch();
+}
+
+}  // extern "C"

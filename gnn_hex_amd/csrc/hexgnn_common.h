@@ -1,0 +1,36 @@
+// Shared device/host helpers for libhexgnn.so (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hexgnn.h"
+
+namespace hexgnn {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kWave = 64;        // CDNA wavefront
+constexpr int kMaxNT = 8;        // hidden <= 128
+constexpr int kSmallCin = 8;     // raw-feature first layer: c_in <= 8, stored padded to 8
+
+extern thread_local int g_last_hip_error;
+
+inline int check_launch() {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return HEXGNN_EHIP; }
+    return HEXGNN_OK;
+}
+
+inline int padded_width(int hidden) {
+    if (hidden <= 0 || hidden > 16 * kMaxNT) return -1;
+    return 16 * ((hidden + 15) / 16);
+}
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// v_mfma_f32_16x16x4_f32: D[16x16] += A[16x4] * B[4x16], exact fp32 (k-ordered fmaf chain).
+// lane l: a = A[l&15][l>>4], b = B[l>>4][l&15]; acc[r] = D[4*(l>>4)+r][l&15].
+__device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 acc) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+}
+
+}  // namespace hexgnn

@@ -1,0 +1,707 @@
+// GraphSAGE stack for gfx950: fused (CSR mean-gather -> fp32 MFMA [agg|x]*[Wl;Wr]^T -> bias -> ReLU) per
+// layer, its data-gradient twin, and a batched weight-gradient GEMM.
+//
+// Reference semantics: CachifiedGNN.forward (GN0/models.py:261-294) over pyg SAGEConv
+// (GN0/torch_script_models.py:52-73):  y_i = W_l mean_{j in N(i)} x_j + b_l + W_r x_i ; ReLU every layer.
+//
+// Data layout (HBM): every node-feature matrix is [n][HP] fp32, HP = 16*NT (pads zero).  A workgroup is
+// 8 waves; wave w owns the 16-row block 8*blockIdx+w.  The whole packed weight matrix of the layer
+// (2*NT*NT KiB) is staged once per workgroup into LDS in MFMA-fragment order, so every B fragment is one
+// conflict-free ds_read_b128.  The A operand never touches LDS: lane (r = l&15, g = l>>4) gathers, for
+// its row r, the feature chunks {16c+4g .. 16c+4g+3} of every in-neighbour straight into registers; these
+// four floats are the k-slices of four consecutive v_mfma_f32_16x16x4_f32 (the K order is permuted
+// consistently on the packed-weight side).  fp32 in / fp32 accumulate: exact fmaf chains, deterministic.
+#include "hexgnn_common.h"
+
+namespace hexgnn {
+
+constexpr int kMaxLayers = 64;
+
+struct LayerPtrs {
+    const float* wl[kMaxLayers];
+    const float* bl[kMaxLayers];
+    const float* wr[kMaxLayers];
+};
+
+struct StackPlan {
+    int hp, nt, L, c_in;
+    bool small_first;
+    size_t fwd_off[kMaxLayers];   // byte offsets into wpack
+    size_t bwd_off[kMaxLayers];
+    size_t bias_off[kMaxLayers];
+    size_t pack_bytes;
+    size_t agg_off[kMaxLayers];   // byte offsets into saved
+    size_t saved_bytes;
+};
+
+static int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
+    const int hp = padded_width(hidden);
+    if (hp < 0 || L < 1 || L > kMaxLayers) return HEXGNN_EUNSUPPORTED;
+    if (c_in != hidden && (c_in < 1 || c_in > kSmallCin)) return HEXGNN_EUNSUPPORTED;
+    p->hp = hp; p->nt = hp / 16; p->L = L; p->c_in = c_in;
+    p->small_first = (c_in != hidden);
+    size_t off = 0, soff = 0;
+    const size_t pack = (size_t)2 * p->nt * p->nt * 64 * sizeof(f32x4);
+    for (int l = 0; l < L; ++l) {
+        if (l == 0 && p->small_first) {
+            p->fwd_off[l] = off; off += sizeof(float) * (size_t)hp * kSmallCin * 2;  // [HP][8] Wl, [HP][8] Wr
+            p->bwd_off[l] = 0;
+            p->agg_off[l] = soff; soff += align_up(sizeof(float) * (size_t)n * kSmallCin, 256);
+        } else {
+            p->fwd_off[l] = off; off += pack;
+            p->bwd_off[l] = off; off += pack;
+            p->agg_off[l] = soff; soff += align_up(sizeof(float) * (size_t)n * hp, 256);
+        }
+        p->bias_off[l] = off; off += align_up(sizeof(float) * hp, 256);
+    }
+    p->pack_bytes = off;
+    p->saved_bytes = soff;
+    return HEXGNN_OK;
+}
+
+// ---- weight packing (one launch per stack call; grid.y = layer) ------------------------------------
+struct PackArgs {
+    LayerPtrs p;
+    size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers], bias_off[kMaxLayers];
+    int hp, nt, L, c_in, hidden, small_first;
+};
+
+__global__ void sage_pack_kernel(PackArgs a, char* __restrict__ wpack) {
+    const int l = blockIdx.y;
+    const int hp = a.hp, nt = a.nt, H = a.hidden;
+    const float* wl = a.p.wl[l];
+    const float* wr = a.p.wr[l];
+    const float* bl = a.p.bl[l];
+    float* bias = (float*)(wpack + a.bias_off[l]);
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < hp) bias[tid] = tid < H ? bl[tid] : 0.f;
+    if (l == 0 && a.small_first) {
+        float* w0 = (float*)(wpack + a.fwd_off[l]);
+        const int tot = hp * kSmallCin;
+        if (tid < tot) {
+            const int o = tid / kSmallCin, q = tid % kSmallCin;
+            const bool ok = o < H && q < a.c_in;
+            w0[tid] = ok ? wl[o * a.c_in + q] : 0.f;
+            w0[tot + tid] = ok ? wr[o * a.c_in + q] : 0.f;
+        }
+        return;
+    }
+    const int in = H;  // hidden -> hidden
+    const int tot = 2 * nt * nt * 256;
+    if (tid >= tot) return;
+    float* pf = (float*)(wpack + a.fwd_off[l]);
+    float* pb = (float*)(wpack + a.bwd_off[l]);
+    {   // forward pack  P[c][t][lane][j], c < 2NT (k chunk of [agg|x]), t < NT (output tile)
+        const int c = tid / (nt * 256), rem = tid % (nt * 256);
+        const int t = rem / 256, lj = rem % 256, lane = lj >> 2, j = lj & 3;
+        const int g = lane >> 4, cx = lane & 15;
+        const int k = 16 * (c % nt) + 4 * g + j, o = 16 * t + cx;
+        const float* w = c < nt ? wl : wr;
+        pf[tid] = (k < in && o < H) ? w[o * in + k] : 0.f;
+    }
+    {   // backward pack PB[c][t][lane][j], c < NT (k chunk over outputs o), t < 2NT (tile of [dAgg|dXs])
+        const int c = tid / (2 * nt * 256), rem = tid % (2 * nt * 256);
+        const int t = rem / 256, lj = rem % 256, lane = lj >> 2, j = lj & 3;
+        const int g = lane >> 4, cx = lane & 15;
+        const int o = 16 * c + 4 * g + j, i = 16 * (t % nt) + cx;
+        const float* w = t < nt ? wl : wr;
+        pb[tid] = (o < H && i < in) ? w[o * in + i] : 0.f;
+    }
+}
+
+// ---- first layer, raw features (c_in <= 8): VALU, HBM-bound ----------------------------------------
+// 32 rows per 256-thread workgroup.  Saves the aggregated raw features [n][8] for the backward pass.
+__global__ __launch_bounds__(256) void sage_first_fwd_kernel(
+    int n, int c_in, int hp, const int* __restrict__ rowptr, const int* __restrict__ col,
+    const float* __restrict__ invdeg, const float* __restrict__ x, int x_stride,
+    const float* __restrict__ w0 /*[hp][8] Wl then [hp][8] Wr*/, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ agg_out /*[n][8] or null*/) {
+    __shared__ float sA[32][kSmallCin], sX[32][kSmallCin];
+    __shared__ float sW[2 * 128 * kSmallCin + 128];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 32;
+    for (int i = tid; i < 2 * hp * kSmallCin; i += 256) sW[i] = w0[i];
+    for (int i = tid; i < hp; i += 256) sW[2 * 128 * kSmallCin + i] = bias[i];
+    if (tid < 32) {
+        const int row = r0 + tid;
+        float a[kSmallCin], s[kSmallCin];
+#pragma unroll
+        for (int q = 0; q < kSmallCin; ++q) { a[q] = 0.f; s[q] = 0.f; }
+        if (row < n) {
+            for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+                const float* xr = x + (size_t)col[e] * x_stride;
+                for (int q = 0; q < c_in; ++q) a[q] += xr[q];
+            }
+            const float sc = invdeg[row];
+            const float* xs = x + (size_t)row * x_stride;
+            for (int q = 0; q < c_in; ++q) { a[q] *= sc; s[q] = xs[q]; }
+            if (agg_out) {
+#pragma unroll
+                for (int q = 0; q < kSmallCin; ++q) agg_out[(size_t)row * kSmallCin + q] = a[q];
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < kSmallCin; ++q) { sA[tid][q] = a[q]; sX[tid][q] = s[q]; }
+    }
+    __syncthreads();
+    const float* sWl = sW;
+    const float* sWr = sW + hp * kSmallCin;
+    const float* sB = sW + 2 * 128 * kSmallCin;
+    for (int idx = tid; idx < 32 * hp; idx += 256) {
+        const int r = idx / hp, c = idx % hp;
+        const int row = r0 + r;
+        if (row >= n) break;
+        float v = sB[c];
+#pragma unroll
+        for (int q = 0; q < kSmallCin; ++q) v += sWl[c * kSmallCin + q] * sA[r][q] + sWr[c * kSmallCin + q] * sX[r][q];
+        y[(size_t)row * hp + c] = v > 0.f ? v : 0.f;
+    }
+}
+
+// ---- hidden layer forward ----------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ invdeg,
+    const float* __restrict__ x, const f32x4* __restrict__ wpack, const float* __restrict__ bias,
+    float* __restrict__ y, float* __restrict__ agg_out) {
+    constexpr int HP = 16 * NT;
+    extern __shared__ f32x4 wlds[];  // [2NT][NT][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * NT * NT * 64; i += 512) wlds[i] = wpack[i];
+
+    const int row0 = (blockIdx.x * 8 + wave) * 16;
+    const int r = lane & 15, g = lane >> 4;
+    const int row = row0 + r;
+    f32x4 xs[NT], ag[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) { xs[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (row < n) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * HP) + g;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xs[c] = xr[4 * c];
+        const int e0 = rowptr[row], e1 = rowptr[row + 1];
+        for (int e = e0; e < e1; ++e) {
+            const f32x4* xj = reinterpret_cast<const f32x4*>(x + (size_t)col[e] * HP) + g;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
+        }
+        const float sc = invdeg[row];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] *= sc;
+        if (agg_out) {
+            f32x4* ar = reinterpret_cast<f32x4*>(agg_out + (size_t)row * HP) + g;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ar[4 * c] = ag[c];
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 b = wlds[(c * NT + t) * 64 + lane];
+            acc[t] = mfma16x16x4(ag[c][0], b[0], acc[t]);
+            acc[t] = mfma16x16x4(ag[c][1], b[1], acc[t]);
+            acc[t] = mfma16x16x4(ag[c][2], b[2], acc[t]);
+            acc[t] = mfma16x16x4(ag[c][3], b[3], acc[t]);
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 b = wlds[((NT + c) * NT + t) * 64 + lane];
+            acc[t] = mfma16x16x4(xs[c][0], b[0], acc[t]);
+            acc[t] = mfma16x16x4(xs[c][1], b[1], acc[t]);
+            acc[t] = mfma16x16x4(xs[c][2], b[2], acc[t]);
+            acc[t] = mfma16x16x4(xs[c][3], b[3], acc[t]);
+        }
+    }
+    // epilogue: lane holds D[4g+q][16t + (lane&15)]
+    const int cx = lane & 15;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const float bv = bias[16 * t + cx];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int orow = row0 + 4 * g + q;
+            if (orow < n) {
+                const float v = acc[t][q] + bv;
+                y[(size_t)orow * HP + 16 * t + cx] = v > 0.f ? v : 0.f;
+            }
+        }
+    }
+}
+
+// ---- hidden layer backward (data): G = (dXs' + sum_{j in T(i)} dAggS'_j) * [y>0];  [dAggS|dXs] = G [Wl|Wr] -----
+template <int NT>
+__global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
+    int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t, const float* __restrict__ invdeg,
+    const float* __restrict__ dxs_in, const float* __restrict__ dagg_in /*null: dxs_in is dY*/,
+    const float* __restrict__ y, const f32x4* __restrict__ wpackb,
+    float* __restrict__ g_out, float* __restrict__ dagg_out, float* __restrict__ dxs_out) {
+    constexpr int HP = 16 * NT;
+    extern __shared__ f32x4 wlds[];  // [NT][2NT][64]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * NT * NT * 64; i += 512) wlds[i] = wpackb[i];
+
+    const int row0 = (blockIdx.x * 8 + wave) * 16;
+    const int r = lane & 15, g = lane >> 4;
+    const int row = row0 + r;
+    f32x4 gx[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) gx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (row < n) {
+        const f32x4* dr = reinterpret_cast<const f32x4*>(dxs_in + (size_t)row * HP) + g;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) gx[c] = dr[4 * c];
+        if (dagg_in) {
+            const int e0 = rowptr_t[row], e1 = rowptr_t[row + 1];
+            for (int e = e0; e < e1; ++e) {
+                const f32x4* dj = reinterpret_cast<const f32x4*>(dagg_in + (size_t)col_t[e] * HP) + g;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
+            }
+        }
+        const f32x4* yr = reinterpret_cast<const f32x4*>(y + (size_t)row * HP) + g;
+        f32x4* go = reinterpret_cast<f32x4*>(g_out + (size_t)row * HP) + g;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) {
+            const f32x4 yv = yr[4 * c];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) gx[c][j] = yv[j] > 0.f ? gx[c][j] : 0.f;
+            go[4 * c] = gx[c];
+        }
+    }
+    __syncthreads();
+
+    f32x4 acc[2 * NT];
+#pragma unroll
+    for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < NT; ++c) {
+#pragma unroll
+        for (int t = 0; t < 2 * NT; ++t) {
+            const f32x4 b = wlds[(c * 2 * NT + t) * 64 + lane];
+            acc[t] = mfma16x16x4(gx[c][0], b[0], acc[t]);
+            acc[t] = mfma16x16x4(gx[c][1], b[1], acc[t]);
+            acc[t] = mfma16x16x4(gx[c][2], b[2], acc[t]);
+            acc[t] = mfma16x16x4(gx[c][3], b[3], acc[t]);
+        }
+    }
+    const int cx = lane & 15;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int orow = row0 + 4 * g + q;
+        if (orow < n) {
+            const float sc = invdeg[orow];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                dagg_out[(size_t)orow * HP + 16 * t + cx] = acc[t][q] * sc;
+                dxs_out[(size_t)orow * HP + 16 * t + cx] = acc[NT + t][q];
+            }
+        }
+    }
+}
+
+// ---- out = dxs + sum_{j in T(i)} dagg_j, optionally masked by y>0 (stack-input gradient / G of a raw first layer) ----
+__global__ void sage_combine_kernel(int n, int hp, const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
+                                    const float* __restrict__ dxs, const float* __restrict__ dagg,
+                                    const float* __restrict__ ymask, float* __restrict__ out) {
+    const int q4 = hp / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * q4) return;
+    const int row = (int)(i / q4), p = (int)(i % q4);
+    f32x4 v = reinterpret_cast<const f32x4*>(dxs + (size_t)row * hp)[p];
+    if (dagg) {
+        for (int e = rowptr_t[row]; e < rowptr_t[row + 1]; ++e)
+            v += reinterpret_cast<const f32x4*>(dagg + (size_t)col_t[e] * hp)[p];
+    }
+    if (ymask) {
+        const f32x4 yv = reinterpret_cast<const f32x4*>(ymask + (size_t)row * hp)[p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = yv[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(out + (size_t)row * hp)[p] = v;
+}
+
+// ---- batched weight gradient: dW[o][i'] = sum_rows G[row][o] * [agg|x][row][i'], db[o] = sum_rows G[row][o] -----
+// grid (S slices, number of hidden-input layers); NT waves; wave w owns output channels 16w..16w+15.
+struct DwArgs {
+    const float* xin[kMaxLayers];
+    const float* agg[kMaxLayers];
+    const float* g[kMaxLayers];
+    int n, rows_per_slice, S;
+};
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
+    constexpr int HP = 16 * NT;
+    constexpr int R = 32;
+    constexpr int AS = 2 * HP + 16;                     // == 16 (mod 32): conflict-free fragment reads
+    constexpr int GS = (NT % 2 == 1) ? HP : HP + 16;
+    constexpr int NTHR = 64 * NT;
+    __shared__ __attribute__((aligned(16))) float As[R * AS];
+    __shared__ __attribute__((aligned(16))) float Gs[R * GS];
+    const int li = blockIdx.y, s = blockIdx.x;
+    const float* __restrict__ xin = a.xin[li];
+    const float* __restrict__ agg = a.agg[li];
+    const float* __restrict__ gg = a.g[li];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int r_beg = s * a.rows_per_slice;
+    const int r_end = min(a.n, r_beg + a.rows_per_slice);
+
+    f32x4 acc[2 * NT];
+#pragma unroll
+    for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float bsum = 0.f;
+
+    for (int rc = r_beg; rc < r_end; rc += R) {
+        constexpr int Q = NT * 4;  // float4 pieces per row
+        for (int p = tid; p < R * Q; p += NTHR) {
+            const int rr = p / Q, q = p % Q;
+            const int row = rc + rr;
+            f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f}, vx = va, vg = va;
+            if (row < r_end) {
+                va = reinterpret_cast<const f32x4*>(agg + (size_t)row * HP)[q];
+                vx = reinterpret_cast<const f32x4*>(xin + (size_t)row * HP)[q];
+                vg = reinterpret_cast<const f32x4*>(gg + (size_t)row * HP)[q];
+            }
+            *reinterpret_cast<f32x4*>(&As[rr * AS + 4 * q]) = va;
+            *reinterpret_cast<f32x4*>(&As[rr * AS + HP + 4 * q]) = vx;
+            *reinterpret_cast<f32x4*>(&Gs[rr * GS + 4 * q]) = vg;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < R / 4; ++ks) {
+            const float av = Gs[(4 * ks + kq) * GS + 16 * w + m];
+            bsum += av;
+#pragma unroll
+            for (int t = 0; t < 2 * NT; ++t) {
+                const float bv = As[(4 * ks + kq) * AS + 16 * t + m];
+                acc[t] = mfma16x16x4(av, bv, acc[t]);
+            }
+        }
+        __syncthreads();
+    }
+    // slab [HP][2HP] then bias [HP]
+    float* slab = part + ((size_t)li * a.S + s) * ((size_t)HP * (2 * HP + 1));
+#pragma unroll
+    for (int t = 0; t < 2 * NT; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) slab[(size_t)(16 * w + 4 * kq + q) * (2 * HP) + 16 * t + m] = acc[t][q];
+    bsum += __shfl_xor(bsum, 16);
+    bsum += __shfl_xor(bsum, 32);
+    if (kq == 0) slab[(size_t)HP * 2 * HP + 16 * w + m] = bsum;
+}
+
+struct DwReduceArgs {
+    float* dwl[kMaxLayers];
+    float* dbl[kMaxLayers];
+    float* dwr[kMaxLayers];
+    int S, hp, hidden;
+};
+
+// out element space per layer: [hidden][2*hidden + 1]; fixed summation order over slices (deterministic)
+__global__ void sage_dw_reduce_kernel(DwReduceArgs a, const float* __restrict__ part) {
+    const int li = blockIdx.y;
+    const int H = a.hidden, hp = a.hp;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * H + 1;
+    if (idx >= H * per) return;
+    const int o = idx / per, c = idx % per;
+    const size_t slab_sz = (size_t)hp * (2 * hp + 1);
+    size_t off;
+    if (c < H) off = (size_t)o * 2 * hp + c;
+    else if (c < 2 * H) off = (size_t)o * 2 * hp + hp + (c - H);
+    else off = (size_t)hp * 2 * hp + o;
+    const float* p = part + (size_t)li * a.S * slab_sz + off;
+    float sum = 0.f;
+    for (int s = 0; s < a.S; ++s) sum += p[(size_t)s * slab_sz];
+    if (c < H) a.dwl[li][o * H + c] = sum;
+    else if (c < 2 * H) a.dwr[li][o * H + (c - H)] = sum;
+    else a.dbl[li][o] = sum;
+}
+
+// ---- raw first layer weight gradient: partial [S][hp][17] = sum_rows G[row][o] * (agg0[row][0..7] | x0[row][0..7] | 1) ----
+__global__ __launch_bounds__(256) void sage_first_dw_kernel(
+    int n, int c_in, int hp, int rows_per_slice, const float* __restrict__ g, const float* __restrict__ agg0,
+    const float* __restrict__ x, int x_stride, float* __restrict__ part) {
+    __shared__ float red[128 * 17];
+    const int tid = threadIdx.x, o = tid & 127, ph = tid >> 7;
+    const int r_beg = blockIdx.x * rows_per_slice, r_end = min(n, r_beg + rows_per_slice);
+    float acc[17];
+#pragma unroll
+    for (int q = 0; q < 17; ++q) acc[q] = 0.f;
+    if (o < hp) {
+        for (int row = r_beg + ph; row < r_end; row += 2) {
+            const float gv = g[(size_t)row * hp + o];
+#pragma unroll
+            for (int q = 0; q < kSmallCin; ++q) acc[q] += gv * agg0[(size_t)row * kSmallCin + q];
+            for (int q = 0; q < c_in; ++q) acc[kSmallCin + q] += gv * x[(size_t)row * x_stride + q];
+            acc[16] += gv;
+        }
+    }
+    if (ph == 1) {
+#pragma unroll
+        for (int q = 0; q < 17; ++q) red[o * 17 + q] = acc[q];
+    }
+    __syncthreads();
+    if (ph == 0 && o < hp) {
+        float* out = part + ((size_t)blockIdx.x * hp + o) * 17;
+#pragma unroll
+        for (int q = 0; q < 17; ++q) out[q] = acc[q] + red[o * 17 + q];
+    }
+}
+
+__global__ void sage_first_dw_reduce_kernel(int S, int hp, int hidden, int c_in, const float* __restrict__ part,
+                                            float* __restrict__ dwl, float* __restrict__ dbl, float* __restrict__ dwr) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = 2 * c_in + 1;
+    if (idx >= hidden * per) return;
+    const int o = idx / per, c = idx % per;
+    const int q = c < c_in ? c : (c < 2 * c_in ? kSmallCin + (c - c_in) : 16);
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += part[((size_t)s * hp + o) * 17 + q];
+    if (c < c_in) dwl[o * c_in + c] = sum;
+    else if (c < 2 * c_in) dwr[o * c_in + (c - c_in)] = sum;
+    else dbl[o] = sum;
+}
+
+// ---- host-side dispatch ---------------------------------------------------------------------------------
+template <int NT>
+static void launch_fwd(int n, const int* rowptr, const int* col, const float* invdeg, const float* x,
+                       const void* wp, const float* bias, float* y, float* agg, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_fwd_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
+        return true;
+    }();
+    (void)once;
+    sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
+        n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg);
+}
+
+template <int NT>
+static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float* invdeg, const float* dxs_in,
+                       const float* dagg_in, const float* y, const void* wpb, float* g_out, float* dagg_out,
+                       float* dxs_out, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_bwd_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
+        return true;
+    }();
+    (void)once;
+    sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
+        n, rowptr_t, col_t, invdeg, dxs_in, dagg_in, y, (const f32x4*)wpb, g_out, dagg_out, dxs_out);
+}
+
+template <int NT>
+static void launch_dw(const DwArgs& a, int layers, float* part, hipStream_t st) {
+    sage_dw_kernel<NT><<<dim3(a.S, layers), 64 * NT, 0, st>>>(a, part);
+}
+
+#define HEXGNN_NT_SWITCH(nt, CALL)                 \
+    switch (nt) {                                  \
+        case 1: { constexpr int NT_ = 1; CALL; } break; \
+        case 2: { constexpr int NT_ = 2; CALL; } break; \
+        case 3: { constexpr int NT_ = 3; CALL; } break; \
+        case 4: { constexpr int NT_ = 4; CALL; } break; \
+        case 5: { constexpr int NT_ = 5; CALL; } break; \
+        case 6: { constexpr int NT_ = 6; CALL; } break; \
+        case 7: { constexpr int NT_ = 7; CALL; } break; \
+        case 8: { constexpr int NT_ = 8; CALL; } break; \
+        default: return HEXGNN_EUNSUPPORTED;       \
+    }
+
+static int dw_slices(int n) {
+    int s = (n + 1023) / 1024;
+    if (s < 1) s = 1;
+    if (s > 64) s = 64;
+    return s;
+}
+static int dw_rows_per_slice(int n, int S) {
+    int r = (n + S - 1) / S;
+    return (r + 31) / 32 * 32;
+}
+
+struct BwdPlan {
+    size_t g_off, pair_off[2][2], part_off, part0_off, total;
+    int S, rps;
+};
+static void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
+    const size_t slab = align_up(sizeof(float) * (size_t)n * p.hp, 256);
+    size_t off = 0;
+    b->g_off = off; off += slab * p.L;
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { b->pair_off[i][j] = off; off += slab; }
+    b->S = dw_slices(n);
+    b->rps = dw_rows_per_slice(n, b->S);
+    b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * b->S * p.hp * (2 * p.hp + 1), 256);
+    b->part0_off = off; off += align_up(sizeof(float) * (size_t)b->S * p.hp * 17, 256);
+    b->total = off;
+}
+
+}  // namespace hexgnn
+
+using namespace hexgnn;
+
+extern "C" {
+
+size_t hexgnn_sage_stack_pack_bytes(int c_in, int hidden, int num_layers) {
+    StackPlan p;
+    if (make_plan(0, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
+    return p.pack_bytes;
+}
+
+size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers) {
+    StackPlan p;
+    if (n < 0 || make_plan(n, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
+    return p.saved_bytes;
+}
+
+int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                              const float* invdeg, const float* x, int x_stride, const float* const* wl,
+                              const float* const* bl, const float* const* wr, void* wpack, float* acts,
+                              void* saved, int need_backward, hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    StackPlan p;
+    if (n < 0) return HEXGNN_EINVAL;
+    int rc = make_plan(n, c_in, hidden, num_layers, &p);
+    if (rc != HEXGNN_OK) return rc;
+    if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts)) return HEXGNN_EINVAL;
+    if (need_backward && !saved) return HEXGNN_EINVAL;
+    if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
+
+    PackArgs pa;
+    for (int l = 0; l < p.L; ++l) {
+        if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
+        pa.p.wl[l] = wl[l]; pa.p.bl[l] = bl[l]; pa.p.wr[l] = wr[l];
+        pa.fwd_off[l] = p.fwd_off[l]; pa.bwd_off[l] = p.bwd_off[l]; pa.bias_off[l] = p.bias_off[l];
+    }
+    pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
+    const int pack_elems = 2 * p.nt * p.nt * 256;
+    sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
+    if (n == 0) return check_launch();
+
+    const size_t slab = (size_t)n * p.hp;
+    char* wp = (char*)wpack;
+    char* sv = (char*)saved;
+    for (int l = 0; l < p.L; ++l) {
+        float* y = acts + slab * l;
+        const float* bias = (const float*)(wp + p.bias_off[l]);
+        float* agg = need_backward ? (float*)(sv + p.agg_off[l]) : nullptr;
+        if (l == 0 && p.small_first) {
+            sage_first_fwd_kernel<<<(n + 31) / 32, 256, 0, st>>>(n, c_in, p.hp, rowptr, col, invdeg, x, x_stride,
+                                                              (const float*)(wp + p.fwd_off[0]), bias, y, agg);
+        } else {
+            const float* xin = l == 0 ? x : acts + slab * (l - 1);
+            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, st)));
+        }
+    }
+    return check_launch();
+}
+
+size_t hexgnn_sage_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers) {
+    StackPlan p;
+    if (n < 0 || make_plan(n, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
+    BwdPlan b;
+    make_bwd_plan(n, p, &b);
+    return b.total;
+}
+
+int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                               const int* rowptr_t, const int* col_t, const float* invdeg, const float* x,
+                               int x_stride, const float* acts, const void* saved, const void* wpack,
+                               const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
+                               float* const* d_wr, void* workspace, size_t workspace_bytes,
+                               hexgnn_stream_t stream_) {
+    (void)rowptr; (void)col;
+    hipStream_t st = (hipStream_t)stream_;
+    StackPlan p;
+    if (n < 0) return HEXGNN_EINVAL;
+    int rc = make_plan(n, c_in, hidden, num_layers, &p);
+    if (rc != HEXGNN_OK) return rc;
+    BwdPlan b;
+    make_bwd_plan(n, p, &b);
+    if (!workspace || workspace_bytes < b.total) return HEXGNN_EWORKSPACE;
+    if (!d_wl || !d_bl || !d_wr || !wpack || !saved) return HEXGNN_EINVAL;
+    for (int l = 0; l < p.L; ++l) if (!d_wl[l] || !d_bl[l] || !d_wr[l]) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr_t || !col_t || !invdeg || !x || !acts || !dy)) return HEXGNN_EINVAL;
+
+    const size_t slab = (size_t)n * p.hp;
+    char* ws = (char*)workspace;
+    const char* wp = (const char*)wpack;
+    const char* sv = (const char*)saved;
+    float* G = (float*)(ws + b.g_off);
+    float* pair[2][2] = {{(float*)(ws + b.pair_off[0][0]), (float*)(ws + b.pair_off[0][1])},
+                         {(float*)(ws + b.pair_off[1][0]), (float*)(ws + b.pair_off[1][1])}};
+    float* part = (float*)(ws + b.part_off);
+    float* part0 = (float*)(ws + b.part0_off);
+
+    if (n == 0) {  // empty batch: all parameter gradients are zero
+        for (int l = 0; l < p.L; ++l) {
+            const int in = (l == 0) ? c_in : hidden;
+            (void)hipMemsetAsync(d_wl[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_wr[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_bl[l], 0, sizeof(float) * (size_t)hidden, st);
+        }
+        return check_launch();
+    }
+
+    // data-gradient chain, top layer first.  pair[k] = (dAggS, dXs) produced by the layer processed last.
+    const int first_hidden = p.small_first ? 1 : 0;
+    int cur = 0;
+    const float* in_dxs = dy;
+    const float* in_dagg = nullptr;
+    for (int l = p.L - 1; l >= first_hidden; --l) {
+        const float* y = acts + slab * l;
+        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, in_dxs, in_dagg, y, wp + p.bwd_off[l],
+                                                G + slab * l, pair[cur][0], pair[cur][1], st)));
+        in_dagg = pair[cur][0];
+        in_dxs = pair[cur][1];
+        cur ^= 1;
+    }
+    const int q4 = p.hp / 4;
+    const unsigned cgrid = (unsigned)(((int64_t)n * q4 + 255) / 256);
+    if (p.small_first) {
+        // G_0 = (dXs_1 + gather dAggS_1) * [y_0 > 0]   (or dy * mask when the stack is a single raw layer)
+        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, acts, G);
+    } else if (dx) {
+        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, nullptr, dx);
+    }
+
+    // weight gradients: one batched launch over all hidden-input layers
+    const int nh = p.L - first_hidden;
+    if (nh > 0) {
+        DwArgs da;
+        DwReduceArgs ra;
+        for (int i = 0; i < nh; ++i) {
+            const int l = first_hidden + i;
+            da.xin[i] = l == 0 ? x : acts + slab * (l - 1);
+            da.agg[i] = (const float*)(sv + p.agg_off[l]);
+            da.g[i] = G + slab * l;
+            ra.dwl[i] = d_wl[l]; ra.dbl[i] = d_bl[l]; ra.dwr[i] = d_wr[l];
+        }
+        da.n = n; da.rows_per_slice = b.rps; da.S = b.S;
+        ra.S = b.S; ra.hp = p.hp; ra.hidden = hidden;
+        HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
+        const int tot = hidden * (2 * hidden + 1);
+        sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
+    }
+    if (p.small_first) {
+        sage_first_dw_kernel<<<b.S, 256, 0, st>>>(n, c_in, p.hp, b.rps, G, (const float*)(sv + p.agg_off[0]), x,
+                                                  x_stride, part0);
+        const int tot = hidden * (2 * c_in + 1);
+        sage_first_dw_reduce_kernel<<<(tot + 255) / 256, 256, 0, st>>>(b.S, p.hp, hidden, c_in, part0, d_wl[0],
+                                                                       d_bl[0], d_wr[0]);
+    }
+    return check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,358 @@
+"""Drop-in mirror of ``GN0.models`` for the RainbowDQN hot path: ``get_pre_defined("modern_two_headed", args)``.
+
+Same module tree, attribute names, method signatures and state-dict keys as the reference
+(GN0/models.py:36-82 MLP, 144-295 CachifiedGNN, 318-384 HeadNetwork, 477-590 DuellingTwoHeaded,
+892-947 get_pre_defined), so reference checkpoints ``{"state_dict","args","cache"}`` load with
+``load_state_dict`` and ``train.py`` uses the model unchanged.  The arithmetic does NOT go through
+torch_geometric / torch_scatter: every forward/backward is a call into the hand-written HIP kernels
+of libhexgnn.so (gnn_hex_amd/ops.py).  CUDA(HIP) tensors only -- there is no CPU fallback.
+
+Out of scope here (raise NotImplementedError): ``--norm=True`` (LayerNorm / CachedGraphNorm),
+``--noisy_dqn=True`` (FactorizedNoisyLinear) and the other model families of the reference factory;
+all BASELINE configs run ``--norm=False --noisy_dqn=False`` (README.md:5,7).
+"""
+from __future__ import annotations
+
+from argparse import Namespace
+from typing import Optional, Tuple, Union
+
+import torch
+from torch import Tensor
+from torch.nn import Linear, ModuleList, Tanh
+
+from . import ops
+from .data import Batch, Data
+
+
+class MLP(torch.nn.Module):
+    """Parameter holder with the reference layout (GN0/models.py:36-82); evaluated inside the head kernel."""
+
+    def __init__(self, hidden_channels, num_hidden_layers, num_input, num_output, output_activation=None):
+        super().__init__()
+        self.layers = ModuleList()
+        self.num_input = num_input
+        self.num_output = num_output
+        self.hidden_channels = hidden_channels
+        if num_hidden_layers == 0:
+            self.layers.append(Linear(num_input, num_output))
+        else:
+            self.layers.append(Linear(num_input, hidden_channels))
+            for _ in range(num_hidden_layers - 1):
+                self.layers.append(Linear(hidden_channels, hidden_channels))
+            self.layers.append(Linear(hidden_channels, num_output))
+        self.output_activation = output_activation
+
+    def grow_input_width(self, new_input_width, new_hidden_channels):
+        """GN0/models.py:51-73 for the 1-hidden-layer value head (zero-padded copy of the old weights)."""
+        if len(self.layers) != 2:
+            raise NotImplementedError("grow_input_width: only the 1-hidden-layer value head is supported")
+        old0, old1 = self.layers[0], self.layers[1]
+        dev = old0.weight.device
+        new0 = Linear(new_input_width, new_hidden_channels).to(dev)
+        new0.weight.data.fill_(0)
+        new0.bias.data.fill_(0)
+        new0.weight.data[:self.hidden_channels, :self.num_input] = old0.weight.data
+        new0.bias.data[:self.hidden_channels] = old0.bias.data
+        new1 = Linear(new_hidden_channels, 1).to(dev)
+        new1.weight.data.fill_(0)
+        new1.weight.data[:, :self.hidden_channels] = old1.weight.data
+        new1.bias.data[:] = old1.bias.data
+        self.layers[0], self.layers[1] = new0, new1
+        self.num_input = new_input_width
+        self.hidden_channels = new_hidden_channels
+
+
+class SAGEConv(torch.nn.Module):
+    """Parameter holder for pyg SAGEConv(aggr='mean', root_weight=True, bias=True): ``lin_l`` (with bias)
+    acts on the neighbour mean, ``lin_r`` (no bias) on the root (GN0/torch_script_models.py:52-73)."""
+
+    def __init__(self, in_channels: int, out_channels: int, **kwargs):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.lin_l = Linear(in_channels, out_channels, bias=True)
+        self.lin_r = Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+        raise NotImplementedError(
+            "a single SAGEConv is not evaluated on its own in this build; run it through GraphSAGE "
+            "(the kernels fuse the ReLU that CachifiedGNN applies after every layer)")
+
+
+class GraphSAGE(torch.nn.Module):
+    """torch_geometric BasicGNN/GraphSAGE layout (restated at GN0/torch_script_models.py:96-144)."""
+
+    supports_edge_weight = False
+    supports_edge_attr = False
+
+    def __init__(self, in_channels: int, hidden_channels: int, num_layers: int, out_channels: Optional[int] = None,
+                 dropout: float = 0.0, act="relu", norm=None, jk=None, **kwargs):
+        super().__init__()
+        if norm is not None:
+            raise NotImplementedError("--norm=True is outside the accelerated hot path (README.md:5,7 use --norm=False)")
+        if act != "relu" or jk is not None or dropout != 0.0:
+            raise NotImplementedError("only act='relu', jk=None, dropout=0 (the modern_two_headed configuration)")
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.dropout = dropout
+        self.act = torch.nn.ReLU()
+        self.jk_mode = jk
+        self.act_first = False
+        self.out_channels = out_channels if out_channels is not None else hidden_channels
+        self.convs = ModuleList()
+        c = in_channels
+        if num_layers > 1:
+            self.convs.append(self.init_conv(c, hidden_channels, **kwargs))
+            c = hidden_channels
+        for _ in range(num_layers - 2):
+            self.convs.append(self.init_conv(c, hidden_channels, **kwargs))
+            c = hidden_channels
+        self.convs.append(self.init_conv(c, self.out_channels, **kwargs))
+        self.norms = None
+
+    def init_conv(self, in_channels: int, out_channels: int, **kwargs) -> SAGEConv:
+        return SAGEConv(in_channels, out_channels, **kwargs)
+
+
+def cachify_gnn(gnn):
+    """GN0/models.py:144-295.  Only GraphSAGE is accelerated."""
+    if gnn is not GraphSAGE:
+        raise NotImplementedError("cachify_gnn: only GraphSAGE is supported by the HIP path")
+
+    class CachifiedGNN(gnn):
+        supports_edge_weight = False
+        supports_edge_attr = False
+        supports_cache = True
+
+        def __init__(self, *args, out_channels: Optional[int] = None, cached_norm=False, **kwargs):
+            if "conv_kwargs" in kwargs:
+                self.conv_kwargs = kwargs["conv_kwargs"]
+                kwargs.update(kwargs["conv_kwargs"])
+                del kwargs["conv_kwargs"]
+            else:
+                self.conv_kwargs = dict()
+            super().__init__(*args, out_channels=out_channels, **kwargs)
+            self.cached_norm = cached_norm
+            self.has_output = out_channels is not None
+            self.has_cache = False
+            if self.has_output:
+                raise NotImplementedError("out_channels != None (linear last layer) is not on the hot path")
+
+        def grow_depth(self, additional_layers):
+            """GN0/models.py:166-185: append identity layers (lin_l = 0, lin_r = I)."""
+            assert not self.has_output
+            self.num_layers += additional_layers
+            device = self.convs[0].lin_l.weight.device
+            for _ in range(additional_layers):
+                conv = self.init_conv(self.hidden_channels, self.hidden_channels, **self.conv_kwargs).to(device)
+                conv.lin_l.weight.data[:] = 0
+                conv.lin_l.bias.data[:] = 0
+                conv.lin_r.weight.data[:] = torch.eye(self.hidden_channels)
+                self.convs.append(conv)
+            self.has_cache = False
+
+        def grow_width(self, new_width, new_in_channels=None):
+            """GN0/models.py:187-238: widen every layer, old weights in the top-left block, new input
+            columns zero, new output rows freshly initialised."""
+            device = self.convs[0].lin_l.weight.device
+            old_convs = self.convs
+            old_in_channels = self.in_channels
+            if new_in_channels is not None:
+                self.in_channels = new_in_channels
+            self.convs = ModuleList()
+            self.convs.append(self.init_conv(self.in_channels, new_width, **self.conv_kwargs).to(device))
+            for _ in range(self.num_layers - 1):
+                self.convs.append(self.init_conv(new_width, new_width, **self.conv_kwargs).to(device))
+            h = self.hidden_channels
+            for i, (conv, old) in enumerate(zip(self.convs, old_convs)):
+                if i == 0:
+                    if new_in_channels is None:
+                        conv.lin_l.weight.data[:h, :] = old.lin_l.weight.data
+                        conv.lin_r.weight.data[:h, :] = old.lin_r.weight.data
+                    else:
+                        conv.lin_l.weight.data[:h, :old_in_channels] = old.lin_l.weight.data
+                        conv.lin_r.weight.data[:h, :old_in_channels] = old.lin_r.weight.data
+                        conv.lin_l.weight.data[:h, old_in_channels:] = 0
+                        conv.lin_r.weight.data[:h, old_in_channels:] = 0
+                else:
+                    conv.lin_l.weight.data[:h, :h] = old.lin_l.weight.data
+                    conv.lin_r.weight.data[:h, :h] = old.lin_r.weight.data
+                    conv.lin_l.weight.data[:h, h:] = 0
+                    conv.lin_r.weight.data[:h, h:] = 0
+                conv.lin_l.bias.data[:h] = old.lin_l.bias.data
+            self.has_cache = False
+            self.hidden_channels = new_width
+            self.out_channels = new_width
+
+        def export_norm_cache(self):
+            if self.norms is None:
+                return
+            raise NotImplementedError
+
+        def import_norm_cache(self, mean_cache, var_cache):
+            if self.norms is None or not self.cached_norm:
+                return
+            raise NotImplementedError
+
+        def forward(self, x: Tensor, edge_index, *, edge_weight=None, edge_attr=None, set_cache: bool = False,
+                    _graph: Optional[ops.GraphStructure] = None) -> Tensor:
+            """conv -> relu for every layer (GN0/models.py:261-294 with has_output False, norms None)."""
+            gs = _graph if _graph is not None else ops.GraphStructure(edge_index, x.shape[0])
+            return ops.sage_stack(x, gs, self.in_channels, self.hidden_channels, self.convs)
+
+    return CachifiedGNN
+
+
+class HeadNetwork(torch.nn.Module):
+    """GN0/models.py:318-384 (noisy_dqn=False)."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, GNN, value_head_type="linear",
+                 value_aggr_types=("mean",), noisy_dqn=True, noise_sigma=0, **gnn_kwargs):
+        super().__init__()
+        if noisy_dqn:
+            raise NotImplementedError("--noisy_dqn=True is outside the accelerated hot path (README.md:5,7)")
+        if value_head_type != "mlp" or tuple(value_aggr_types) != ("sum", "max", "min", "mean") or out_channels != 1:
+            raise NotImplementedError("head kernel implements value_head_type='mlp' over (sum,max,min,mean), out=1")
+        self.gnn = GNN(in_channels=in_channels, hidden_channels=hidden_channels, **gnn_kwargs)
+        self.supports_cache = hasattr(self.gnn, "supports_cache") and self.gnn.supports_cache
+        self.value_head_type = value_head_type
+        self.hidden_channels = hidden_channels
+        self.value_head = MLP(self.hidden_channels // 2, 1, self.hidden_channels * len(value_aggr_types), 1)
+        self.out_channels = out_channels
+        self.value_aggr_types = value_aggr_types
+        self.linear = Linear(hidden_channels, out_channels)
+
+    def grow_width(self, new_width, new_in_channels=None):
+        """GN0/models.py:336-357."""
+        self.gnn.grow_width(new_width, new_in_channels=new_in_channels)
+        old = self.linear
+        self.linear = Linear(new_width, self.out_channels).to(old.weight.device)
+        self.linear.weight.data.fill_(0)
+        self.linear.weight.data[:, :self.hidden_channels] = old.weight.data
+        self.linear.bias.data[:] = old.bias.data[:]
+        self.value_head.grow_input_width(new_width * len(self.value_aggr_types), new_width // 2)
+        self.hidden_channels = new_width
+
+    def grow_depth(self, additional_layers):
+        self.gnn.grow_depth(additional_layers)
+
+    def export_norm_cache(self, *args, **kwargs):
+        return self.gnn.export_norm_cache(*args, **kwargs)
+
+    def import_norm_cache(self, *args, **kwargs):
+        return self.gnn.import_norm_cache(*args, **kwargs)
+
+    def _tail(self, x, gptr, b, mode):
+        vh = self.value_head
+        return ops.HeadTailFn.apply(x, gptr, b, self.hidden_channels, mode, self.linear.weight, self.linear.bias,
+                                    vh.layers[0].weight, vh.layers[0].bias, vh.layers[1].weight, vh.layers[1].bias)
+
+    def forward(self, x: Tensor, edge_index: Tensor, graph_indices, advantages_only=False, set_cache=False):
+        """Raw (pre-activation) ``advantages [N,1]`` (and ``value [B,1]``) like the reference head is NOT what
+        the fused kernel produces; DuellingTwoHeaded drives ``_tail`` directly.  Calling the head on its own
+        is supported only through DuellingTwoHeaded."""
+        raise NotImplementedError("HeadNetwork is evaluated through DuellingTwoHeaded.forward in this build")
+
+
+class DuellingTwoHeaded(torch.nn.Module):
+    """GN0/models.py:477-590."""
+
+    def __init__(self, GNN, advantage_head, gnn_kwargs, head_kwargs):
+        super().__init__()
+        self.gnn = GNN(**gnn_kwargs)
+        if "norm" in gnn_kwargs and gnn_kwargs["norm"]:
+            raise NotImplementedError("--norm=True is outside the accelerated hot path")
+        self.after_embed_norm = None
+        self.supports_cache = hasattr(self.gnn, "supports_cache") and self.gnn.supports_cache
+        self.value_activation = Tanh()
+        self.advantage_activation = Tanh()
+        h = gnn_kwargs["hidden_channels"]
+        self.maker_head = advantage_head(in_channels=h, hidden_channels=h, out_channels=1, **head_kwargs)
+        self.breaker_head = advantage_head(in_channels=h, hidden_channels=h, out_channels=1, **head_kwargs)
+        self.final_conv_acts = None
+        self.final_conv_grad = None
+
+    def grow_depth(self, additional_layers):
+        self.gnn.grow_depth(additional_layers)
+
+    def grow_width(self, new_width):
+        self.gnn.grow_width(new_width)
+        self.maker_head.grow_width(new_width, new_in_channels=new_width)
+        self.breaker_head.grow_width(new_width, new_in_channels=new_width)
+
+    def export_norm_cache(self, *args):
+        cache_list = []
+        for m in (self.gnn, self.maker_head, self.breaker_head):
+            if hasattr(m, "supports_cache") and m.supports_cache:
+                cache_list.append(m.export_norm_cache(*args))
+        return cache_list
+
+    def import_norm_cache(self, *args):
+        ind = 0
+        for m in (self.gnn, self.maker_head, self.breaker_head):
+            if hasattr(m, "supports_cache") and m.supports_cache:
+                if ind < len(args) and args[ind] is not None:
+                    m.import_norm_cache(*args[ind])
+                ind += 1
+
+    def activations_hook(self, grad):
+        self.final_conv_grads = grad
+
+    def forward(self, x: Tensor, edge_index, graph_indices: Optional[Tensor] = None, ptr: Optional[Tensor] = None,
+                set_cache: bool = False, advantages_only=False, seperate=False
+                ) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        """Same contract as GN0/models.py:537-584.
+
+        Host syncs of the reference (``x[0,2]`` at 538-539, ``graph_indices.max()`` at 576) are avoided when the
+        caller already knows the answers: ``ptr`` gives the graph count, and a ``Batch``/``Data`` built by
+        ``gnn_hex_amd`` (env manager, ``Batch.from_data_list``) carries the side to move as ``x._hex_is_maker``.
+        Without the hint the reference behaviour (assert + sync) is kept."""
+        ops._require_cuda(x, "x")
+        hint = getattr(x, "_hex_is_maker", None)
+        if hint is None:
+            assert torch.all(x[:, 2] == x[0, 2])
+            is_maker = bool(x[0, 2] == 1)
+        else:
+            is_maker = bool(hint)
+        n = x.shape[0]
+        x2 = x[:, :2]
+
+        gs = ops.GraphStructure(edge_index, n)           # edge_index CSR-sorted once per batch
+        embeds = self.gnn(x2, edge_index, set_cache=set_cache, _graph=gs)
+        self.final_conv_acts = embeds
+        if embeds.requires_grad:
+            embeds.register_hook(self.activations_hook)
+
+        head = self.maker_head if is_maker else self.breaker_head
+        hx = head.gnn(embeds, edge_index, set_cache=set_cache, _graph=gs)
+        gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
+        if advantages_only:
+            return head._tail(hx, gptr, b, 2).view(-1, 1)
+        if seperate:
+            v, a = head._tail(hx, gptr, b, 1)
+            return v.squeeze(), a.squeeze()
+        return head._tail(hx, gptr, b, 0).squeeze()
+
+    def simple_forward(self, data: Union[Data, Batch]):
+        if isinstance(data, Batch) or getattr(data, "batch", None) is not None:
+            return self.forward(data.x, data.edge_index, data.batch, getattr(data, "ptr", None))
+        return self.forward(data.x, data.edge_index)
+
+
+def get_pre_defined(name, args: Optional[Namespace] = None) -> torch.nn.Module:
+    """GN0/models.py:892-980.  Only ``modern_two_headed`` (the RainbowDQN GNN of README.md:5,7) is built."""
+    if name == "modern_two_headed":
+        if getattr(args, "norm", False):
+            raise NotImplementedError("--norm=True is outside the accelerated hot path")
+        return DuellingTwoHeaded(
+            cachify_gnn(GraphSAGE), HeadNetwork,
+            gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
+                            cached_norm=False, norm=None, act="relu"),
+            head_kwargs=dict(GNN=cachify_gnn(GraphSAGE), value_head_type="mlp",
+                             value_aggr_types=("sum", "max", "min", "mean"),
+                             num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2,
+                             noisy_dqn=args.noisy_dqn, noise_sigma=args.noisy_sigma0, cached_norm=False,
+                             norm=None, act="relu"))
+    raise NotImplementedError(
+        "%r: only 'modern_two_headed' is part of the MI355X hot path (SURVEY.md section 8)" % (name,))

@@ -1,0 +1,266 @@
+"""Host side of the HIP path: graph-structure build + ``torch.autograd.Function`` wrappers that hand raw
+device pointers and the current HIP stream to libhexgnn.so (include/hexgnn.h).
+
+PyTorch is plumbing here: allocator, stream, autograd bookkeeping.  All arithmetic of the hot path
+runs in the hand-written kernels under gnn_hex_amd/csrc; there is no eager/PyTorch fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _require_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.HexGnnError(
+            "%s is on %s: gnn_hex_amd runs only on the MI355X HIP path (no CPU fallback)" % (what, t.device))
+
+
+def padded_width(hidden: int) -> int:
+    hp = _lib.lib().hexgnn_padded_width(int(hidden))
+    if hp < 0:
+        raise _lib.HexGnnError("hidden_channels=%d not supported by the compiled kernels (1..128)" % hidden)
+    return hp
+
+
+def _bytes(nbytes: int, device) -> torch.Tensor:
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)
+
+
+def _ptr_array(tensors: Sequence[torch.Tensor]):
+    return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class GraphStructure:
+    """Target-major CSR of a batch + its transpose + 1/deg, built once per batch on the device.
+
+    rowptr/col: in-neighbours (sources) of every node, ascending; rowptr_t/col_t: out-neighbours.
+    Replaces the per-layer x[edge_index[0]] / scatter(edge_index[1]) indexing of the reference
+    (GN0/models.py:276)."""
+
+    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status")
+
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+        _require_cuda(edge_index, "edge_index")
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise ValueError("edge_index must be [2, E]")
+        if edge_index.dtype != torch.int64:
+            edge_index = edge_index.long()
+        edge_index = edge_index.contiguous()
+        dev = edge_index.device
+        n, e = int(num_nodes), int(edge_index.shape[1])
+        L = _lib.lib()
+        self.n, self.e = n, e
+        self.rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.rowptr_t = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        self.col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        self.col_t = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+        self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        self.status = torch.empty(1, dtype=torch.int32, device=dev)
+        ws_bytes = L.hexgnn_csr_workspace_bytes(n, e)
+        ws = _bytes(ws_bytes, dev)
+        src = edge_index[0]
+        dst = edge_index[1]
+        _lib.check(L.hexgnn_csr_build(n, e, src.data_ptr(), dst.data_ptr(), self.rowptr.data_ptr(),
+                                      self.col.data_ptr(), self.rowptr_t.data_ptr(), self.col_t.data_ptr(),
+                                      self.invdeg.data_ptr(), self.status.data_ptr(), ws.data_ptr(), ws_bytes,
+                                      _stream()), "hexgnn_csr_build")
+
+    def check(self) -> None:
+        """Host-synchronising validity check (debug aid; not called on the hot path)."""
+        if int(self.status.item()) != 0:
+            raise IndexError("edge_index contains node ids outside [0, %d)" % self.n)
+
+
+def graph_ptr(graph_indices: Optional[torch.Tensor], ptr: Optional[torch.Tensor], n: int, device):
+    """(gptr int32 [B+1] on device, B).  Uses ``ptr`` when given (no host sync); otherwise derives it from
+    the sorted ``graph_indices`` with B = max+1 -- the same host sync the reference has at
+    GN0/models.py:576."""
+    if ptr is not None:
+        b = int(ptr.numel()) - 1
+        return ptr.to(device=device, dtype=torch.int32), b
+    if graph_indices is None:
+        return torch.tensor([0, n], dtype=torch.int32, device=device), 1
+    _require_cuda(graph_indices, "graph_indices")
+    b = int(graph_indices.max()) + 1 if n > 0 else 0
+    gi = graph_indices.long().contiguous()
+    gptr = torch.empty(b + 1, dtype=torch.int32, device=device)
+    _lib.check(_lib.lib().hexgnn_graph_ptr(n, b, gi.data_ptr(), gptr.data_ptr(), _stream()), "hexgnn_graph_ptr")
+    return gptr, b
+
+
+# ------------------------------------------------------------------------------------------------
+# padded layout helpers
+# ------------------------------------------------------------------------------------------------
+
+def _is_padded_view(t: torch.Tensor, hidden: int, hp: int) -> bool:
+    if t.dim() != 2 or t.shape[1] != hidden or t.dtype != torch.float32:
+        return False
+    if t.shape[0] > 0 and t.stride() != (hp, 1):
+        return False
+    need = (t.storage_offset() + t.shape[0] * hp) * 4
+    return t.untyped_storage().nbytes() >= need and t.data_ptr() % 16 == 0
+
+
+def as_padded(t: torch.Tensor, hidden: int, trust_pads: bool) -> torch.Tensor:
+    """Return a [n, HP] tensor sharing memory with ``t`` when ``t`` already is a padded-layout view whose pad
+    columns are known to be zero (tensors produced by this module carry ``_hexgnn_hp``), or whose pads do
+    not matter (``trust_pads``: gradients, which the kernels mask); otherwise a zero-padded copy."""
+    hp = padded_width(hidden)
+    n = t.shape[0]
+    tagged = getattr(t, "_hexgnn_hp", None) == hp
+    if (tagged or trust_pads) and _is_padded_view(t, hidden, hp):
+        return torch.as_strided(t, (n, hp), (hp, 1))
+    _require_cuda(t, "feature matrix")
+    src = t if (t.stride(1) == 1 and t.dtype == torch.float32) else t.float().contiguous()
+    out = torch.empty((n, hp), dtype=torch.float32, device=t.device)
+    _lib.check(_lib.lib().hexgnn_pad_rows(n, hidden, src.data_ptr(), src.stride(0) if n > 0 else hidden,
+                                          out.data_ptr(), _stream()), "hexgnn_pad_rows")
+    return out
+
+
+def _logical(padded: torch.Tensor, hidden: int) -> torch.Tensor:
+    v = padded[:, :hidden]
+    v._hexgnn_hp = padded.shape[1]
+    return v
+
+
+# ------------------------------------------------------------------------------------------------
+# GraphSAGE stack
+# ------------------------------------------------------------------------------------------------
+
+class SageStackFn(torch.autograd.Function):
+    """y = relu(SAGE_L(... relu(SAGE_1(x)) ...)); CachifiedGNN.forward, GN0/models.py:261-294."""
+
+    @staticmethod
+    def forward(ctx, x, gs: GraphStructure, c_in: int, hidden: int, num_layers: int, *params):
+        L = _lib.lib()
+        dev = x.device
+        n = int(x.shape[0])
+        hp = padded_width(hidden)
+        small = c_in != hidden
+        if small:
+            if x.dtype != torch.float32 or x.stride(1) != 1:
+                x = x.float().contiguous()
+            xin, x_stride = x, (x.stride(0) if n > 0 else c_in)
+        else:
+            xin = as_padded(x, hidden, trust_pads=False)
+            x_stride = hp
+        params = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous() for p in params]
+        wl, bl, wr = params[0::3], params[1::3], params[2::3]
+        need_bwd = any(ctx.needs_input_grad)
+        acts = torch.empty((num_layers, n, hp), dtype=torch.float32, device=dev)
+        wpack = _bytes(L.hexgnn_sage_stack_pack_bytes(c_in, hidden, num_layers), dev)
+        saved = _bytes(L.hexgnn_sage_stack_saved_bytes(n, c_in, hidden, num_layers), dev) if need_bwd else None
+        _lib.check(L.hexgnn_sage_stack_forward(
+            n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
+            xin.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), wpack.data_ptr(),
+            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), _stream()),
+            "hexgnn_sage_stack_forward")
+        if need_bwd:
+            ctx.gs = gs
+            ctx.dims = (n, c_in, hidden, num_layers, hp, x_stride)
+            ctx.bufs = (xin, acts, saved, wpack)
+            ctx.param_shapes = [p.shape for p in params]
+        return acts[num_layers - 1][:, :hidden]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = _lib.lib()
+        n, c_in, hidden, num_layers, hp, x_stride = ctx.dims
+        xin, acts, saved, wpack = ctx.bufs
+        gs = ctx.gs
+        dev = acts.device
+        dy = as_padded(grad_out, hidden, trust_pads=True)
+        want_dx = ctx.needs_input_grad[0] and c_in == hidden
+        dx = torch.empty((n, hp), dtype=torch.float32, device=dev) if want_dx else None
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
+        ws_bytes = L.hexgnn_sage_stack_backward_workspace_bytes(n, c_in, hidden, num_layers)
+        ws = _bytes(ws_bytes, dev)
+        _lib.check(L.hexgnn_sage_stack_backward(
+            n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.rowptr_t.data_ptr(),
+            gs.col_t.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(), x_stride, acts.data_ptr(),
+            saved.data_ptr(), wpack.data_ptr(), dy.data_ptr(), dx.data_ptr() if dx is not None else None,
+            _ptr_array(grads[0::3]), _ptr_array(grads[1::3]), _ptr_array(grads[2::3]), ws.data_ptr(), ws_bytes,
+            _stream()), "hexgnn_sage_stack_backward")
+        gx = _logical(dx, hidden) if dx is not None else None
+        return (gx, None, None, None, None) + tuple(grads)
+
+
+def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, convs) -> torch.Tensor:
+    """Run a stack of SAGEConv parameter holders (objects with lin_l.weight/bias, lin_r.weight)."""
+    _require_cuda(x, "x")
+    params: List[torch.Tensor] = []
+    for conv in convs:
+        params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
+    out = SageStackFn.apply(x, gs, c_in, hidden, len(convs), *params)
+    out._hexgnn_hp = padded_width(hidden)
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# head tail (advantage linear + pooling + value MLP + dueling combine)
+# ------------------------------------------------------------------------------------------------
+
+class HeadTailFn(torch.autograd.Function):
+    """mode 0: Q [n]; mode 1: (V [b], A - mean(A) [n]); mode 2: 2*tanh(adv) [n].  GN0/models.py:374-384,567-584."""
+
+    @staticmethod
+    def forward(ctx, h, gptr, b: int, hidden: int, mode: int, lin_w, lin_b, v0_w, v0_b, v1_w, v1_b):
+        L = _lib.lib()
+        dev = h.device
+        n = int(h.shape[0])
+        hp = padded_width(hidden)
+        hpad = as_padded(h, hidden, trust_pads=False)
+        ps = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous()
+              for p in (lin_w, lin_b, v0_w, v0_b, v1_w, v1_b)]
+        q = torch.empty(n, dtype=torch.float32, device=dev)
+        out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+        saved = _bytes(L.hexgnn_head_saved_bytes(n, b, hidden), dev)
+        _lib.check(L.hexgnn_head_forward(
+            n, b, hidden, mode, gptr.data_ptr(), hpad.data_ptr(), ps[0].data_ptr(), ps[1].data_ptr(),
+            ps[2].data_ptr(), ps[3].data_ptr(), ps[4].data_ptr(), ps[5].data_ptr(), q.data_ptr(),
+            out_v.data_ptr() if out_v is not None else None, saved.data_ptr(), _stream()), "hexgnn_head_forward")
+        ctx.dims = (n, b, hidden, mode, hp)
+        ctx.bufs = (hpad, gptr, saved, ps)
+        if mode == 1:
+            return out_v, q
+        return q
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        L = _lib.lib()
+        n, b, hidden, mode, hp = ctx.dims
+        hpad, gptr, saved, ps = ctx.bufs
+        dev = hpad.device
+        if mode == 1:
+            d_v, dq = gouts
+            if d_v is None:
+                d_v = torch.zeros(b, dtype=torch.float32, device=dev)
+            if dq is None:
+                dq = torch.zeros(n, dtype=torch.float32, device=dev)
+            d_v = d_v.float().contiguous()
+        else:
+            (dq,) = gouts
+            d_v = None
+        dq = dq.float().contiguous()
+        dh = torch.empty((n, hp), dtype=torch.float32, device=dev)
+        g = [torch.empty_like(p) for p in ps]
+        ws_bytes = L.hexgnn_head_backward_workspace_bytes(n, b, hidden)
+        ws = _bytes(ws_bytes, dev)
+        _lib.check(L.hexgnn_head_backward(
+            n, b, hidden, mode, gptr.data_ptr(), hpad.data_ptr(), ps[0].data_ptr(), ps[2].data_ptr(),
+            ps[4].data_ptr(), saved.data_ptr(), dq.data_ptr(), d_v.data_ptr() if d_v is not None else None,
+            dh.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(),
+            g[5].data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "hexgnn_head_backward")
+        if mode == 2:   # value path unused: no gradient for the value head (reference: grads stay None)
+            g[2] = g[3] = g[4] = g[5] = None
+        return (_logical(dh, hidden), None, None, None, None) + tuple(g)

@@ -1,0 +1,128 @@
+/* hexgnn.h -- C ABI of libhexgnn.so: the MI355X (gfx950) hot path of GNN_Hex's RainbowDQN loop.
+ *
+ * The reference (yannikkellerde/GNN_Hex) has no FFI for this path: its boundary is two Python
+ * surfaces, GN0.models.get_pre_defined("modern_two_headed") and
+ * graph_game.multi_env_manager.Env_manager.  gnn_hex_amd/ mirrors those surfaces in Python and
+ * binds THIS header through ctypes; every entry point below names the reference code it replaces.
+ *
+ * Conventions
+ *   - plain pointers and sizes; every pointer is a DEVICE pointer unless its comment says HOST.
+ *   - stream-ordered: work is enqueued on `stream` (a hipStream_t passed as void*); no call
+ *     synchronises, allocates or frees device memory (scratch is passed in, sized by *_bytes()).
+ *   - returns 0 (HEXGNN_OK) or a negative HEXGNN_E* code; never throws.
+ *   - node features are fp32 rows padded to HP = hexgnn_padded_width(hidden) = 16*ceil(hidden/16)
+ *     floats ("padded layout"); pad columns are zero on output and must be zero on input.
+ *   - indices on the device are int32 (N, E < 2^31); int64 only where the reference API has int64.
+ *   - re-entrant; a hexgnn_env handle must not be used from two threads at once.
+ */
+#ifndef HEXGNN_H
+#define HEXGNN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HEXGNN_ABI_VERSION 1
+
+#define HEXGNN_OK 0
+#define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
+#define HEXGNN_EUNSUPPORTED (-2) /* shape outside the compiled kernels (hidden > 128, c_in > 8, ...) */
+#define HEXGNN_EWORKSPACE (-3)   /* workspace smaller than the matching *_bytes() query */
+#define HEXGNN_EHIP (-4)         /* HIP runtime reported an error at launch (see hexgnn_last_hip_error) */
+
+typedef void* hexgnn_stream_t; /* hipStream_t */
+
+/* ---- library ------------------------------------------------------------------------------ */
+int hexgnn_abi_version(void);
+const char* hexgnn_strerror(int code);
+int hexgnn_last_hip_error(void);      /* last hipError_t seen by this thread's failing call */
+int hexgnn_padded_width(int hidden);  /* HP; <0 if unsupported */
+
+/* ---- graph structure ---------------------------------------------------------------------- */
+/* Replaces the per-call edge_index indexing of torch_geometric MessagePassing.propagate
+ * (x[edge_index[0]] gather + scatter onto edge_index[1]; call site GN0/models.py:276): the COO
+ * list is sorted ONCE per batch into a target-major CSR (rowptr/col: in-neighbours of each node,
+ * ascending) and its transpose (rowptr_t/col_t: out-neighbours, used by the backward gather).
+ * invdeg[i] = 1/max(in_degree(i),1) (torch_scatter mean: count.clamp(min=1)).
+ * status[0] is set non-zero if an index was outside [0,n) (such edges are dropped).
+ * src/dst: the two rows of edge_index (int64, length e). */
+size_t hexgnn_csr_workspace_bytes(int n, int e);
+int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst,
+                     int* rowptr /*[n+1]*/, int* col /*[e]*/, int* rowptr_t /*[n+1]*/, int* col_t /*[e]*/,
+                     float* invdeg /*[n]*/, int* status /*[1]*/,
+                     void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+
+/* Replaces the segment lookup inside torch_scatter.scatter(x, graph_indices) (GN0/models.py:381,578)
+ * and torch_geometric Batch.ptr: batch (int64, sorted ascending, values in [0,b)) -> gptr[b+1]. */
+int hexgnn_graph_ptr(int n, int b, const int64_t* batch, int* gptr /*[b+1]*/, hexgnn_stream_t stream);
+
+/* ---- GraphSAGE stack (CachifiedGNN.forward, GN0/models.py:261-294; SAGEConv semantics
+ *      GN0/torch_script_models.py:52-73): y_i = W_l * mean_{j in N(i)} x_j + b_l + W_r * x_i, ReLU
+ *      after every layer.  Layer 0 maps c_in -> hidden, the rest hidden -> hidden.
+ *      c_in <= 8 (raw features, row stride x_stride floats) or c_in == hidden (padded layout).
+ *      wl/bl/wr: HOST arrays (num_layers entries) of device pointers to the torch parameters
+ *      lin_l.weight [out,in], lin_l.bias [out], lin_r.weight [out,in]. ------------------------ */
+size_t hexgnn_sage_stack_pack_bytes(int c_in, int hidden, int num_layers);
+size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers);
+/* acts:  [num_layers][n][HP] outputs of every layer (post-ReLU); the last slab is the result.
+ * saved: aggregated inputs of every layer, kept for the backward pass (may be NULL when
+ *        need_backward == 0).  wpack: scratch of hexgnn_sage_stack_pack_bytes(), also read by the
+ *        backward call of the same step. */
+int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers,
+                              const int* rowptr, const int* col, const float* invdeg,
+                              const float* x, int x_stride,
+                              const float* const* wl, const float* const* bl, const float* const* wr,
+                              void* wpack, float* acts, void* saved, int need_backward,
+                              hexgnn_stream_t stream);
+
+size_t hexgnn_sage_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers);
+/* dy: gradient w.r.t. the stack output, padded layout [n][HP].
+ * dx: gradient w.r.t. the stack input, padded layout [n][HP]; NULL to skip (always skipped when
+ *     c_in != hidden).  d_wl/d_bl/d_wr: HOST arrays of device pointers, written (not accumulated),
+ *     same shapes as the parameters.  Deterministic: fixed reduction order, no float atomics. */
+int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers,
+                               const int* rowptr, const int* col,
+                               const int* rowptr_t, const int* col_t, const float* invdeg,
+                               const float* x, int x_stride,
+                               const float* acts, const void* saved, const void* wpack,
+                               const float* dy, float* dx,
+                               float* const* d_wl, float* const* d_bl, float* const* d_wr,
+                               void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+
+/* ---- head tail: HeadNetwork.forward after its gnn (GN0/models.py:374-384), MLP value head
+ *      (GN0/models.py:36-82: Linear(4H,H/2) -> relu -> Linear(H/2,1)) and the dueling combine of
+ *      DuellingTwoHeaded.forward (GN0/models.py:567-584).
+ *      mode 0: q[n]   = tanh(v)[g] + 2tanh(a) - mean_g(2tanh(a))
+ *      mode 1: out_v[b] = tanh(v), q[n] = 2tanh(a) - mean_g(2tanh(a))          (seperate=True)
+ *      mode 2: q[n]   = 2tanh(a); pooling / value path skipped                  (advantages_only=True)
+ *      Pooled order is [sum | max | min | mean] (value_aggr_types, GN0/models.py:940); max/min route
+ *      their gradient to the FIRST row attaining the extremum (torch_scatter CPU kernel). -------- */
+size_t hexgnn_head_saved_bytes(int n, int b, int hidden);
+int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, const float* h /*[n][HP]*/,
+                        const float* lin_w /*[hidden]*/, const float* lin_b /*[1]*/,
+                        const float* v0_w /*[hidden/2][4*hidden]*/, const float* v0_b /*[hidden/2]*/,
+                        const float* v1_w /*[hidden/2]*/, const float* v1_b /*[1]*/,
+                        float* q /*[n]*/, float* out_v /*[b] (mode 1) or NULL*/,
+                        void* saved, hexgnn_stream_t stream);
+size_t hexgnn_head_backward_workspace_bytes(int n, int b, int hidden);
+/* dq: gradient of q [n]; d_out_v: gradient of out_v [b] (mode 1) or NULL.
+ * dh: [n][HP] gradient w.r.t. h (padded layout, written).  Parameter gradients written. */
+int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, const float* h,
+                         const float* lin_w, const float* v0_w, const float* v1_w,
+                         const void* saved, const float* dq, const float* d_out_v,
+                         float* dh, float* d_lin_w, float* d_lin_b,
+                         float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
+                         void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+
+/* ---- layout helpers (host tensors <-> padded layout) ---------------------------------------- */
+/* dst[n][HP] <- src[n][hidden] (row stride src_stride floats), pad columns zeroed; and back. */
+int hexgnn_pad_rows(int n, int hidden, const float* src, int src_stride, float* dst, hexgnn_stream_t stream);
+int hexgnn_unpad_rows(int n, int hidden, const float* src, float* dst, int dst_stride, hexgnn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HEXGNN_H */

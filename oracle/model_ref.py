@@ -1,0 +1,244 @@
+"""CPU restatement of the reference's ``modern_two_headed`` Q-network.
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  PARITY UNPINNED: the
+reference executes this path through torch_geometric 2.2.0 (``GraphSAGE`` /
+``BasicGNN`` / ``SAGEConv``) and torch_scatter 2.1.0 (``scatter``), neither of
+which is vendored or installed; the reference's tests pin no number for it.
+This file restates the published algorithm of those packages op for op, anchored
+on the reference's own call sites:
+
+* ``MLPRef``                <- GN0/models.py:36-82
+* ``SAGEConvRef``           <- GN0/torch_script_models.py:52-73 (in-tree restatement
+                               of pyg SAGEConv: lin_l(mean_j x_j) + lin_r(x_i),
+                               bias on lin_l only, GN0/models.py:175-177)
+* ``GraphSAGERef``          <- GN0/torch_script_models.py:96-144 (layer layout) and
+                               GN0/models.py:144-164,261-294 (CachifiedGNN loop:
+                               ReLU after EVERY layer because out_channels=None)
+* ``HeadNetworkRef``        <- GN0/models.py:318-384
+* ``DuellingTwoHeadedRef``  <- GN0/models.py:477-590
+* ``get_pre_defined_ref``   <- GN0/models.py:892-947 (``modern_two_headed`` only)
+* ``scatter_ref``           <- torch_scatter 2.1.0 ``scatter`` (sum / mean / max /
+                               min over dim 0; mean divides by max(count,1); max/min
+                               send their gradient to the FIRST index that attains
+                               the extremum, as the CPU kernel's strict comparison does)
+
+Execution structure mirrors the reference on purpose (materialised ``[E, C]``
+gather, scatter, two linears per layer): ``bench.py`` times it as the CPU
+baseline ("CPU restatement of the torch_geometric path").
+"""
+from __future__ import annotations
+
+from argparse import Namespace
+from typing import Optional, Tuple, Union
+
+import torch
+import torch.nn.functional as F
+from torch import Tensor
+
+
+def scatter_ref(src: Tensor, index: Tensor, dim_size: Optional[int] = None, reduce: str = "sum") -> Tensor:
+    """torch_scatter.scatter(src, index, dim=0, dim_size=..., reduce=...)."""
+    if dim_size is None:
+        dim_size = int(index.max()) + 1 if index.numel() > 0 else 0
+    tail = src.shape[1:]
+    if reduce in ("sum", "add", "mean"):
+        out = src.new_zeros((dim_size,) + tuple(tail))
+        out = out.index_add(0, index, src)
+        if reduce == "mean":
+            cnt = src.new_zeros(dim_size).index_add(0, index, src.new_ones(index.numel()))
+            cnt = cnt.clamp(min=1)
+            out = out / cnt.view((-1,) + (1,) * len(tail))
+        return out
+    if reduce in ("max", "min"):
+        flat = src.reshape(src.shape[0], -1)
+        n, c = flat.shape
+        idx = index.view(-1, 1).expand(n, c)
+        red = "amax" if reduce == "max" else "amin"
+        with torch.no_grad():
+            ext = torch.full((dim_size, c), float("-inf") if reduce == "max" else float("inf"),
+                             dtype=src.dtype).scatter_reduce(0, idx, flat, red, include_self=True)
+            hit = flat == ext.index_select(0, index)
+            pos = torch.arange(n).view(-1, 1).expand(n, c)
+            cand = torch.where(hit, pos, torch.full_like(pos, n))
+            arg = torch.full((dim_size, c), n, dtype=torch.long).scatter_reduce(
+                0, idx, cand, "amin", include_self=True)
+            empty = arg >= n
+            arg = arg.clamp(max=max(n - 1, 0))
+        out = flat.gather(0, arg)
+        out = torch.where(empty, torch.zeros_like(out), out)  # empty segments -> 0
+        return out.view((dim_size,) + tuple(tail))
+    raise ValueError(reduce)
+
+
+class MLPRef(torch.nn.Module):
+    """GN0/models.py:36-82 (grow_input_width omitted: parameter surgery, not arithmetic)."""
+
+    def __init__(self, hidden_channels, num_hidden_layers, num_input, num_output, output_activation=None):
+        super().__init__()
+        self.layers = torch.nn.ModuleList()
+        self.num_input = num_input
+        self.num_output = num_output
+        self.hidden_channels = hidden_channels
+        if num_hidden_layers == 0:
+            self.layers.append(torch.nn.Linear(num_input, num_output))
+        else:
+            self.layers.append(torch.nn.Linear(num_input, hidden_channels))
+            for _ in range(num_hidden_layers - 1):
+                self.layers.append(torch.nn.Linear(hidden_channels, hidden_channels))
+            self.layers.append(torch.nn.Linear(hidden_channels, num_output))
+        self.output_activation = output_activation
+
+    def forward(self, x):
+        for layer in self.layers:
+            x = layer(x)
+            if layer is not self.layers[-1]:
+                x = F.relu(x)
+        if self.output_activation is not None:
+            x = self.output_activation(x)
+        return x
+
+
+class SAGEConvRef(torch.nn.Module):
+    """pyg SAGEConv(aggr='mean', root_weight=True, bias=True), torch_script_models.py:52-73."""
+
+    def __init__(self, in_channels: int, out_channels: int):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.lin_l = torch.nn.Linear(in_channels, out_channels, bias=True)
+        self.lin_r = torch.nn.Linear(in_channels, out_channels, bias=False)
+
+    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+        src, dst = edge_index[0], edge_index[1]
+        x_j = x.index_select(0, src)                                     # propagate: gather [E, C]
+        out = scatter_ref(x_j, dst, dim_size=x.size(0), reduce="mean")   # aggregate at the targets
+        out = self.lin_l(out)
+        out = out + self.lin_r(x)
+        return out
+
+
+class GraphSAGERef(torch.nn.Module):
+    """BasicGNN layout (torch_script_models.py:118-144) + CachifiedGNN loop (models.py:261-294)."""
+
+    supports_cache = True
+
+    def __init__(self, in_channels: int, hidden_channels: int, num_layers: int,
+                 out_channels: Optional[int] = None, norm=None, act="relu", cached_norm=False, **_):
+        super().__init__()
+        if norm is not None:
+            raise NotImplementedError("oracle covers norm=None only (all BASELINE configs use --norm=False)")
+        self.in_channels = in_channels
+        self.hidden_channels = hidden_channels
+        self.num_layers = num_layers
+        self.has_output = out_channels is not None
+        self.out_channels = out_channels if out_channels is not None else hidden_channels
+        self.convs = torch.nn.ModuleList()
+        c = in_channels
+        if num_layers > 1:
+            self.convs.append(SAGEConvRef(c, hidden_channels))
+            c = hidden_channels
+        for _ in range(num_layers - 2):
+            self.convs.append(SAGEConvRef(c, hidden_channels))
+            c = hidden_channels
+        self.convs.append(SAGEConvRef(c, self.out_channels))
+        self.norms = None
+
+    def forward(self, x: Tensor, edge_index: Tensor, set_cache: bool = False) -> Tensor:
+        for i in range(self.num_layers):
+            x = self.convs[i](x, edge_index)
+            if i == self.num_layers - 1 and self.has_output:
+                break
+            x = F.relu(x)
+        return x
+
+
+class HeadNetworkRef(torch.nn.Module):
+    """GN0/models.py:318-384 with noisy_dqn=False."""
+
+    def __init__(self, in_channels, hidden_channels, out_channels, value_head_type="linear",
+                 value_aggr_types=("mean",), num_layers=2, **_):
+        super().__init__()
+        self.gnn = GraphSAGERef(in_channels=in_channels, hidden_channels=hidden_channels, num_layers=num_layers)
+        self.supports_cache = True
+        self.value_head_type = value_head_type
+        self.hidden_channels = hidden_channels
+        if value_head_type == "linear":
+            self.value_head = torch.nn.Linear(hidden_channels * len(value_aggr_types), 1)
+        else:
+            self.value_head = MLPRef(hidden_channels // 2, 1, hidden_channels * len(value_aggr_types), 1)
+        self.out_channels = out_channels
+        self.value_aggr_types = value_aggr_types
+        self.linear = torch.nn.Linear(hidden_channels, out_channels)
+
+    def forward(self, x, edge_index, graph_indices, advantages_only=False, set_cache=False):
+        x = self.gnn(x, edge_index)
+        advantages = self.linear(x)
+        if advantages_only:
+            return advantages
+        parts = [scatter_ref(x, graph_indices, reduce=a) for a in self.value_aggr_types]
+        graph_parts = torch.cat(parts, dim=1)
+        value = self.value_head(graph_parts)
+        return advantages, value
+
+
+class DuellingTwoHeadedRef(torch.nn.Module):
+    """GN0/models.py:477-590."""
+
+    def __init__(self, gnn_kwargs, head_kwargs):
+        super().__init__()
+        self.gnn = GraphSAGERef(**gnn_kwargs)
+        self.after_embed_norm = None
+        self.supports_cache = True
+        self.value_activation = torch.nn.Tanh()
+        self.advantage_activation = torch.nn.Tanh()
+        h = gnn_kwargs["hidden_channels"]
+        self.maker_head = HeadNetworkRef(in_channels=h, hidden_channels=h, out_channels=1, **head_kwargs)
+        self.breaker_head = HeadNetworkRef(in_channels=h, hidden_channels=h, out_channels=1, **head_kwargs)
+        self.final_conv_acts = None
+        self.final_conv_grads = None
+
+    def activations_hook(self, grad):
+        self.final_conv_grads = grad
+
+    def forward(self, x: Tensor, edge_index: Tensor, graph_indices: Optional[Tensor] = None,
+                ptr: Optional[Tensor] = None, set_cache: bool = False, advantages_only=False,
+                seperate=False) -> Union[Tensor, Tuple[Tensor, Tensor]]:
+        assert torch.all(x[:, 2] == x[0, 2])
+        is_maker = x[0, 2]
+        x = x[:, :2]
+        if graph_indices is None:
+            graph_indices = x.new_zeros(x.size(0), dtype=torch.long)
+        embeds = self.gnn(x, edge_index)
+        self.final_conv_acts = embeds
+        if embeds.requires_grad:
+            embeds.register_hook(self.activations_hook)
+        head = self.maker_head if is_maker == 1 else self.breaker_head
+        head_res = head(embeds, edge_index, graph_indices, advantages_only=advantages_only)
+        if advantages_only:
+            return 2 * self.advantage_activation(head_res)
+        advantages = 2 * self.advantage_activation(head_res[0])
+        value = self.value_activation(head_res[1])
+        batch_size = int(graph_indices.max()) + 1
+        adv_means = scatter_ref(advantages, graph_indices, dim_size=batch_size, reduce="mean")
+        if seperate:
+            return value.squeeze(), (advantages - adv_means.index_select(0, graph_indices)).squeeze()
+        return (value.index_select(0, graph_indices)
+                + (advantages - adv_means.index_select(0, graph_indices))).squeeze()
+
+    def simple_forward(self, data):
+        if hasattr(data, "batch") and data.batch is not None:
+            return self.forward(data.x, data.edge_index, data.batch, getattr(data, "ptr", None))
+        return self.forward(data.x, data.edge_index)
+
+
+def get_pre_defined_ref(name: str, args: Optional[Namespace] = None) -> torch.nn.Module:
+    """GN0/models.py:892-947, ``modern_two_headed`` branch only (norm / noisy off)."""
+    if name != "modern_two_headed":
+        raise NotImplementedError(name)
+    if getattr(args, "norm", False) or getattr(args, "noisy_dqn", False):
+        raise NotImplementedError("oracle covers --norm=False --noisy_dqn=False (README.md:5,7)")
+    return DuellingTwoHeadedRef(
+        gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
+                        cached_norm=False, norm=None, act="relu"),
+        head_kwargs=dict(value_head_type="mlp", value_aggr_types=("sum", "max", "min", "mean"),
+                         num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2))
