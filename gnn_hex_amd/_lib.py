@@ -39,6 +39,8 @@ _SIGS = {
     "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, sz, vp]),
+    "hexgnn_profile_enable": (ci, [ci]),
+    "hexgnn_profile_read": (ci, [vp, vp]),
     "hexgnn_pad_rows": (ci, [ci, ci, vp, ci, vp, vp]),
     "hexgnn_unpad_rows": (ci, [ci, ci, vp, vp, ci, vp]),
 }

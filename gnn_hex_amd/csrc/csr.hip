@@ -148,6 +148,7 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* 
     (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
     (void)hipMemsetAsync(status, 0, sizeof(int), stream);
     if (n > 0) (void)hipMemsetAsync(cur, 0, sizeof(int) * 2 * (size_t)n, stream);
+    KernelTimer kt(HEXGNN_K_CSR, stream);
     if (e > 0)
         csr_count_kernel<<<(e + 255) / 256, 256, 0, stream>>>(n, e, src, dst, rowptr, rowptr_t, status);
     csr_scan_kernel<<<2, 1024, 0, stream>>>(n + 1, rowptr, rowptr_t);

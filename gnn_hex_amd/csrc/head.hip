@@ -302,6 +302,7 @@ int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, con
     if (b == 0) return HEXGNN_OK;
     const HeadSaved s = head_saved_plan(n, b, hidden);
     char* sv = (char*)saved;
+    KernelTimer kt(HEXGNN_K_HEAD_FWD, (hipStream_t)stream_);
     head_fwd_kernel<<<b, 256, 0, (hipStream_t)stream_>>>(
         hidden, hp, mode, gptr, h, lin_w, lin_b, v0_w, v0_b, v1_w, v1_b, q, out_v, (float*)(sv + s.adv_off),
         (float*)(sv + s.pooled_off), (int*)(sv + s.amax_off), (int*)(sv + s.amin_off), (float*)(sv + s.z_off),
@@ -337,6 +338,7 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
     float* dvr = (float*)(ws + w.dvr_off);
     float* part = (float*)(ws + w.part_off);
     const int H2 = hidden / 2, H4 = 4 * hidden;
+    KernelTimer kt(HEXGNN_K_HEAD_BWD, st);
     if (b > 0)
         head_bwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, lin_w, v0_w, v1_w, (const float*)(sv + s.adv_off),
                                            (const int*)(sv + s.amax_off), (const int*)(sv + s.amin_off),

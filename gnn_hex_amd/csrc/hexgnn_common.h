@@ -20,6 +20,16 @@ inline int check_launch() {
     return HEXGNN_OK;
 }
 
+// RAII event pair around one launch of a profiled kernel class (profile.hip)
+extern int g_prof_class;
+void prof_begin(hipStream_t st);
+void prof_end(hipStream_t st);
+struct KernelTimer {
+    hipStream_t st; bool on;
+    KernelTimer(int cls, hipStream_t s) : st(s), on(cls == g_prof_class) { if (on) prof_begin(st); }
+    ~KernelTimer() { if (on) prof_end(st); }
+};
+
 inline int padded_width(int hidden) {
     if (hidden <= 0 || hidden > 16 * kMaxNT) return -1;
     return 16 * ((hidden + 15) / 16);

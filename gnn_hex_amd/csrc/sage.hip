@@ -483,6 +483,7 @@ static void launch_fwd(int n, const int* rowptr, const int* col, const float* in
         return true;
     }();
     (void)once;
+    KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
     sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
         n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg);
 }
@@ -497,12 +498,14 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
         return true;
     }();
     (void)once;
+    KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
     sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
         n, rowptr_t, col_t, invdeg, dxs_in, dagg_in, y, (const f32x4*)wpb, g_out, dagg_out, dxs_out);
 }
 
 template <int NT>
 static void launch_dw(const DwArgs& a, int layers, float* part, hipStream_t st) {
+    KernelTimer kt(HEXGNN_K_SAGE_DW, st);
     sage_dw_kernel<NT><<<dim3(a.S, layers), 64 * NT, 0, st>>>(a, part);
 }
 
@@ -597,6 +600,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
         const float* bias = (const float*)(wp + p.bias_off[l]);
         float* agg = need_backward ? (float*)(sv + p.agg_off[l]) : nullptr;
         if (l == 0 && p.small_first) {
+            KernelTimer kt(HEXGNN_K_SAGE_FIRST, st);
             sage_first_fwd_kernel<<<(n + 31) / 32, 256, 0, st>>>(n, c_in, p.hp, rowptr, col, invdeg, x, x_stride,
                                                               (const float*)(wp + p.fwd_off[0]), bias, y, agg);
         } else {
@@ -671,8 +675,10 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
     const unsigned cgrid = (unsigned)(((int64_t)n * q4 + 255) / 256);
     if (p.small_first) {
         // G_0 = (dXs_1 + gather dAggS_1) * [y_0 > 0]   (or dy * mask when the stack is a single raw layer)
+        KernelTimer kt(HEXGNN_K_COMBINE, st);
         sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, acts, G);
     } else if (dx) {
+        KernelTimer kt(HEXGNN_K_COMBINE, st);
         sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, nullptr, dx);
     }
 

@@ -117,6 +117,22 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
                          float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
                          void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
 
+/* ---- in-library kernel timing: HIP events recorded on the launch stream around every launch of ONE
+ *      kernel class (bench.py's live roofline measurement; torch.cuda.Event would only see torch's current
+ *      stream and whole calls).  Not for use under graph capture. --------------------------------------- */
+#define HEXGNN_K_SAGE_FWD 0   /* sage_hidden_fwd_kernel  (gather + MFMA, one launch per hidden-input layer) */
+#define HEXGNN_K_SAGE_BWD 1   /* sage_hidden_bwd_kernel  (gradient gather + MFMA) */
+#define HEXGNN_K_SAGE_DW 2    /* sage_dw_kernel          (batched weight-gradient GEMM) */
+#define HEXGNN_K_HEAD_FWD 3
+#define HEXGNN_K_HEAD_BWD 4
+#define HEXGNN_K_SAGE_FIRST 5 /* raw-feature first layer forward */
+#define HEXGNN_K_COMBINE 6
+#define HEXGNN_K_CSR 7        /* the four CSR-build kernels together */
+#define HEXGNN_K_COUNT 8
+int hexgnn_profile_enable(int kernel_class); /* -1: off.  Clears earlier samples. */
+/* Waits for the recorded events; returns the number of launches and their summed duration. */
+int hexgnn_profile_read(int* launches, float* total_ms);
+
 /* ---- layout helpers (host tensors <-> padded layout) ---------------------------------------- */
 /* dst[n][HP] <- src[n][hidden] (row stride src_stride floats), pad columns zeroed; and back. */
 int hexgnn_pad_rows(int n, int hidden, const float* src, int src_stride, float* dst, hexgnn_stream_t stream);
