@@ -35,7 +35,8 @@ CONFIGS = {
     "MIX": (15, 110, lambda b: [5 + (g % 9) for g in range(b)], "GNN-L mixed Hex-5..13 ragged batch=256"),
 }
 
-KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel"}
+KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel",
+          8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
 
 
 def bytes_fwd(n, e, c):
@@ -94,6 +95,7 @@ def main():
         sel, tgt = sel_and_targets(ptr)
         xd = x.to(dev)
         xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
+        xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
         batches.append(dict(x=xd, ei=ei.to(dev), bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
 
@@ -132,7 +134,7 @@ def main():
         # ---- live per-kernel timing (HIP events on the launch stream) over the same steps ---------------
         L = _lib.lib()
         per_kernel = {}
-        for cls in (0, 1, 2):
+        for cls in (0, 1, 2, 8, 9):
             L.hexgnn_profile_enable(cls)
             for i in range(args.steps):
                 step_local(hip, batches, i)
@@ -143,12 +145,16 @@ def main():
         L.hexgnn_profile_enable(-1)
         n = (batches[0]["n"] + batches[1]["n"]) / 2.0
         e = (batches[0]["e"] + batches[1]["e"]) / 2.0
+        per_kernel = {k: v for k, v in per_kernel.items() if v[0] > 0}
         dom = max(per_kernel, key=lambda k: per_kernel[k][1])
         launches, tot_ms = per_kernel[dom]
         avg_s = tot_ms / max(launches, 1) * 1e-3
         hidden_layers = num_layers + 1          # hidden-input SAGE layers per step: (L-1) body + 2 head
         if dom in (0, 1):   # gather kernels: HBM roofline on the un-fused aggregation bytes of ONE layer
             alg = bytes_fwd(n, e, hidden)          # bytes per launch (one layer, one direction)
+            roof = dict(bound="hbm", achieved=alg / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
+        elif dom in (8, 9):  # fused per-graph kernels: one launch = all layers of one direction
+            alg = bytes_fwd(n, e, 2) + hidden_layers * bytes_fwd(n, e, hidden)
             roof = dict(bound="hbm", achieved=alg / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         else:               # batched weight-gradient GEMM: fp32 MFMA roofline (flops per launch = per-step / launches)
             flops = 2.0 * n * (2 * hidden) * hidden * hidden_layers / (launches / args.steps)

@@ -39,6 +39,13 @@ _SIGS = {
     "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, sz, vp]),
+    "hexgnn_qnet_supported": (ci, [ci, ci, ci]),
+    "hexgnn_qnet_saved_bytes": (sz, [ci, ci, ci, ci, ci]),
+    "hexgnn_qnet_forward": (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                 vp, vp, vp, ci, vp, vp, vp, vp]),
+    "hexgnn_qnet_backward_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
+    "hexgnn_qnet_backward": (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp,
+                                  vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
     "hexgnn_profile_enable": (ci, [ci]),
     "hexgnn_profile_read": (ci, [vp, vp]),
     "hexgnn_pad_rows": (ci, [ci, ci, vp, ci, vp, vp]),

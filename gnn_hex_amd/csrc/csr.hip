@@ -20,30 +20,49 @@ __global__ void csr_count_kernel(int n, int e, const int64_t* __restrict__ src, 
     atomicAdd(&rowptr_t[s + 1], 1);
 }
 
-// ---- 2. in-place inclusive scan of m ints, one 1024-thread workgroup per array -------------------
-__global__ __launch_bounds__(1024) void csr_scan_kernel(int m, int* __restrict__ a0, int* __restrict__ a1) {
-    int* a = blockIdx.x == 0 ? a0 : a1;
-    __shared__ int wsum[16];
+// ---- 2. in-place inclusive scan of m ints, two coalesced phases; blockIdx.y selects the array --------
+// phase A: every 256-thread workgroup scans its tile of 1024 ints in place and publishes the tile total.
+__global__ __launch_bounds__(256) void csr_scan_local_kernel(int m, int* __restrict__ a0, int* __restrict__ a1,
+                                                           int* __restrict__ tsum0, int* __restrict__ tsum1) {
+    int* a = blockIdx.y == 0 ? a0 : a1;
+    int* tsum = blockIdx.y == 0 ? tsum0 : tsum1;
+    __shared__ int wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int per = (m + 1023) / 1024;
-    const int beg = tid * per, end = min(beg + per, m);
-    int sum = 0;
-    for (int i = beg; i < end; ++i) sum += a[i];
-    // wave inclusive scan of the per-thread sums
-    int inc = sum;
+    const int base = blockIdx.x * 1024 + tid * 4;
+    int v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = base + k < m ? a[base + k] : 0;
+    v[1] += v[0]; v[2] += v[1]; v[3] += v[2];
+    int inc = v[3];
     for (int off = 1; off < 64; off <<= 1) {
-        int v = __shfl_up(inc, off);
-        if (lane >= off) inc += v;
+        const int t = __shfl_up(inc, off);
+        if (lane >= off) inc += t;
     }
     if (lane == 63) wsum[wave] = inc;
     __syncthreads();
-    if (tid == 0) {
-        int c = 0;
-        for (int w = 0; w < 16; ++w) { int t = wsum[w]; wsum[w] = c; c += t; }
-    }
+    int pre = inc - v[3];
+    for (int w = 0; w < wave; ++w) pre += wsum[w];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < m) a[base + k] = v[k] + pre;
+    if (tid == 255) tsum[blockIdx.x] = pre + v[3];
+}
+// phase B: add the totals of all preceding tiles.
+__global__ __launch_bounds__(256) void csr_scan_fix_kernel(int m, int* __restrict__ a0, int* __restrict__ a1,
+                                                         const int* __restrict__ tsum0, const int* __restrict__ tsum1) {
+    if (blockIdx.x == 0) return;
+    int* a = blockIdx.y == 0 ? a0 : a1;
+    const int* tsum = blockIdx.y == 0 ? tsum0 : tsum1;
+    __shared__ int wsum[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int part = 0;
+    for (int j = tid; j < (int)blockIdx.x; j += 256) part += tsum[j];
+    for (int off = 32; off >= 1; off >>= 1) part += __shfl_xor(part, off);
+    if (lane == 0) wsum[wave] = part;
     __syncthreads();
-    int run = wsum[wave] + inc - sum;  // exclusive prefix of this thread's chunk
-    for (int i = beg; i < end; ++i) { run += a[i]; a[i] = run; }
+    const int pre = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const int base = blockIdx.x * 1024 + tid * 4;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) if (base + k < m) a[base + k] += pre;
 }
 
 // ---- 3. fill (arrival order within a row is arbitrary; step 4 sorts every row) -------------------
@@ -132,7 +151,8 @@ int hexgnn_padded_width(int hidden) { return padded_width(hidden); }
 size_t hexgnn_csr_workspace_bytes(int n, int e) {
     (void)e;
     if (n < 0) return 0;
-    return align_up(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1), 256);
+    const size_t tiles = ((size_t)n + 1 + 1023) / 1024;
+    return align_up(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1), 256) + align_up(sizeof(int) * 2 * tiles, 256);
 }
 
 int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* rowptr, int* col,
@@ -144,6 +164,9 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* 
     if (workspace_bytes < hexgnn_csr_workspace_bytes(n, e) || !workspace) return HEXGNN_EWORKSPACE;
     int* cur = (int*)workspace;
     int* cur_t = cur + n;
+    const int tiles = (n + 1 + 1023) / 1024;
+    int* tsum = (int*)((char*)workspace + align_up(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1), 256));
+    int* tsum_t = tsum + tiles;
     (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(n + 1), stream);
     (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
     (void)hipMemsetAsync(status, 0, sizeof(int), stream);
@@ -151,7 +174,8 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* 
     KernelTimer kt(HEXGNN_K_CSR, stream);
     if (e > 0)
         csr_count_kernel<<<(e + 255) / 256, 256, 0, stream>>>(n, e, src, dst, rowptr, rowptr_t, status);
-    csr_scan_kernel<<<2, 1024, 0, stream>>>(n + 1, rowptr, rowptr_t);
+    csr_scan_local_kernel<<<dim3(tiles, 2), 256, 0, stream>>>(n + 1, rowptr, rowptr_t, tsum, tsum_t);
+    if (tiles > 1) csr_scan_fix_kernel<<<dim3(tiles, 2), 256, 0, stream>>>(n + 1, rowptr, rowptr_t, tsum, tsum_t);
     if (e > 0)
         csr_fill_kernel<<<(e + 255) / 256, 256, 0, stream>>>(n, e, src, dst, rowptr, rowptr_t, cur, cur_t, col, col_t);
     if (n > 0)

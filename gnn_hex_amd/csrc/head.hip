@@ -5,14 +5,11 @@
 // DuellingTwoHeaded.forward GN0/models.py:567-584, torch_scatter.scatter (sum/max/min/mean).
 // HBM/L2-bound (reads h once forward, writes dh once backward); no MFMA: the dense parts are
 // [1 x 4H] x [4H x H/2] per graph.
-#include "hexgnn_common.h"
+#include "hexgnn_internal.h"
 
 namespace hexgnn {
 
-struct HeadSaved {
-    size_t adv_off, pooled_off, amax_off, amin_off, z_off, v_off, total;
-};
-static HeadSaved head_saved_plan(int n, int b, int hidden) {
+HeadSaved head_saved_plan(int n, int b, int hidden) {
     HeadSaved s;
     size_t off = 0;
     const int h2 = hidden / 2;
@@ -26,20 +23,14 @@ static HeadSaved head_saved_plan(int n, int b, int hidden) {
     return s;
 }
 
-struct HeadWs {
-    size_t dadv_off, dz_off, dvr_off, part_off, total;
-    int S, rps;
-};
-static HeadWs head_ws_plan(int n, int b, int hidden) {
+HeadWs head_ws_plan(int n, int b, int hidden) {
     HeadWs w;
     const int hp = padded_width(hidden), h2 = hidden / 2;
     size_t off = 0;
     w.dadv_off = off; off += align_up(sizeof(float) * (size_t)n, 256);
     w.dz_off = off; off += align_up(sizeof(float) * (size_t)b * (h2 > 0 ? h2 : 1), 256);
     w.dvr_off = off; off += align_up(sizeof(float) * (size_t)b, 256);
-    w.S = (n + 511) / 512; if (w.S < 1) w.S = 1; if (w.S > 256) w.S = 256;
-    w.rps = (n + w.S - 1) / w.S;
-    w.part_off = off; off += align_up(sizeof(float) * (size_t)w.S * (hp + 1), 256);
+    w.part_off = off; off += align_up(sizeof(float) * (size_t)(b > 0 ? b : 1) * (hp + 1), 256);
     w.total = off;
     return w;
 }
@@ -50,6 +41,15 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+__device__ __forceinline__ float block_sum_256(float v, float* s4) {
+    // fixed-shape reduction (wave butterflies + 4 partials): deterministic
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
 // block = 256 threads (4 waves), one graph per block
 __global__ __launch_bounds__(256) void head_fwd_kernel(
     int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ h,
@@ -57,52 +57,69 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     const float* __restrict__ v0_b, const float* __restrict__ v1_w, const float* __restrict__ v1_b,
     float* __restrict__ q, float* __restrict__ out_v, float* __restrict__ adv_raw, float* __restrict__ pooled,
     int* __restrict__ amax, int* __restrict__ amin, float* __restrict__ z, float* __restrict__ vraw) {
+    __shared__ __attribute__((aligned(16))) float s_w[128];
     __shared__ float s_pool[4 * 128];
     __shared__ float s_z[64];
-    __shared__ float s_part[4];
+    __shared__ float s_red[4];
     __shared__ float s_v;
+    __shared__ float s_mx[128], s_mn[128], s_sm[128];
+    __shared__ int s_ax[128], s_an[128];
     const int g = blockIdx.x;
     const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H2 = H / 2, H4 = 4 * H;
+    if (tid < 128) s_w[tid] = tid < H ? lin_w[tid] : 0.f;
+    __syncthreads();
 
-    // 1. advantages: one wave per row (lane 0 owns the row's scalar for the rest of the kernel)
-    const float w0 = lane < H ? lin_w[lane] : 0.f;
-    const float w1 = lane + 64 < H ? lin_w[lane + 64] : 0.f;
+    // 1. advantages: one thread per row, 16-byte loads along the row (all independent => deep MLP)
     const float lb = lin_b[0];
     float tsum = 0.f;
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const float* hr = h + (size_t)row * hp;
-        float p = (lane < H ? hr[lane] * w0 : 0.f) + (lane + 64 < H ? hr[lane + 64] * w1 : 0.f);
-        p = wave_sum(p);
-        if (lane == 0) {
-            const float a = p + lb;
-            adv_raw[row] = a;
-            const float t = 2.f * tanhf(a);
-            tsum += t;
-            if (mode == 2) q[row] = t;
+    for (int row = r0 + tid; row < r1; row += 256) {
+        const f32x4* hr = reinterpret_cast<const f32x4*>(h + (size_t)row * hp);
+        const f32x4* wv = reinterpret_cast<const f32x4*>(s_w);
+        float a = 0.f;
+        for (int c = 0; c < hp / 4; ++c) {
+            const f32x4 hv = hr[c], ww = wv[c];
+            a += hv[0] * ww[0] + hv[1] * ww[1] + hv[2] * ww[2] + hv[3] * ww[3];
         }
+        a += lb;
+        adv_raw[row] = a;
+        const float t = 2.f * tanhf(a);
+        tsum += t;
+        if (mode == 2) q[row] = t;
     }
     if (mode == 2) return;
-    if (lane == 0) s_part[wave] = tsum;
+    const float adv_total = block_sum_256(tsum, s_red);
 
-    // 2. pooling: thread c owns feature column c
-    if (tid < H) {
+    // 2. pooling: column c = tid & 127, two row phases (even / odd rows), first-index ties
+    {
+        const int c = tid & 127, ph = tid >> 7;
         float sum = 0.f, mx = -INFINITY, mn = INFINITY;
         int ax = -1, an = -1;
-        for (int row = r0; row < r1; ++row) {
-            const float v = h[(size_t)row * hp + tid];
-            sum += v;
-            if (v > mx) { mx = v; ax = row; }
-            if (v < mn) { mn = v; an = row; }
+        if (c < H) {
+            for (int row = r0 + ph; row < r1; row += 2) {
+                const float v = h[(size_t)row * hp + c];
+                sum += v;
+                if (v > mx) { mx = v; ax = row; }
+                if (v < mn) { mn = v; an = row; }
+            }
         }
-        if (cnt == 0) { mx = 0.f; mn = 0.f; }
-        const float mean = sum / (float)max(cnt, 1);
-        s_pool[tid] = sum; s_pool[H + tid] = mx; s_pool[2 * H + tid] = mn; s_pool[3 * H + tid] = mean;
-        float* pg = pooled + (size_t)g * H4;
-        pg[tid] = sum; pg[H + tid] = mx; pg[2 * H + tid] = mn; pg[3 * H + tid] = mean;
-        amax[(size_t)g * H + tid] = ax;
-        amin[(size_t)g * H + tid] = an;
+        if (ph == 1) { s_sm[c] = sum; s_mx[c] = mx; s_mn[c] = mn; s_ax[c] = ax; s_an[c] = an; }
+        __syncthreads();
+        if (ph == 0 && c < H) {
+            sum += s_sm[c];
+            const float mx1 = s_mx[c], mn1 = s_mn[c];
+            const int ax1 = s_ax[c], an1 = s_an[c];
+            if (ax1 >= 0 && (mx1 > mx || (mx1 == mx && ax1 < ax))) { mx = mx1; ax = ax1; }
+            if (an1 >= 0 && (mn1 < mn || (mn1 == mn && an1 < an))) { mn = mn1; an = an1; }
+            if (cnt == 0) { mx = 0.f; mn = 0.f; }
+            const float mean = sum / (float)max(cnt, 1);
+            s_pool[c] = sum; s_pool[H + c] = mx; s_pool[2 * H + c] = mn; s_pool[3 * H + c] = mean;
+            float* pg = pooled + (size_t)g * H4;
+            pg[c] = sum; pg[H + c] = mx; pg[2 * H + c] = mn; pg[3 * H + c] = mean;
+            amax[(size_t)g * H + c] = ax;
+            amin[(size_t)g * H + c] = an;
+        }
     }
     __syncthreads();
 
@@ -130,28 +147,29 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     }
     __syncthreads();
 
-    // 4. dueling combine
-    const float mean_adv = (s_part[0] + s_part[1] + s_part[2] + s_part[3]) / (float)max(cnt, 1);
+    // 4. dueling combine (each thread re-reads the adv_raw it wrote itself)
+    const float mean_adv = adv_total / (float)max(cnt, 1);
     const float V = s_v;
     if (mode == 1 && tid == 0) out_v[g] = V;
-    if (lane == 0) {
-        for (int row = r0 + wave; row < r1; row += 4) {
-            const float t = 2.f * tanhf(adv_raw[row]);  // written by this same lane above
-            q[row] = (mode == 0 ? V : 0.f) + t - mean_adv;
-        }
+    for (int row = r0 + tid; row < r1; row += 256) {
+        const float t = 2.f * tanhf(adv_raw[row]);
+        q[row] = (mode == 0 ? V : 0.f) + t - mean_adv;
     }
 }
 
 __global__ __launch_bounds__(256) void head_bwd_kernel(
-    int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ lin_w,
-    const float* __restrict__ v0_w, const float* __restrict__ v1_w, const float* __restrict__ adv_raw,
-    const int* __restrict__ amax, const int* __restrict__ amin, const float* __restrict__ z,
-    const float* __restrict__ vraw, const float* __restrict__ dq, const float* __restrict__ d_out_v,
-    float* __restrict__ dh, float* __restrict__ dadv, float* __restrict__ dz, float* __restrict__ dvr) {
+    int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ h,
+    const float* __restrict__ lin_w, const float* __restrict__ v0_w, const float* __restrict__ v1_w,
+    const float* __restrict__ adv_raw, const int* __restrict__ amax, const int* __restrict__ amin,
+    const float* __restrict__ z, const float* __restrict__ vraw, const float* __restrict__ dq,
+    const float* __restrict__ d_out_v, float* __restrict__ dh, float* __restrict__ dadv, float* __restrict__ dz,
+    float* __restrict__ dvr, float* __restrict__ lin_part /*[b][hp+1]*/) {
     __shared__ float s_dp[4 * 128];
     __shared__ float s_dz[64];
     __shared__ int s_ax[128], s_an[128];
-    __shared__ float s_part[4];
+    __shared__ float s_red[4];
+    __shared__ float s_acc[129];
+    __shared__ float s_dar[1024];   // per-row advantage gradient of this graph (graphs beyond 1024 rows re-read global)
     const int g = blockIdx.x;
     const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -159,48 +177,41 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float w0 = lane < H ? lin_w[lane] : 0.f;
     const float w1 = lane + 64 < H ? lin_w[lane + 64] : 0.f;
 
-    if (mode == 2) {
-        for (int row = r0 + wave; row < r1; row += 4) {
-            const float t = tanhf(adv_raw[row]);
-            const float dar = dq[row] * 2.f * (1.f - t * t);
-            if (lane == 0) dadv[row] = dar;
-            float* dr = dh + (size_t)row * hp;
-            if (lane < hp) dr[lane] = dar * w0;
-            if (lane + 64 < hp) dr[lane + 64] = dar * w1;
+    float mean_dq = 0.f, inv_cnt = 1.f / (float)max(cnt, 1);
+    if (mode != 2) {
+        float ps = 0.f;
+        for (int row = r0 + tid; row < r1; row += 256) ps += dq[row];
+        const float sdq = block_sum_256(ps, s_red);
+        mean_dq = sdq * inv_cnt;
+        if (tid < H) { s_ax[tid] = amax[(size_t)g * H + tid]; s_an[tid] = amin[(size_t)g * H + tid]; }
+        const float dV = mode == 0 ? sdq : d_out_v[g];
+        const float V = tanhf(vraw[g]);
+        const float dv = dV * (1.f - V * V);
+        if (tid == 0) dvr[g] = dv;
+        if (tid < H2) {
+            const float zz = z[(size_t)g * H2 + tid];
+            const float d = zz > 0.f ? v1_w[tid] * dv : 0.f;
+            s_dz[tid] = d;
+            dz[(size_t)g * H2 + tid] = d;
         }
-        return;
+        __syncthreads();
+        for (int c = tid; c < H4; c += 256) {
+            float p = 0.f;
+            for (int k = 0; k < H2; ++k) p += v0_w[(size_t)k * H4 + c] * s_dz[k];
+            s_dp[c] = p;
+        }
     }
-    // sum of dq over the graph (fixed order: 4 strided partials)
-    float ps = 0.f;
-    for (int row = r0 + tid; row < r1; row += 256) ps += dq[row];
-    ps = wave_sum(ps);
-    if (lane == 0) s_part[wave] = ps;
-    if (tid < H) { s_ax[tid] = amax[(size_t)g * H + tid]; s_an[tid] = amin[(size_t)g * H + tid]; }
-    __syncthreads();
-    const float sdq = s_part[0] + s_part[1] + s_part[2] + s_part[3];
-    const float inv_cnt = 1.f / (float)max(cnt, 1);
-    const float mean_dq = sdq * inv_cnt;
-    const float dV = mode == 0 ? sdq : d_out_v[g];
-    const float V = tanhf(vraw[g]);
-    const float dv = dV * (1.f - V * V);
-    if (tid == 0) dvr[g] = dv;
-    if (tid < H2) {
-        const float zz = z[(size_t)g * H2 + tid];
-        const float d = zz > 0.f ? v1_w[tid] * dv : 0.f;
-        s_dz[tid] = d;
-        dz[(size_t)g * H2 + tid] = d;
-    }
-    __syncthreads();
-    for (int c = tid; c < H4; c += 256) {
-        float p = 0.f;
-        for (int k = 0; k < H2; ++k) p += v0_w[(size_t)k * H4 + c] * s_dz[k];
-        s_dp[c] = p;
-    }
-    __syncthreads();
-    for (int row = r0 + wave; row < r1; row += 4) {
+    // per-row advantage gradient: thread per row
+    for (int row = r0 + tid; row < r1; row += 256) {
         const float t = tanhf(adv_raw[row]);
         const float dar = (dq[row] - mean_dq) * 2.f * (1.f - t * t);
-        if (lane == 0) dadv[row] = dar;
+        dadv[row] = dar;
+        if (row - r0 < 1024) s_dar[row - r0] = dar;
+    }
+    __syncthreads();
+    // dh rows: one wave per row; advantage-linear gradient: column c = tid&127, two row phases
+    for (int row = r0 + wave; row < r1; row += 4) {
+        const float dar = (row - r0 < 1024) ? s_dar[row - r0] : dadv[row];
         float* dr = dh + (size_t)row * hp;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
@@ -208,74 +219,89 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
             if (c < hp) {
                 float v = 0.f;
                 if (c < H) {
-                    v = dar * (half ? w1 : w0) + s_dp[c] + s_dp[3 * H + c] * inv_cnt;
-                    if (s_ax[c] == row) v += s_dp[H + c];
-                    if (s_an[c] == row) v += s_dp[2 * H + c];
+                    v = dar * (half ? w1 : w0);
+                    if (mode != 2) {
+                        v += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
+                        if (s_ax[c] == row) v += s_dp[H + c];
+                        if (s_an[c] == row) v += s_dp[2 * H + c];
+                    }
                 }
                 dr[c] = v;
             }
         }
     }
+    {
+        const int c = tid & 127, ph = tid >> 7;
+        float acc = 0.f, accb = 0.f;
+        for (int row = r0 + ph; row < r1; row += 2) {
+            const float d = (row - r0 < 1024) ? s_dar[row - r0] : dadv[row];
+            if (c < hp) acc += d * h[(size_t)row * hp + c];
+            accb += d;
+        }
+        if (ph == 1) { s_acc[c] = acc; if (c == 0) s_acc[128] = accb; }
+        __syncthreads();
+        if (ph == 0) {
+            if (c < hp) lin_part[(size_t)g * (hp + 1) + c] = acc + s_acc[c];
+            if (c == 0) lin_part[(size_t)g * (hp + 1) + hp] = accb + s_acc[128];
+        }
+    }
 }
 
-// value-head parameter gradients: fixed order over graphs (deterministic)
-__global__ void head_value_wgrad_kernel(int b, int H, const float* __restrict__ dz, const float* __restrict__ dvr,
-                                        const float* __restrict__ pooled, const float* __restrict__ z,
-                                        float* __restrict__ d_v0_w, float* __restrict__ d_v0_b,
-                                        float* __restrict__ d_v1_w, float* __restrict__ d_v1_b) {
+// value-head parameter gradients.  d_v0_w[k][c] = sum_g dz[g][k]*pooled[g][c]: grid (ceil(4H/64), H/2), block 256 =
+// 64 columns x 4 graph phases, fixed-shape combine (deterministic).  Block (0,0) also does the three small vectors.
+__global__ __launch_bounds__(256) void head_value_wgrad_kernel(int b, int H, const float* __restrict__ dz,
+                                                             const float* __restrict__ dvr,
+                                                             const float* __restrict__ pooled,
+                                                             const float* __restrict__ z, float* __restrict__ d_v0_w,
+                                                             float* __restrict__ d_v0_b, float* __restrict__ d_v1_w,
+                                                             float* __restrict__ d_v1_b) {
+    __shared__ float red[3][64];
     const int H2 = H / 2, H4 = 4 * H;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n0 = H2 * H4;
-    if (idx < n0) {
-        const int k = idx / H4, c = idx % H4;
-        float s = 0.f;
-        for (int g = 0; g < b; ++g) s += dz[(size_t)g * H2 + k] * pooled[(size_t)g * H4 + c];
-        d_v0_w[idx] = s;
-    } else if (idx < n0 + H2) {
-        const int k = idx - n0;
-        float s = 0.f;
-        for (int g = 0; g < b; ++g) s += dz[(size_t)g * H2 + k];
-        d_v0_b[k] = s;
-    } else if (idx < n0 + 2 * H2) {
-        const int k = idx - n0 - H2;
-        float s = 0.f;
-        for (int g = 0; g < b; ++g) s += dvr[g] * z[(size_t)g * H2 + k];
-        d_v1_w[k] = s;
-    } else if (idx == n0 + 2 * H2) {
-        float s = 0.f;
-        for (int g = 0; g < b; ++g) s += dvr[g];
-        d_v1_b[0] = s;
-    }
-}
-
-// advantage Linear gradient, stage 1: partial[s][c] = sum_{rows in slice} dadv[row]*h[row][c]; partial[s][hp] = sum dadv
-__global__ __launch_bounds__(256) void head_lin_grad_kernel(int n, int hp, int rps, const float* __restrict__ dadv,
-                                                          const float* __restrict__ h, float* __restrict__ part) {
-    __shared__ float red[129];
-    const int tid = threadIdx.x, c = tid & 127, ph = tid >> 7;
-    const int r_beg = blockIdx.x * rps, r_end = min(n, r_beg + rps);
-    float acc = 0.f, accb = 0.f;
-    for (int row = r_beg + ph; row < r_end; row += 2) {
-        const float d = dadv[row];
-        if (c < hp) acc += d * h[(size_t)row * hp + c];
-        accb += d;
-    }
-    if (ph == 1) { red[c] = acc; if (c == 0) red[128] = accb; }
+    const int k = blockIdx.y;
+    const int tid = threadIdx.x, cl = tid & 63, ph = tid >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < H4)
+        for (int g = ph; g < b; g += 4) s += dz[(size_t)g * H2 + k] * pooled[(size_t)g * H4 + c];
+    if (ph > 0) red[ph - 1][cl] = s;
     __syncthreads();
-    if (ph == 0) {
-        if (c < hp) part[(size_t)blockIdx.x * (hp + 1) + c] = acc + red[c];
-        if (c == 0) part[(size_t)blockIdx.x * (hp + 1) + hp] = accb + red[128];
+    if (ph == 0 && c < H4) d_v0_w[(size_t)k * H4 + c] = s + red[0][cl] + red[1][cl] + red[2][cl];
+    if (blockIdx.x == 0) {
+        // d_v0_b[k], d_v1_w[k] (wave 0 / wave 1), d_v1_b (block k == 0, wave 2)
+        const int lane = tid & 63, wave = tid >> 6;
+        float p = 0.f;
+        if (wave == 0) { for (int g = lane; g < b; g += 64) p += dz[(size_t)g * H2 + k]; }
+        else if (wave == 1) { for (int g = lane; g < b; g += 64) p += dvr[g] * z[(size_t)g * H2 + k]; }
+        else if (wave == 2 && k == 0) { for (int g = lane; g < b; g += 64) p += dvr[g]; }
+        p = wave_sum(p);
+        if (lane == 0) {
+            if (wave == 0) d_v0_b[k] = p;
+            else if (wave == 1) d_v1_w[k] = p;
+            else if (wave == 2 && k == 0) d_v1_b[0] = p;
+        }
     }
 }
 
-__global__ void head_lin_grad_reduce_kernel(int S, int hp, int H, const float* __restrict__ part,
-                                            float* __restrict__ d_lin_w, float* __restrict__ d_lin_b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > H) return;
+// advantage Linear gradient: sum the per-graph partials; one wave per output column (hp+1 of them)
+__global__ __launch_bounds__(64) void head_lin_grad_reduce_kernel(int b, int hp, int H, const float* __restrict__ part,
+                                                                 float* __restrict__ d_lin_w, float* __restrict__ d_lin_b) {
+    const int c = blockIdx.x, lane = threadIdx.x;   // c in [0, H]  (H == bias)
     const int src = c < H ? c : hp;
     float s = 0.f;
-    for (int i = 0; i < S; ++i) s += part[(size_t)i * (hp + 1) + src];
-    if (c < H) d_lin_w[c] = s; else d_lin_b[0] = s;
+    for (int g = lane; g < b; g += 64) s += part[(size_t)g * (hp + 1) + src];
+    s = wave_sum(s);
+    if (lane == 0) { if (c < H) d_lin_w[c] = s; else d_lin_b[0] = s; }
+}
+
+int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const float* dvr, const float* pooled,
+                            const float* z, const float* lin_part, float* d_lin_w, float* d_lin_b, float* d_v0_w,
+                            float* d_v0_b, float* d_v1_w, float* d_v1_b, hipStream_t st) {
+    const int hp = padded_width(hidden), H2 = hidden / 2, H4 = 4 * hidden;
+    if (mode != 2 && H2 > 0)
+        head_value_wgrad_kernel<<<dim3((H4 + 63) / 64, H2), 256, 0, st>>>(b, hidden, dz, dvr, pooled, z, d_v0_w, d_v0_b,
+                                                                          d_v1_w, d_v1_b);
+    head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, lin_part, d_lin_w, d_lin_b);
+    return HEXGNN_OK;
 }
 
 }  // namespace hexgnn
@@ -337,21 +363,14 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
     float* dz = (float*)(ws + w.dz_off);
     float* dvr = (float*)(ws + w.dvr_off);
     float* part = (float*)(ws + w.part_off);
-    const int H2 = hidden / 2, H4 = 4 * hidden;
     KernelTimer kt(HEXGNN_K_HEAD_BWD, st);
     if (b > 0)
-        head_bwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, lin_w, v0_w, v1_w, (const float*)(sv + s.adv_off),
+        head_bwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, h, lin_w, v0_w, v1_w, (const float*)(sv + s.adv_off),
                                            (const int*)(sv + s.amax_off), (const int*)(sv + s.amin_off),
                                            (const float*)(sv + s.z_off), (const float*)(sv + s.v_off), dq, d_out_v,
-                                           dh, dadv, dz, dvr);
-    if (mode != 2) {
-        const int tot = H2 * H4 + 2 * H2 + 1;
-        head_value_wgrad_kernel<<<(tot + 255) / 256, 256, 0, st>>>(
-            b, hidden, dz, dvr, (const float*)(sv + s.pooled_off), (const float*)(sv + s.z_off), d_v0_w, d_v0_b,
-            d_v1_w, d_v1_b);
-    }
-    head_lin_grad_kernel<<<w.S, 256, 0, st>>>(n, hp, w.rps, dadv, h, part);
-    head_lin_grad_reduce_kernel<<<(hidden + 1 + 127) / 128, 128, 0, st>>>(w.S, hp, hidden, part, d_lin_w, d_lin_b);
+                                           dh, dadv, dz, dvr, part);
+    launch_head_param_grads(b, hidden, mode, dz, dvr, (const float*)(sv + s.pooled_off), (const float*)(sv + s.z_off),
+                            part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b, st);
     return check_launch();
 }
 

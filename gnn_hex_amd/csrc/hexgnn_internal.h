@@ -1,0 +1,46 @@
+// Cross-translation-unit internals of libhexgnn.so (plans + launch helpers shared by the layer-major
+// path in sage.hip / head.hip and the fused per-graph path in qnet_fused.hip).
+#pragma once
+#include "hexgnn_common.h"
+
+namespace hexgnn {
+
+constexpr int kMaxLayers = 64;
+
+struct StackPlan {
+    int hp, nt, L, c_in;
+    bool small_first;
+    size_t fwd_off[kMaxLayers];   // byte offsets into wpack
+    size_t bwd_off[kMaxLayers];
+    size_t bias_off[kMaxLayers];
+    size_t pack_bytes;
+    size_t agg_off[kMaxLayers];   // byte offsets into saved
+    size_t saved_bytes;
+};
+int make_plan(int n, int c_in, int hidden, int L, StackPlan* p);
+
+struct BwdPlan {
+    size_t g_off, pair_off[2][2], part_off, part0_off, total;
+    int S, rps;
+    int S0, rps0;   // raw first layer: many small slices (VALU kernel, one pass over G)
+};
+void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b);
+
+// pack all layers of a stack (forward + backward fragment order, padded bias) -- one launch
+int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
+                const float* const* wr, void* wpack, hipStream_t st);
+// batched weight-gradient GEMM + reductions for all layers of a stack, given G (per-layer masked output gradients)
+int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
+                        int x_stride, const float* acts, const char* saved, const float* G, float* const* d_wl,
+                        float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st);
+
+struct HeadSaved { size_t adv_off, pooled_off, amax_off, amin_off, z_off, v_off, total; };
+HeadSaved head_saved_plan(int n, int b, int hidden);
+struct HeadWs { size_t dadv_off, dz_off, dvr_off, part_off, total; };
+HeadWs head_ws_plan(int n, int b, int hidden);
+// value-head + advantage-linear parameter gradients from the per-graph partials
+int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const float* dvr, const float* pooled,
+                            const float* z, const float* lin_part, float* d_lin_w, float* d_lin_b, float* d_v0_w,
+                            float* d_v0_b, float* d_v1_w, float* d_v1_b, hipStream_t st);
+
+}  // namespace hexgnn

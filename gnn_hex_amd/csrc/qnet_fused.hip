@@ -1,0 +1,856 @@
+// Whole modern_two_headed Q-network per launch: one 512-thread workgroup per board graph (<= 128 nodes).
+//
+// Reference path: DuellingTwoHeaded.forward (GN0/models.py:537-584) = CachifiedGNN body (261-294) -> head gnn ->
+// HeadNetwork tail (374-384) -> dueling combine (571-584), and its autograd backward.
+//
+// MI355X design.  A Hex-11 graph is 123 x 110 fp32 = 54 KB: the node features of ALL layers stay in the CU's
+// 160 KB LDS, so neighbour gathers are LDS reads and nothing but the saved activations goes to HBM.
+//   LDS:  [ W half A | W half B | node rows 128 x (HP+4) | CSR (u16 rowptr, u8 col) ]
+//   wave w owns rows 16w..16w+15; lane (r = l&15, g = l>>4) holds, for its row r, the 4-float feature chunks
+//   {16c+4g..+3}, c < NT.  MFMAs run with SWAPPED operands (a = packed weights, b = row fragment): the tile comes
+//   out transposed, i.e. in the SAME lane layout, so a layer's output registers are the next layer's self operand.
+//   Per layer the [agg|x] contraction is split in two K phases (W_l half, W_r half); while one half is in use the
+//   other half of the next phase/layer is streamed L2 -> registers -> LDS (two barriers per layer).
+//   fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): exact fmaf chains, deterministic.
+#include "hexgnn_internal.h"
+
+namespace hexgnn {
+
+constexpr int kMaxL = kMaxLayers;
+constexpr int kRows = 128;            // rows per workgroup
+constexpr int kLdsBytes = 160 * 1024;
+
+struct QFwdArgs {
+    int n, b, c_in, H, L, mode, x_stride, need_backward;
+    const int* gptr; const int* rowptr; const int* col; const float* invdeg;
+    const float* x;
+    const char* wpack; size_t fwd_off[kMaxL]; size_t bias_off[kMaxL];
+    float* acts; char* saved; size_t agg_off[kMaxL];
+    const float* lin_w; const float* lin_b; const float* v0_w; const float* v0_b; const float* v1_w; const float* v1_b;
+    float* adv_raw; float* pooled; int* amax; int* amin; float* z; float* vraw;
+    float* q; float* out_v; int* status;
+};
+
+struct QBwdArgs {
+    int n, b, H, L, mode, body_layers;
+    const int* gptr; const int* rowptr_t; const int* col_t; const float* invdeg;
+    const char* wpack; size_t bwd_off[kMaxL];
+    const float* acts;
+    const float* lin_w; const float* v0_w; const float* v1_w;
+    const float* adv_raw; const int* amax; const int* amin; const float* z; const float* vraw;
+    const float* dq; const float* d_out_v;
+    float* G; float* d_embeds;
+    float* dadv; float* dz; float* dvr; float* lin_part;
+    int* status;
+};
+
+template <int NT> struct QLds {
+    static constexpr int HP = 16 * NT;
+    static constexpr int XS = HP + 4;                       // row stride (floats): (4NT+1) 16-B slots, odd
+    static constexpr int kHalf = NT * NT * 64;              // float4 per weight half
+    static constexpr int off_w = 0;
+    static constexpr int off_x = 2 * kHalf * 16;
+    static constexpr int off_rp = off_x + kRows * XS * 4;
+    static constexpr int off_col = off_rp + 272;            // (kRows+2) u16, padded
+    static constexpr int col_cap = (kLdsBytes - off_col) < 8192 ? (kLdsBytes - off_col) : 8192;
+    // 16 KB of scratch (first-layer operands, head-tail reductions): aliases the weight halves when they are
+    // large enough (NT >= 4), otherwise a region of its own (small widths leave plenty of LDS)
+    static constexpr bool scr_alias = NT >= 4;
+    static constexpr int scr_bytes = 16384;
+    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_col + col_cap;   // half B
+    static constexpr int off_scr_tail = scr_alias ? off_w : off_col + col_cap;
+    static constexpr int total = off_col + col_cap + (scr_alias ? 0 : scr_bytes);
+    static_assert(col_cap >= 1024 && total <= kLdsBytes, "LDS budget");
+    static_assert(!scr_alias || kHalf * 16 >= scr_bytes, "scratch must fit one weight half");
+};
+
+__device__ __forceinline__ float wsum64(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// CSR of the workgroup's graph -> LDS (u16 row offsets, u8 local column ids).  Returns false when it does not fit
+// (the caller then walks the global CSR).
+template <int NT>
+__device__ __forceinline__ bool load_csr(char* lds, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                         int r0, int cnt, int e0, int ne, int* status) {
+    using LD = QLds<NT>;
+    unsigned short* s_rp = reinterpret_cast<unsigned short*>(lds + LD::off_rp);
+    unsigned char* s_col = reinterpret_cast<unsigned char*>(lds + LD::off_col);
+    const bool fits = ne <= LD::col_cap;
+    if (!fits) return false;
+    for (int i = threadIdx.x; i <= cnt; i += 512) s_rp[i] = (unsigned short)(rowptr[r0 + i] - e0);
+    for (int e = threadIdx.x; e < ne; e += 512) {
+        const int j = col[e0 + e] - r0;
+        if (j < 0 || j >= cnt) { atomicOr(status, 2); s_col[e] = 0; }
+        else s_col[e] = (unsigned char)j;
+    }
+    return true;
+}
+
+// ================================================= forward =================================================
+template <int NT>
+__global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
+    using LD = QLds<NT>;
+    constexpr int HP = LD::HP, XS = LD::XS, kHalf = LD::kHalf;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    f32x4* wbuf = reinterpret_cast<f32x4*>(lds + LD::off_w);       // [2][kHalf]
+    float* xbuf = reinterpret_cast<float*>(lds + LD::off_x);       // [kRows][XS]
+    const unsigned short* s_rp = reinterpret_cast<const unsigned short*>(lds + LD::off_rp);
+    const unsigned char* s_col = reinterpret_cast<const unsigned char*>(lds + LD::off_col);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int gi = blockIdx.x;
+    const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
+    const int cnt = r1 - r0;
+    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 1); return; }
+    const int H = a.H;
+    const int lrow = wave * 16 + r;                 // local row of this lane
+    const bool rvalid = lrow < cnt;
+    const bool wactive = wave * 16 < cnt;           // wave-uniform
+    const int grow = r0 + lrow;
+    const int e0 = a.rowptr[r0], ne = a.rowptr[r1] - e0;
+    const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
+
+    // ---- stage W_l of layer 1 into half A; first-layer scratch lives in half B ----
+    if (a.L > 1) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]);
+        for (int i = tid; i < kHalf; i += 512) wbuf[i] = src[i];
+    }
+    float* s_w0 = reinterpret_cast<float*>(lds + LD::off_scr_first);  // [2][HP][8]
+    float* s_f = s_w0 + 2 * HP * kSmallCin;                          // [kRows][16]: agg0 | x0
+    {
+        const float* w0 = reinterpret_cast<const float*>(a.wpack + a.fwd_off[0]);
+        for (int i = tid; i < 2 * HP * kSmallCin; i += 512) s_w0[i] = w0[i];
+        if (tid < kRows) {
+            float ag0[kSmallCin], xs0[kSmallCin];
+#pragma unroll
+            for (int qq = 0; qq < kSmallCin; ++qq) { ag0[qq] = 0.f; xs0[qq] = 0.f; }
+            if (tid < cnt) {
+                const int row = r0 + tid;
+                for (int e = a.rowptr[row]; e < a.rowptr[row + 1]; ++e) {
+                    const float* xr = a.x + (size_t)a.col[e] * a.x_stride;
+                    for (int qq = 0; qq < a.c_in; ++qq) ag0[qq] += xr[qq];
+                }
+                const float sc = a.invdeg[row];
+                const float* xr = a.x + (size_t)row * a.x_stride;
+                for (int qq = 0; qq < a.c_in; ++qq) { ag0[qq] *= sc; xs0[qq] = xr[qq]; }
+                if (a.need_backward) {
+                    float* ao = reinterpret_cast<float*>(a.saved + a.agg_off[0]) + (size_t)row * kSmallCin;
+#pragma unroll
+                    for (int qq = 0; qq < kSmallCin; ++qq) ao[qq] = ag0[qq];
+                }
+            }
+#pragma unroll
+            for (int qq = 0; qq < kSmallCin; ++qq) { s_f[tid * 16 + qq] = ag0[qq]; s_f[tid * 16 + 8 + qq] = xs0[qq]; }
+        }
+    }
+    __syncthreads();
+
+    // ---- layer 0 (raw features): every lane produces its own row chunks, already in the chained layout ----
+    f32x4 xs[NT];
+    {
+        const float* b0 = reinterpret_cast<const float*>(a.wpack + a.bias_off[0]);
+        float f[16];
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) f[qq] = s_f[lrow * 16 + qq];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = reinterpret_cast<const f32x4*>(b0)[4 * t + g];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int o = 16 * t + 4 * g + q4;
+                const float* wl0 = s_w0 + o * kSmallCin;
+                const float* wr0 = s_w0 + HP * kSmallCin + o * kSmallCin;
+                float s = v[q4];
+#pragma unroll
+                for (int qq = 0; qq < kSmallCin; ++qq) s += wl0[qq] * f[qq] + wr0[qq] * f[8 + qq];
+                v[q4] = rvalid ? fmaxf(s, 0.f) : 0.f;
+            }
+            xs[t] = v;
+        }
+        f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) xr[4 * t] = xs[t];
+        if (rvalid) {
+            f32x4* yo = reinterpret_cast<f32x4*>(a.acts + (size_t)grow * HP) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
+        }
+    }
+    __syncthreads();   // xbuf + half A visible; half B (scratch) free
+
+    // ---- hidden layers ----
+    constexpr int kStage = (kHalf + 511) / 512;
+    const size_t slab = (size_t)a.n * HP;
+    for (int l = 1; l < a.L; ++l) {
+        f32x4 stg[kStage];
+        {   // stream W_r(l) towards half B
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]) + kHalf;
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wactive) {
+            // phase 1: mean-gather from LDS, then K-half over W_l (half A)
+            f32x4 ag[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rvalid) {
+                if (csr_lds) {
+                    const int eb = s_rp[lrow], ee = s_rp[lrow + 1];
+                    for (int e = eb; e < ee; ++e) {
+                        const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (int)s_col[e] * XS) + g;
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
+                    }
+                } else {
+                    for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
+                        const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
+                    }
+                }
+                const float sc = a.invdeg[grow];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ag[c] *= sc;
+                if (a.need_backward) {
+                    f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 w = wbuf[(c * NT + t) * 64 + lane];
+                    acc[t] = mfma16x16x4(w[0], ag[c][0], acc[t]);
+                    acc[t] = mfma16x16x4(w[1], ag[c][1], acc[t]);
+                    acc[t] = mfma16x16x4(w[2], ag[c][2], acc[t]);
+                    acc[t] = mfma16x16x4(w[3], ag[c][3], acc[t]);
+                }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        __syncthreads();   // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
+        if (l + 1 < a.L) {   // stream W_l(l+1) towards half A
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
+        }
+        if (wactive) {
+            // phase 2: K-half over W_r (half B) with the self rows kept in registers
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 w = wbuf[kHalf + (c * NT + t) * 64 + lane];
+                    acc[t] = mfma16x16x4(w[0], xs[c][0], acc[t]);
+                    acc[t] = mfma16x16x4(w[1], xs[c][1], acc[t]);
+                    acc[t] = mfma16x16x4(w[2], xs[c][2], acc[t]);
+                    acc[t] = mfma16x16x4(w[3], xs[c][3], acc[t]);
+                }
+            }
+            const f32x4* br = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]) + g;
+            f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 v = acc[t] + br[4 * t];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = (rvalid && v[q4] > 0.f) ? v[q4] : 0.f;
+                xs[t] = v;
+                xr[4 * t] = v;
+            }
+            if (rvalid) {
+                f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
+            }
+        }
+        if (l + 1 < a.L) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
+        }
+        __syncthreads();   // barrier 2: new rows + half A visible; half B free
+    }
+
+    // ---- head tail (scratch aliases the weight halves, free after the last barrier) ----
+    float* sc = reinterpret_cast<float*>(lds + LD::off_scr_tail);
+    float* s_w = sc;                 // [128] advantage weights
+    float* s_pool = sc + 128;        // [4*128]
+    float* s_z = sc + 640;           // [64]
+    float* s_red = sc + 704;         // [8]
+    float* s_misc = sc + 712;        // [0] = tanh(v)
+    float* s_mx = sc + 768;          // [3][128]
+    float* s_mn = sc + 1152;         // [3][128]
+    float* s_sm = sc + 1536;         // [3][128]
+    int* s_ax = reinterpret_cast<int*>(sc + 1920);   // [3][128]
+    int* s_an = reinterpret_cast<int*>(sc + 2304);   // [3][128]
+    const int H2 = H / 2, H4 = 4 * H;
+    if (tid < 128) s_w[tid] = tid < H ? a.lin_w[tid] : 0.f;
+    __syncthreads();
+    // advantages from the registers: partial dot over this lane's chunks, reduce over the 4 lanes of the row
+    float adv = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
+        adv += xs[t][0] * w[0] + xs[t][1] * w[1] + xs[t][2] * w[2] + xs[t][3] * w[3];
+    }
+    adv += __shfl_xor(adv, 16);
+    adv += __shfl_xor(adv, 32);
+    adv += a.lin_b[0];
+    const float tadv = 2.f * tanhf(adv);
+    if (g == 0 && rvalid) {
+        a.adv_raw[grow] = adv;
+        if (a.mode == 2) a.q[grow] = tadv;
+    }
+    if (a.mode == 2) return;
+    {   // sum of 2tanh(adv) over the graph: lanes g==0 of valid rows; fixed-shape tree
+        float v = (g == 0 && rvalid) ? tadv : 0.f;
+        v = wsum64(v);
+        if (lane == 0) s_red[wave] = v;
+    }
+    // pooling straight from the LDS rows: column c = tid&127, four row phases
+    {
+        const int c = tid & 127, ph = tid >> 7;
+        float sum = 0.f, mx = -INFINITY, mn = INFINITY;
+        int ax = -1, an = -1;
+        if (c < H) {
+            for (int row = ph; row < cnt; row += 4) {
+                const float v = xbuf[row * XS + c];
+                sum += v;
+                if (v > mx) { mx = v; ax = row; }
+                if (v < mn) { mn = v; an = row; }
+            }
+        }
+        if (ph > 0) {
+            const int o = (ph - 1) * 128 + c;
+            s_sm[o] = sum; s_mx[o] = mx; s_mn[o] = mn; s_ax[o] = ax; s_an[o] = an;
+        }
+        __syncthreads();
+        if (ph == 0 && c < H) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+                const int o = p * 128 + c;
+                sum += s_sm[o];
+                const float mx1 = s_mx[o], mn1 = s_mn[o];
+                const int ax1 = s_ax[o], an1 = s_an[o];
+                if (ax1 >= 0 && (ax < 0 || mx1 > mx || (mx1 == mx && ax1 < ax))) { mx = mx1; ax = ax1; }
+                if (an1 >= 0 && (an < 0 || mn1 < mn || (mn1 == mn && an1 < an))) { mn = mn1; an = an1; }
+            }
+            if (cnt == 0) { mx = 0.f; mn = 0.f; }
+            const float mean = sum / (float)max(cnt, 1);
+            s_pool[c] = sum; s_pool[H + c] = mx; s_pool[2 * H + c] = mn; s_pool[3 * H + c] = mean;
+            float* pg = a.pooled + (size_t)gi * H4;
+            pg[c] = sum; pg[H + c] = mx; pg[2 * H + c] = mn; pg[3 * H + c] = mean;
+            a.amax[(size_t)gi * H + c] = ax >= 0 ? r0 + ax : -1;
+            a.amin[(size_t)gi * H + c] = an >= 0 ? r0 + an : -1;
+        }
+    }
+    __syncthreads();
+    for (int k = wave; k < H2; k += 8) {
+        const float* wr = a.v0_w + (size_t)k * H4;
+        float p = 0.f;
+        for (int c = lane; c < H4; c += 64) p += wr[c] * s_pool[c];
+        p = wsum64(p);
+        if (lane == 0) {
+            const float zz = fmaxf(p + a.v0_b[k], 0.f);
+            s_z[k] = zz;
+            a.z[(size_t)gi * H2 + k] = zz;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float p = lane < H2 ? a.v1_w[lane] * s_z[lane] : 0.f;
+        p = wsum64(p);
+        if (lane == 0) {
+            const float v = p + a.v1_b[0];
+            a.vraw[gi] = v;
+            s_misc[0] = tanhf(v);
+        }
+    }
+    __syncthreads();
+    float adv_total = 0.f;
+#pragma unroll
+    for (int w = 0; w < 8; ++w) adv_total += s_red[w];
+    const float mean_adv = adv_total / (float)max(cnt, 1);
+    const float V = s_misc[0];
+    if (a.mode == 1 && tid == 0) a.out_v[gi] = V;
+    if (g == 0 && rvalid) a.q[grow] = (a.mode == 0 ? V : 0.f) + tadv - mean_adv;
+}
+
+// ================================================= backward =================================================
+// Data-gradient chain of the whole network for one graph: head tail backward, then per layer
+//   G_l = (dXs_{l+1} + sum_{j in T(i)} dAggS_{l+1,j}) * [y_l > 0];  [dAggS_l | dXs_l] = G_l [W_l | W_r]
+// with dAggS rows exchanged through LDS and dXs / G kept in registers.  Writes G_l (all layers) for the batched
+// weight-gradient GEMM, and the head's per-graph partials.
+template <int NT>
+__global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
+    using LD = QLds<NT>;
+    constexpr int HP = LD::HP, XS = LD::XS, kHalf = LD::kHalf;
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    f32x4* wbuf = reinterpret_cast<f32x4*>(lds + LD::off_w);
+    float* dbuf = reinterpret_cast<float*>(lds + LD::off_x);
+    const unsigned short* s_rp = reinterpret_cast<const unsigned short*>(lds + LD::off_rp);
+    const unsigned char* s_col = reinterpret_cast<const unsigned char*>(lds + LD::off_col);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 15, g = lane >> 4;
+    const int gi = blockIdx.x;
+    const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
+    const int cnt = r1 - r0;
+    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 1); return; }
+    const int H = a.H, L = a.L;
+    const int lrow = wave * 16 + r;
+    const bool rvalid = lrow < cnt;
+    const bool wactive = wave * 16 < cnt;
+    const int grow = r0 + lrow;
+    const int e0 = a.rowptr_t[r0], ne = a.rowptr_t[r1] - e0;
+    const bool csr_lds = load_csr<NT>(lds, a.rowptr_t, a.col_t, r0, cnt, e0, ne, a.status);
+    const size_t slab = (size_t)a.n * HP;
+    const int H2 = H / 2, H4 = 4 * H;
+    constexpr int kStage = (kHalf + 511) / 512;
+
+    // stage both weight halves of the top layer (tiles t < NT -> half A, t >= NT -> half B)
+    if (L > 1) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]);
+        for (int i = tid; i < 2 * kHalf; i += 512) {
+            const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
+            const int dst = (t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li;
+            wbuf[dst] = src[i];
+        }
+    }
+
+    // ---- head tail backward; scratch aliases dbuf (not written before the first barrier A) ----
+    float* sc = dbuf;
+    float* s_w = sc;                  // [128]
+    float* s_dp = sc + 128;           // [4*128]
+    float* s_dz = sc + 640;           // [64]
+    float* s_red = sc + 704;          // [8]
+    float* s_dar = sc + 768;          // [128]
+    int* s_ax = reinterpret_cast<int*>(sc + 896);    // [128] local row of the max
+    int* s_an = reinterpret_cast<int*>(sc + 1024);
+    float* s_lin = sc + 1152;         // [8][HP+1]
+    if (tid < 128) s_w[tid] = tid < H ? a.lin_w[tid] : 0.f;
+    float mean_dq = 0.f;
+    const float inv_cnt = 1.f / (float)max(cnt, 1);
+    if (a.mode != 2) {
+        float ps = 0.f;
+        if (tid < cnt) ps = a.dq[r0 + tid];
+        ps = wsum64(ps);
+        if (lane == 0) s_red[wave] = ps;
+        if (tid < H) {
+            const int ax = a.amax[(size_t)gi * H + tid], an = a.amin[(size_t)gi * H + tid];
+            s_ax[tid] = ax >= 0 ? ax - r0 : -1;
+            s_an[tid] = an >= 0 ? an - r0 : -1;
+        }
+        __syncthreads();
+        float sdq = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) sdq += s_red[w];
+        mean_dq = sdq * inv_cnt;
+        const float dV = a.mode == 0 ? sdq : a.d_out_v[gi];
+        const float V = tanhf(a.vraw[gi]);
+        const float dv = dV * (1.f - V * V);
+        if (tid == 0) a.dvr[gi] = dv;
+        if (tid < H2) {
+            const float zz = a.z[(size_t)gi * H2 + tid];
+            const float d = zz > 0.f ? a.v1_w[tid] * dv : 0.f;
+            s_dz[tid] = d;
+            a.dz[(size_t)gi * H2 + tid] = d;
+        }
+        __syncthreads();
+        for (int c = tid; c < H4; c += 512) {
+            float p = 0.f;
+            for (int k = 0; k < H2; ++k) p += a.v0_w[(size_t)k * H4 + c] * s_dz[k];
+            s_dp[c] = p;
+        }
+    }
+    if (tid < kRows) {
+        float dar = 0.f;
+        if (tid < cnt) {
+            const float t = tanhf(a.adv_raw[r0 + tid]);
+            dar = (a.dq[r0 + tid] - mean_dq) * 2.f * (1.f - t * t);
+            a.dadv[r0 + tid] = dar;
+        }
+        s_dar[tid] = dar;
+    }
+    __syncthreads();
+
+    // gradient w.r.t. the top layer's output, in the chained lane layout; advantage-linear partial alongside
+    f32x4 gx[NT];
+    {
+        const float dar = s_dar[lrow];
+        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
+        float lacc[NT * 4];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
+            f32x4 yv = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rvalid) yv = yr[4 * t];
+            f32x4 v;
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const int c = 16 * t + 4 * g + q4;
+                float s = dar * w[q4];
+                if (a.mode != 2 && c < H) {
+                    s += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
+                    if (s_ax[c] == lrow) s += s_dp[H + c];
+                    if (s_an[c] == lrow) s += s_dp[2 * H + c];
+                }
+                v[q4] = (rvalid && c < H) ? s : 0.f;
+                lacc[4 * t + q4] = dar * yv[q4];
+            }
+            gx[t] = v;
+        }
+        // d lin_w[c] partial = sum_rows dar*h[row][c]: reduce over the 16 rows of the wave, then over waves
+        float bacc = g == 0 ? dar : 0.f;
+#pragma unroll
+        for (int off = 1; off <= 8; off <<= 1) {
+#pragma unroll
+            for (int k = 0; k < NT * 4; ++k) lacc[k] += __shfl_xor(lacc[k], off);
+            bacc += __shfl_xor(bacc, off);
+        }
+        if (r == 0) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) s_lin[wave * (HP + 1) + 16 * t + 4 * g + q4] = lacc[4 * t + q4];
+            if (g == 0) s_lin[wave * (HP + 1) + HP] = bacc;
+        }
+    }
+    __syncthreads();
+    if (tid <= HP) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) s += s_lin[w * (HP + 1) + tid];
+        a.lin_part[(size_t)gi * (HP + 1) + tid] = s;
+    }
+    __syncthreads();   // scratch consumed; dbuf may be overwritten from here on
+
+    // ---- layer chain ----
+    for (int l = L - 1; l >= 1; --l) {
+        if (a.d_embeds && l == a.body_layers - 1 && rvalid) {
+            f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
+        }
+        f32x4 stg[kStage];
+        const bool more = l - 1 >= 1;
+        if (more) {   // stream [W_l part] of layer l-1 towards half A
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) {
+                const int i = tid + 512 * k;
+                if (i < kHalf) { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + t) * 64 + li]; }
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (wactive) {
+            // mask by this layer's ReLU, publish G_l
+            if (rvalid) {
+                const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
+                f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 yv = yr[4 * t];
+#pragma unroll
+                    for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
+                    go[4 * t] = gx[t];
+                }
+            }
+            // phase 1: dAggS = (G W_l) / deg     (half A)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 w = wbuf[(c * NT + t) * 64 + lane];
+                    acc[t] = mfma16x16x4(w[0], gx[c][0], acc[t]);
+                    acc[t] = mfma16x16x4(w[1], gx[c][1], acc[t]);
+                    acc[t] = mfma16x16x4(w[2], gx[c][2], acc[t]);
+                    acc[t] = mfma16x16x4(w[3], gx[c][3], acc[t]);
+                }
+            }
+        }
+        __syncthreads();   // barrier A: gathers of the previous layer are done (dbuf free); half A free
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) {   // stream [W_r part] of layer l-1 towards half B
+                const int i = tid + 512 * k;
+                if (i < kHalf) { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
+            }
+        }
+        f32x4 dxs[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) dxs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        {
+            const float scl = rvalid ? a.invdeg[grow] : 0.f;
+            f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dr[4 * t] = acc[t] * scl;
+        }
+        if (wactive) {
+            // phase 2: dXs = G W_r     (half B)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const f32x4 w = wbuf[kHalf + (c * NT + t) * 64 + lane];
+                    dxs[t] = mfma16x16x4(w[0], gx[c][0], dxs[t]);
+                    dxs[t] = mfma16x16x4(w[1], gx[c][1], dxs[t]);
+                    dxs[t] = mfma16x16x4(w[2], gx[c][2], dxs[t]);
+                    dxs[t] = mfma16x16x4(w[3], gx[c][3], dxs[t]);
+                }
+            }
+        }
+        __syncthreads();   // barrier B: dAggS rows + half A visible; half B free
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        }
+        // gradient w.r.t. this layer's input = dXs + transposed gather of dAggS
+#pragma unroll
+        for (int t = 0; t < NT; ++t) gx[t] = dxs[t];
+        if (rvalid) {
+            if (csr_lds) {
+                const int eb = s_rp[lrow], ee = s_rp[lrow + 1];
+                for (int e = eb; e < ee; ++e) {
+                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (int)s_col[e] * XS) + g;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
+                }
+            } else {
+                for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
+                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
+                }
+            }
+        }
+    }
+    // ---- layer 0: G_0 = grad * [y_0 > 0] (its weight gradient is a separate VALU kernel) ----
+    if (a.d_embeds && a.body_layers - 1 == 0 && rvalid) {
+        f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
+    }
+    if (rvalid) {
+        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + (size_t)grow * HP) + g;
+        f32x4* go = reinterpret_cast<f32x4*>(a.G + (size_t)grow * HP) + g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const f32x4 yv = yr[4 * t];
+            f32x4 v = gx[t];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) v[q4] = yv[q4] > 0.f ? v[q4] : 0.f;
+            go[4 * t] = v;
+        }
+    }
+}
+
+template <int NT>
+static int launch_qfwd(const QFwdArgs& a, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fwd_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLds<NT>::total);
+        return true;
+    }();
+    (void)once;
+    qnet_fwd_kernel<NT><<<a.b, 512, QLds<NT>::total, st>>>(a);
+    return HEXGNN_OK;
+}
+template <int NT>
+static int launch_qbwd(const QBwdArgs& a, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_bwd_kernel<NT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLds<NT>::total);
+        return true;
+    }();
+    (void)once;
+    qnet_bwd_kernel<NT><<<a.b, 512, QLds<NT>::total, st>>>(a);
+    return HEXGNN_OK;
+}
+
+#define HEXGNN_NT_SWITCH7(nt, CALL)                     \
+    switch (nt) {                                      \
+        case 1: { constexpr int NT_ = 1; CALL; } break; \
+        case 2: { constexpr int NT_ = 2; CALL; } break; \
+        case 3: { constexpr int NT_ = 3; CALL; } break; \
+        case 4: { constexpr int NT_ = 4; CALL; } break; \
+        case 5: { constexpr int NT_ = 5; CALL; } break; \
+        case 6: { constexpr int NT_ = 6; CALL; } break; \
+        case 7: { constexpr int NT_ = 7; CALL; } break; \
+        default: return HEXGNN_EUNSUPPORTED;           \
+    }
+
+}  // namespace hexgnn
+
+using namespace hexgnn;
+
+namespace {
+struct QPlan {
+    StackPlan sp;
+    HeadSaved hs;
+    size_t head_saved_off, saved_total;
+    BwdPlan bp;
+    HeadWs hw;
+    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_total;
+};
+int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
+    int rc = make_plan(n, c_in, hidden, L, &q->sp);
+    if (rc != HEXGNN_OK) return rc;
+    if (!q->sp.small_first || q->sp.nt > 7 || hidden < 2) return HEXGNN_EUNSUPPORTED;
+    q->hs = head_saved_plan(n, b, hidden);
+    q->head_saved_off = align_up(q->sp.saved_bytes, 256);
+    q->saved_total = q->head_saved_off + q->hs.total;
+    make_bwd_plan(n, q->sp, &q->bp);
+    q->hw = head_ws_plan(n, b, hidden);
+    const size_t slab = align_up(sizeof(float) * (size_t)n * q->sp.hp, 256);
+    size_t off = 0;
+    q->ws_g_off = off; off += slab * L;
+    q->ws_part_off = off; off += align_up(sizeof(float) * (size_t)L * q->bp.S * q->sp.hp * (2 * q->sp.hp + 1), 256);
+    q->ws_part0_off = off; off += align_up(sizeof(float) * (size_t)q->bp.S0 * q->sp.hp * 17, 256);
+    q->ws_head_off = off; off += q->hw.total;
+    q->ws_total = off;
+    return HEXGNN_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int hexgnn_qnet_supported(int c_in, int hidden, int max_nodes_per_graph) {
+    const int hp = padded_width(hidden);
+    return hp > 0 && hp <= 112 && hidden >= 2 && c_in >= 1 && c_in <= kSmallCin && c_in != hidden &&
+           max_nodes_per_graph <= kRows;
+}
+
+size_t hexgnn_qnet_saved_bytes(int n, int b, int c_in, int hidden, int total_layers) {
+    QPlan q;
+    if (n < 0 || b < 0 || make_qplan(n, b, c_in, hidden, total_layers, &q) != HEXGNN_OK) return 0;
+    return q.saved_total;
+}
+
+int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,
+                        const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
+                        const float* const* wl, const float* const* bl, const float* const* wr,
+                        const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
+                        const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
+                        int need_backward, float* q, float* out_v, int* status, hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n < 0 || b < 0 || mode < 0 || mode > 2) return HEXGNN_EINVAL;
+    QPlan qp;
+    int rc = make_qplan(n, b, c_in, hidden, total_layers, &qp);
+    if (rc != HEXGNN_OK) return rc;
+    if (!gptr || !wl || !bl || !wr || !lin_w || !lin_b || !wpack || !saved || !status) return HEXGNN_EINVAL;
+    if (mode != 2 && (!v0_w || !v0_b || !v1_w || !v1_b)) return HEXGNN_EINVAL;
+    if (mode == 1 && !out_v) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts || !q)) return HEXGNN_EINVAL;
+    if (x_stride < c_in) return HEXGNN_EINVAL;
+    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st);
+    if (rc != HEXGNN_OK) return rc;
+    if (b == 0) return check_launch();
+    QFwdArgs a;
+    a.n = n; a.b = b; a.c_in = c_in; a.H = hidden; a.L = total_layers; a.mode = mode; a.x_stride = x_stride;
+    a.need_backward = need_backward;
+    a.gptr = gptr; a.rowptr = rowptr; a.col = col; a.invdeg = invdeg; a.x = x;
+    a.wpack = (const char*)wpack;
+    for (int l = 0; l < total_layers; ++l) {
+        a.fwd_off[l] = qp.sp.fwd_off[l]; a.bias_off[l] = qp.sp.bias_off[l]; a.agg_off[l] = qp.sp.agg_off[l];
+    }
+    a.acts = acts; a.saved = (char*)saved;
+    a.lin_w = lin_w; a.lin_b = lin_b; a.v0_w = v0_w; a.v0_b = v0_b; a.v1_w = v1_w; a.v1_b = v1_b;
+    char* hsv = (char*)saved + qp.head_saved_off;
+    a.adv_raw = (float*)(hsv + qp.hs.adv_off); a.pooled = (float*)(hsv + qp.hs.pooled_off);
+    a.amax = (int*)(hsv + qp.hs.amax_off); a.amin = (int*)(hsv + qp.hs.amin_off);
+    a.z = (float*)(hsv + qp.hs.z_off); a.vraw = (float*)(hsv + qp.hs.v_off);
+    a.q = q; a.out_v = out_v; a.status = status;
+    {
+        KernelTimer kt(HEXGNN_K_QNET_FWD, st);
+        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qfwd<NT_>(a, st)));
+    }
+    return check_launch();
+}
+
+size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, int total_layers) {
+    QPlan q;
+    if (n < 0 || b < 0 || make_qplan(n, b, c_in, hidden, total_layers, &q) != HEXGNN_OK) return 0;
+    return q.ws_total;
+}
+
+int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode,
+                         const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                         const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                         const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
+                         const float* d_out_v, float* d_embeds, float* const* d_wl, float* const* d_bl,
+                         float* const* d_wr, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b,
+                         float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
+                         hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n < 0 || b < 0 || mode < 0 || mode > 2 || body_layers < 1 || body_layers > total_layers) return HEXGNN_EINVAL;
+    QPlan qp;
+    int rc = make_qplan(n, b, c_in, hidden, total_layers, &qp);
+    if (rc != HEXGNN_OK) return rc;
+    if (!workspace || workspace_bytes < qp.ws_total) return HEXGNN_EWORKSPACE;
+    if (!gptr || !d_wl || !d_bl || !d_wr || !wpack || !saved || !lin_w || !d_lin_w || !d_lin_b || !status)
+        return HEXGNN_EINVAL;
+    for (int l = 0; l < total_layers; ++l) if (!d_wl[l] || !d_bl[l] || !d_wr[l]) return HEXGNN_EINVAL;
+    if (mode != 2 && (!v0_w || !v1_w || !d_v0_w || !d_v0_b || !d_v1_w || !d_v1_b)) return HEXGNN_EINVAL;
+    if (mode == 1 && !d_out_v) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr_t || !col_t || !invdeg || !x || !acts || !dq)) return HEXGNN_EINVAL;
+    char* ws = (char*)workspace;
+    const char* sv = (const char*)saved;
+    const char* hsv = sv + qp.head_saved_off;
+    float* G = (float*)(ws + qp.ws_g_off);
+    float* part = (float*)(ws + qp.ws_part_off);
+    float* part0 = (float*)(ws + qp.ws_part0_off);
+    char* hws = ws + qp.ws_head_off;
+    QBwdArgs a;
+    a.n = n; a.b = b; a.H = hidden; a.L = total_layers; a.mode = mode; a.body_layers = body_layers;
+    a.gptr = gptr; a.rowptr_t = rowptr_t; a.col_t = col_t; a.invdeg = invdeg;
+    a.wpack = (const char*)wpack;
+    for (int l = 0; l < total_layers; ++l) a.bwd_off[l] = qp.sp.bwd_off[l];
+    a.acts = acts; a.lin_w = lin_w; a.v0_w = v0_w; a.v1_w = v1_w;
+    a.adv_raw = (const float*)(hsv + qp.hs.adv_off); a.amax = (const int*)(hsv + qp.hs.amax_off);
+    a.amin = (const int*)(hsv + qp.hs.amin_off); a.z = (const float*)(hsv + qp.hs.z_off);
+    a.vraw = (const float*)(hsv + qp.hs.v_off);
+    a.dq = dq; a.d_out_v = d_out_v; a.G = G; a.d_embeds = d_embeds;
+    a.dadv = (float*)(hws + qp.hw.dadv_off); a.dz = (float*)(hws + qp.hw.dz_off);
+    a.dvr = (float*)(hws + qp.hw.dvr_off); a.lin_part = (float*)(hws + qp.hw.part_off);
+    a.status = status;
+    if (b > 0 && n > 0) {
+        KernelTimer kt(HEXGNN_K_QNET_BWD, st);
+        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qbwd<NT_>(a, st)));
+    } else {
+        for (int l = 0; l < total_layers; ++l) {
+            const int in = (l == 0) ? c_in : hidden;
+            (void)hipMemsetAsync(d_wl[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_wr[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_bl[l], 0, sizeof(float) * (size_t)hidden, st);
+        }
+        (void)hipMemsetAsync(a.lin_part, 0, sizeof(float) * (size_t)(b > 0 ? b : 1) * (qp.sp.hp + 1), st);
+        (void)hipMemsetAsync(a.dz, 0, sizeof(float) * (size_t)(b > 0 ? b : 1) * (hidden / 2), st);
+        (void)hipMemsetAsync(a.dvr, 0, sizeof(float) * (size_t)(b > 0 ? b : 1), st);
+    }
+    if (n > 0) {
+        rc = launch_weight_grads(n, c_in, hidden, qp.sp, qp.bp, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part,
+                                 part0, st);
+        if (rc != HEXGNN_OK) return rc;
+    }
+    launch_head_param_grads(b, hidden, mode, a.dz, a.dvr, (const float*)(hsv + qp.hs.pooled_off),
+                            (const float*)(hsv + qp.hs.z_off), a.lin_part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w,
+                            d_v1_b, st);
+    return check_launch();
+}
+
+}  // extern "C"

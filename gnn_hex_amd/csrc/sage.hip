@@ -11,11 +11,9 @@
 // its row r, the feature chunks {16c+4g .. 16c+4g+3} of every in-neighbour straight into registers; these
 // four floats are the k-slices of four consecutive v_mfma_f32_16x16x4_f32 (the K order is permuted
 // consistently on the packed-weight side).  fp32 in / fp32 accumulate: exact fmaf chains, deterministic.
-#include "hexgnn_common.h"
+#include "hexgnn_internal.h"
 
 namespace hexgnn {
-
-constexpr int kMaxLayers = 64;
 
 struct LayerPtrs {
     const float* wl[kMaxLayers];
@@ -23,18 +21,7 @@ struct LayerPtrs {
     const float* wr[kMaxLayers];
 };
 
-struct StackPlan {
-    int hp, nt, L, c_in;
-    bool small_first;
-    size_t fwd_off[kMaxLayers];   // byte offsets into wpack
-    size_t bwd_off[kMaxLayers];
-    size_t bias_off[kMaxLayers];
-    size_t pack_bytes;
-    size_t agg_off[kMaxLayers];   // byte offsets into saved
-    size_t saved_bytes;
-};
-
-static int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
+int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
     const int hp = padded_width(hidden);
     if (hp < 0 || L < 1 || L > kMaxLayers) return HEXGNN_EUNSUPPORTED;
     if (c_in != hidden && (c_in < 1 || c_in > kSmallCin)) return HEXGNN_EUNSUPPORTED;
@@ -204,10 +191,10 @@ __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4 b = wlds[(c * NT + t) * 64 + lane];
-            acc[t] = mfma16x16x4(ag[c][0], b[0], acc[t]);
-            acc[t] = mfma16x16x4(ag[c][1], b[1], acc[t]);
-            acc[t] = mfma16x16x4(ag[c][2], b[2], acc[t]);
-            acc[t] = mfma16x16x4(ag[c][3], b[3], acc[t]);
+            acc[t] = mfma16x16x4(b[0], ag[c][0], acc[t]);
+            acc[t] = mfma16x16x4(b[1], ag[c][1], acc[t]);
+            acc[t] = mfma16x16x4(b[2], ag[c][2], acc[t]);
+            acc[t] = mfma16x16x4(b[3], ag[c][3], acc[t]);
         }
     }
 #pragma unroll
@@ -215,24 +202,23 @@ __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4 b = wlds[((NT + c) * NT + t) * 64 + lane];
-            acc[t] = mfma16x16x4(xs[c][0], b[0], acc[t]);
-            acc[t] = mfma16x16x4(xs[c][1], b[1], acc[t]);
-            acc[t] = mfma16x16x4(xs[c][2], b[2], acc[t]);
-            acc[t] = mfma16x16x4(xs[c][3], b[3], acc[t]);
+            acc[t] = mfma16x16x4(b[0], xs[c][0], acc[t]);
+            acc[t] = mfma16x16x4(b[1], xs[c][1], acc[t]);
+            acc[t] = mfma16x16x4(b[2], xs[c][2], acc[t]);
+            acc[t] = mfma16x16x4(b[3], xs[c][3], acc[t]);
         }
     }
-    // epilogue: lane holds D[4g+q][16t + (lane&15)]
-    const int cx = lane & 15;
+    // epilogue.  Operands are swapped (a = packed W^T fragment, b = the row fragment), so the MFMA computes the
+    // TRANSPOSED tile: lane (r,g) holds y[row0+r][16t+4g .. 16t+4g+3] -- the same lane layout as the input rows.
+    if (row < n) {
+        f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * HP) + g;
+        const f32x4* br = reinterpret_cast<const f32x4*>(bias) + g;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const float bv = bias[16 * t + cx];
+        for (int t = 0; t < NT; ++t) {
+            f32x4 v = acc[t] + br[4 * t];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int orow = row0 + 4 * g + q;
-            if (orow < n) {
-                const float v = acc[t][q] + bv;
-                y[(size_t)orow * HP + 16 * t + cx] = v > 0.f ? v : 0.f;
-            }
+            for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+            yr[4 * t] = v;
         }
     }
 }
@@ -287,23 +273,21 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
 #pragma unroll
         for (int t = 0; t < 2 * NT; ++t) {
             const f32x4 b = wlds[(c * 2 * NT + t) * 64 + lane];
-            acc[t] = mfma16x16x4(gx[c][0], b[0], acc[t]);
-            acc[t] = mfma16x16x4(gx[c][1], b[1], acc[t]);
-            acc[t] = mfma16x16x4(gx[c][2], b[2], acc[t]);
-            acc[t] = mfma16x16x4(gx[c][3], b[3], acc[t]);
+            acc[t] = mfma16x16x4(b[0], gx[c][0], acc[t]);
+            acc[t] = mfma16x16x4(b[1], gx[c][1], acc[t]);
+            acc[t] = mfma16x16x4(b[2], gx[c][2], acc[t]);
+            acc[t] = mfma16x16x4(b[3], gx[c][3], acc[t]);
         }
     }
-    const int cx = lane & 15;
+    // transposed tiles (see the forward kernel): lane (r,g) holds out[row0+r][16t+4g .. +3]
+    if (row < n) {
+        const float sc = invdeg[row];
+        f32x4* da = reinterpret_cast<f32x4*>(dagg_out + (size_t)row * HP) + g;
+        f32x4* dx = reinterpret_cast<f32x4*>(dxs_out + (size_t)row * HP) + g;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int orow = row0 + 4 * g + q;
-        if (orow < n) {
-            const float sc = invdeg[orow];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                dagg_out[(size_t)orow * HP + 16 * t + cx] = acc[t][q] * sc;
-                dxs_out[(size_t)orow * HP + 16 * t + cx] = acc[NT + t][q];
-            }
+        for (int t = 0; t < NT; ++t) {
+            da[4 * t] = acc[t] * sc;
+            dx[4 * t] = acc[NT + t];
         }
     }
 }
@@ -459,18 +443,23 @@ __global__ __launch_bounds__(256) void sage_first_dw_kernel(
     }
 }
 
-__global__ void sage_first_dw_reduce_kernel(int S, int hp, int hidden, int c_in, const float* __restrict__ part,
-                                            float* __restrict__ dwl, float* __restrict__ dbl, float* __restrict__ dwr) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void sage_first_dw_reduce_kernel(
+    int S, int hp, int hidden, int c_in, const float* __restrict__ part, float* __restrict__ dwl,
+    float* __restrict__ dbl, float* __restrict__ dwr) {
+    // one wave per output element; lanes stride over the S partial slabs, fixed-shape tree => deterministic
+    const int idx = blockIdx.x, lane = threadIdx.x;
     const int per = 2 * c_in + 1;
-    if (idx >= hidden * per) return;
     const int o = idx / per, c = idx % per;
     const int q = c < c_in ? c : (c < 2 * c_in ? kSmallCin + (c - c_in) : 16);
     float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += part[((size_t)s * hp + o) * 17 + q];
-    if (c < c_in) dwl[o * c_in + c] = sum;
-    else if (c < 2 * c_in) dwr[o * c_in + (c - c_in)] = sum;
-    else dbl[o] = sum;
+    for (int s = lane; s < S; s += 64) sum += part[((size_t)s * hp + o) * 17 + q];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) {
+        if (c < c_in) dwl[o * c_in + c] = sum;
+        else if (c < 2 * c_in) dwr[o * c_in + (c - c_in)] = sum;
+        else dbl[o] = sum;
+    }
 }
 
 // ---- host-side dispatch ---------------------------------------------------------------------------------
@@ -533,11 +522,7 @@ static int dw_rows_per_slice(int n, int S) {
     return (r + 31) / 32 * 32;
 }
 
-struct BwdPlan {
-    size_t g_off, pair_off[2][2], part_off, part0_off, total;
-    int S, rps;
-};
-static void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
+void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     const size_t slab = align_up(sizeof(float) * (size_t)n * p.hp, 256);
     size_t off = 0;
     b->g_off = off; off += slab * p.L;
@@ -545,8 +530,55 @@ static void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     b->S = dw_slices(n);
     b->rps = dw_rows_per_slice(n, b->S);
     b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * b->S * p.hp * (2 * p.hp + 1), 256);
-    b->part0_off = off; off += align_up(sizeof(float) * (size_t)b->S * p.hp * 17, 256);
+    b->rps0 = 128;
+    b->S0 = (n + b->rps0 - 1) / b->rps0; if (b->S0 < 1) b->S0 = 1;
+    b->part0_off = off; off += align_up(sizeof(float) * (size_t)b->S0 * p.hp * 17, 256);
     b->total = off;
+}
+
+int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
+                const float* const* wr, void* wpack, hipStream_t st) {
+    PackArgs pa;
+    for (int l = 0; l < p.L; ++l) {
+        if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
+        pa.p.wl[l] = wl[l]; pa.p.bl[l] = bl[l]; pa.p.wr[l] = wr[l];
+        pa.fwd_off[l] = p.fwd_off[l]; pa.bwd_off[l] = p.bwd_off[l]; pa.bias_off[l] = p.bias_off[l];
+    }
+    pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
+    const int pack_elems = 2 * p.nt * p.nt * 256;
+    sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
+    return HEXGNN_OK;
+}
+
+int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
+                        int x_stride, const float* acts, const char* sv, const float* G, float* const* d_wl,
+                        float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st) {
+    const size_t slab = (size_t)n * p.hp;
+    const int first_hidden = p.small_first ? 1 : 0;
+    const int nh = p.L - first_hidden;
+    if (nh > 0) {
+        DwArgs da;
+        DwReduceArgs ra;
+        for (int i = 0; i < nh; ++i) {
+            const int l = first_hidden + i;
+            da.xin[i] = l == 0 ? x : acts + slab * (l - 1);
+            da.agg[i] = (const float*)(sv + p.agg_off[l]);
+            da.g[i] = G + slab * l;
+            ra.dwl[i] = d_wl[l]; ra.dbl[i] = d_bl[l]; ra.dwr[i] = d_wr[l];
+        }
+        da.n = n; da.rows_per_slice = b.rps; da.S = b.S;
+        ra.S = b.S; ra.hp = p.hp; ra.hidden = hidden;
+        HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
+        const int tot = hidden * (2 * hidden + 1);
+        sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
+    }
+    if (p.small_first) {
+        sage_first_dw_kernel<<<b.S0, 256, 0, st>>>(n, c_in, p.hp, b.rps0, G, (const float*)(sv + p.agg_off[0]), x,
+                                                   x_stride, part0);
+        const int tot = hidden * (2 * c_in + 1);
+        sage_first_dw_reduce_kernel<<<tot, 64, 0, st>>>(b.S0, p.hp, hidden, c_in, part0, d_wl[0], d_bl[0], d_wr[0]);
+    }
+    return HEXGNN_OK;
 }
 
 }  // namespace hexgnn
@@ -581,15 +613,8 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     if (need_backward && !saved) return HEXGNN_EINVAL;
     if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
 
-    PackArgs pa;
-    for (int l = 0; l < p.L; ++l) {
-        if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
-        pa.p.wl[l] = wl[l]; pa.p.bl[l] = bl[l]; pa.p.wr[l] = wr[l];
-        pa.fwd_off[l] = p.fwd_off[l]; pa.bwd_off[l] = p.bwd_off[l]; pa.bias_off[l] = p.bias_off[l];
-    }
-    pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
-    const int pack_elems = 2 * p.nt * p.nt * 256;
-    sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
+    rc = launch_pack(p, c_in, hidden, wl, bl, wr, wpack, st);
+    if (rc != HEXGNN_OK) return rc;
     if (n == 0) return check_launch();
 
     const size_t slab = (size_t)n * p.hp;
@@ -682,31 +707,8 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
         sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, nullptr, dx);
     }
 
-    // weight gradients: one batched launch over all hidden-input layers
-    const int nh = p.L - first_hidden;
-    if (nh > 0) {
-        DwArgs da;
-        DwReduceArgs ra;
-        for (int i = 0; i < nh; ++i) {
-            const int l = first_hidden + i;
-            da.xin[i] = l == 0 ? x : acts + slab * (l - 1);
-            da.agg[i] = (const float*)(sv + p.agg_off[l]);
-            da.g[i] = G + slab * l;
-            ra.dwl[i] = d_wl[l]; ra.dbl[i] = d_bl[l]; ra.dwr[i] = d_wr[l];
-        }
-        da.n = n; da.rows_per_slice = b.rps; da.S = b.S;
-        ra.S = b.S; ra.hp = p.hp; ra.hidden = hidden;
-        HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
-        const int tot = hidden * (2 * hidden + 1);
-        sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
-    }
-    if (p.small_first) {
-        sage_first_dw_kernel<<<b.S, 256, 0, st>>>(n, c_in, p.hp, b.rps, G, (const float*)(sv + p.agg_off[0]), x,
-                                                  x_stride, part0);
-        const int tot = hidden * (2 * c_in + 1);
-        sage_first_dw_reduce_kernel<<<(tot + 255) / 256, 256, 0, st>>>(b.S, p.hp, hidden, c_in, part0, d_wl[0],
-                                                                       d_bl[0], d_wr[0]);
-    }
+    rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);
+    if (rc != HEXGNN_OK) return rc;
     return check_launch();
 }
 

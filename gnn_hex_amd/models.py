@@ -319,14 +319,39 @@ class DuellingTwoHeaded(torch.nn.Module):
         x2 = x[:, :2]
 
         gs = ops.GraphStructure(edge_index, n)           # edge_index CSR-sorted once per batch
+        gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
+        head = self.maker_head if is_maker else self.breaker_head
+        mode = 2 if advantages_only else (1 if seperate else 0)
+
+        # fused per-graph path (one launch per direction) when every graph fits a workgroup's LDS
+        max_nodes = getattr(x, "_hex_max_nodes", None)
+        if max_nodes is None and ops._FUSED_ENABLED:
+            max_nodes = int((gptr[1:] - gptr[:-1]).max()) if b > 0 else 0     # host sync (no size hint given)
+        h = self.gnn.hidden_channels
+        if max_nodes is not None and ops.qnet_fused_supported(self.gnn.in_channels, h, max_nodes) \
+                and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels:
+            params = []
+            for conv in list(self.gnn.convs) + list(head.gnn.convs):
+                params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
+            vh = head.value_head
+            params += [head.linear.weight, head.linear.bias, vh.layers[0].weight, vh.layers[0].bias,
+                       vh.layers[1].weight, vh.layers[1].bias]
+            sink = self.activations_hook if torch.is_grad_enabled() else None
+            outs = ops.QNetFusedFn.apply(x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs),
+                                         len(head.gnn.convs), mode, sink, *params)
+            self.final_conv_acts = outs[-1]
+            if mode == 2:
+                return outs[0].view(-1, 1)
+            if mode == 1:
+                return outs[0].squeeze(), outs[1].squeeze()
+            return outs[0].squeeze()
+
+        # general layer-major path (any graph size, hidden <= 128)
         embeds = self.gnn(x2, edge_index, set_cache=set_cache, _graph=gs)
         self.final_conv_acts = embeds
         if embeds.requires_grad:
             embeds.register_hook(self.activations_hook)
-
-        head = self.maker_head if is_maker else self.breaker_head
         hx = head.gnn(embeds, edge_index, set_cache=set_cache, _graph=gs)
-        gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
         if advantages_only:
             return head._tail(hx, gptr, b, 2).view(-1, 1)
         if seperate:

@@ -264,3 +264,98 @@ class HeadTailFn(torch.autograd.Function):
         if mode == 2:   # value path unused: no gradient for the value head (reference: grads stay None)
             g[2] = g[3] = g[4] = g[5] = None
         return (_logical(dh, hidden), None, None, None, None) + tuple(g)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused per-graph path: whole network in one launch per direction (graphs <= 128 nodes, hidden <= 112)
+# ------------------------------------------------------------------------------------------------
+
+_FUSED_ENABLED = True
+
+
+def set_fused(enabled: bool) -> None:
+    """Enable/disable the fused per-graph kernels (tests exercise both paths)."""
+    global _FUSED_ENABLED
+    _FUSED_ENABLED = bool(enabled)
+
+
+def qnet_fused_supported(c_in: int, hidden: int, max_nodes: int) -> bool:
+    return _FUSED_ENABLED and bool(_lib.lib().hexgnn_qnet_supported(int(c_in), int(hidden), int(max_nodes)))
+
+
+class QNetFusedFn(torch.autograd.Function):
+    """DuellingTwoHeaded.forward (GN0/models.py:537-584) as ONE kernel launch; backward = one data-chain launch +
+    the batched weight-gradient GEMM.  Outputs: mode 0 -> (Q, embeds); 1 -> (V, A-mean(A), embeds);
+    2 -> (2tanh(adv), embeds).  ``embeds`` (final_conv_acts) is returned non-differentiable; its gradient is handed
+    to ``grad_sink(d_embeds)`` during backward (final_conv_grads / Grad-CAM)."""
+
+    @staticmethod
+    def forward(ctx, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
+                head_layers: int, mode: int, grad_sink, *params):
+        L = _lib.lib()
+        dev = x.device
+        n = int(x.shape[0])
+        hp = padded_width(hidden)
+        tot = body_layers + head_layers
+        if x.dtype != torch.float32 or x.stride(1) != 1:
+            x = x.float().contiguous()
+        x_stride = x.stride(0) if n > 0 else c_in
+        params = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous() for p in params]
+        convs, tail = params[:3 * tot], params[3 * tot:]
+        wl, bl, wr = convs[0::3], convs[1::3], convs[2::3]
+        need_bwd = any(ctx.needs_input_grad)
+        acts = torch.empty((tot, n, hp), dtype=torch.float32, device=dev)
+        wpack = _bytes(L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot), dev)
+        saved = _bytes(L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot), dev)
+        q = torch.empty(n, dtype=torch.float32, device=dev)
+        out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        _lib.check(L.hexgnn_qnet_forward(
+            n, b, c_in, hidden, tot, mode, gptr.data_ptr(), gs.rowptr.data_ptr(), gs.col.data_ptr(),
+            gs.invdeg.data_ptr(), x.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr),
+            tail[0].data_ptr(), tail[1].data_ptr(), tail[2].data_ptr(), tail[3].data_ptr(), tail[4].data_ptr(),
+            tail[5].data_ptr(), wpack.data_ptr(), acts.data_ptr(), saved.data_ptr(), int(need_bwd), q.data_ptr(),
+            out_v.data_ptr() if out_v is not None else None, status.data_ptr(), _stream()), "hexgnn_qnet_forward")
+        embeds = acts[body_layers - 1][:, :hidden]
+        ctx.mark_non_differentiable(embeds)
+        if need_bwd:
+            ctx.gs, ctx.gptr = gs, gptr
+            ctx.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride)
+            ctx.bufs = (x, acts, saved, wpack, tail, status)
+            ctx.param_shapes = [p.shape for p in params]
+            ctx.grad_sink = grad_sink
+        if mode == 1:
+            return out_v, q, embeds
+        return q, embeds
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        L = _lib.lib()
+        n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride = ctx.dims
+        x, acts, saved, wpack, tail, status = ctx.bufs
+        gs, gptr = ctx.gs, ctx.gptr
+        dev = acts.device
+        if mode == 1:
+            d_v, dq = gouts[0], gouts[1]
+            d_v = torch.zeros(b, dtype=torch.float32, device=dev) if d_v is None else d_v.float().contiguous()
+        else:
+            dq, d_v = gouts[0], None
+        dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else dq.float().contiguous()
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
+        cg, tg = grads[:3 * tot], grads[3 * tot:]
+        d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if ctx.grad_sink is not None else None
+        ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
+        ws = _bytes(ws_bytes, dev)
+        _lib.check(L.hexgnn_qnet_backward(
+            n, b, c_in, hidden, tot, body_layers, mode, gptr.data_ptr(), gs.rowptr_t.data_ptr(),
+            gs.col_t.data_ptr(), gs.invdeg.data_ptr(), x.data_ptr(), x_stride, acts.data_ptr(), saved.data_ptr(),
+            wpack.data_ptr(), tail[0].data_ptr(), tail[2].data_ptr(), tail[4].data_ptr(), dq.data_ptr(),
+            d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
+            _ptr_array(cg[0::3]), _ptr_array(cg[1::3]), _ptr_array(cg[2::3]), tg[0].data_ptr(), tg[1].data_ptr(),
+            tg[2].data_ptr(), tg[3].data_ptr(), tg[4].data_ptr(), tg[5].data_ptr(), ws.data_ptr(), ws_bytes,
+            status.data_ptr(), _stream()), "hexgnn_qnet_backward")
+        if ctx.grad_sink is not None:
+            ctx.grad_sink(d_emb[:, :hidden])
+        if mode == 2:
+            tg[2] = tg[3] = tg[4] = tg[5] = None
+        return (None,) * 10 + tuple(cg) + tuple(tg)

@@ -117,6 +117,35 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
                          float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
                          void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
 
+/* ---- fused per-graph path: the WHOLE network (raw first layer, all body + head SAGE layers, head tail) in one
+ *      launch per direction, one workgroup per graph with the node features resident in LDS.  Usable when
+ *      hexgnn_qnet_supported(): hidden <= 112, c_in <= 8, every graph <= 128 nodes (status bit 0 is set and the
+ *      graph skipped otherwise; bit 1: an edge leaves its graph).  wl/bl/wr list the body layers followed by the
+ *      layers of the head that is evaluated (HOST arrays, total_layers entries).  saved/wpack/acts are produced
+ *      by the forward call and consumed by the backward call of the same step.  Same results as the
+ *      sage_stack + head calls above (same fmaf chains per output element). ------------------------------- */
+int hexgnn_qnet_supported(int c_in, int hidden, int max_nodes_per_graph);
+size_t hexgnn_qnet_saved_bytes(int n, int b, int c_in, int hidden, int total_layers);
+int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,
+                        const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
+                        const float* const* wl, const float* const* bl, const float* const* wr,
+                        const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
+                        const float* v1_w, const float* v1_b,
+                        void* wpack /* hexgnn_sage_stack_pack_bytes(c_in, hidden, total_layers) */,
+                        float* acts /*[total_layers][n][HP]*/, void* saved, int need_backward,
+                        float* q /*[n]*/, float* out_v /*[b] (mode 1) or NULL*/, int* status /*[1], caller-zeroed*/,
+                        hexgnn_stream_t stream);
+size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, int total_layers);
+/* d_embeds: optional [n][HP] gradient w.r.t. the output of body layer body_layers-1 (final_conv_grads). */
+int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode,
+                         const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                         const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                         const float* lin_w, const float* v0_w, const float* v1_w,
+                         const float* dq, const float* d_out_v, float* d_embeds,
+                         float* const* d_wl, float* const* d_bl, float* const* d_wr,
+                         float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
+                         void* workspace, size_t workspace_bytes, int* status, hexgnn_stream_t stream);
+
 /* ---- in-library kernel timing: HIP events recorded on the launch stream around every launch of ONE
  *      kernel class (bench.py's live roofline measurement; torch.cuda.Event would only see torch's current
  *      stream and whole calls).  Not for use under graph capture. --------------------------------------- */
@@ -128,7 +157,9 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
 #define HEXGNN_K_SAGE_FIRST 5 /* raw-feature first layer forward */
 #define HEXGNN_K_COMBINE 6
 #define HEXGNN_K_CSR 7        /* the four CSR-build kernels together */
-#define HEXGNN_K_COUNT 8
+#define HEXGNN_K_QNET_FWD 8   /* fused per-graph forward (whole network, one launch) */
+#define HEXGNN_K_QNET_BWD 9   /* fused per-graph backward data chain */
+#define HEXGNN_K_COUNT 10
 int hexgnn_profile_enable(int kernel_class); /* -1: off.  Clears earlier samples. */
 /* Waits for the recorded events; returns the number of launches and their summed duration. */
 int hexgnn_profile_read(int* launches, float* total_ms);

@@ -13,6 +13,16 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
+@pytest.fixture(params=[True, False], ids=["fused", "layered"], autouse=True)
+def _both_paths(request):
+    """Every parity test runs through the fused per-graph kernels and through the general layer-major kernels
+    (graphs > 128 nodes or hidden > 112 always take the latter)."""
+    from gnn_hex_amd import ops
+    ops.set_fused(request.param)
+    yield
+    ops.set_fused(True)
+
+
 def _step(model, x, ei, batch, ptr, sel, tgt, **kw):
     model.zero_grad(set_to_none=True)
     q = model(x, ei, batch, ptr, **kw)
