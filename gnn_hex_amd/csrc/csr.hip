@@ -167,10 +167,15 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* 
     const int tiles = (n + 1 + 1023) / 1024;
     int* tsum = (int*)((char*)workspace + align_up(sizeof(int) * 2 * (size_t)(n > 0 ? n : 1), 256));
     int* tsum_t = tsum + tiles;
-    (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(n + 1), stream);
-    (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
-    (void)hipMemsetAsync(status, 0, sizeof(int), stream);
-    if (n > 0) (void)hipMemsetAsync(cur, 0, sizeof(int) * 2 * (size_t)n, stream);
+    if (rowptr_t == rowptr + (n + 1) && status == rowptr_t + (n + 1) && cur == status + 1) {
+        // caller laid out [rowptr | rowptr_t | status | workspace] contiguously: one memset instead of four
+        (void)hipMemsetAsync(rowptr, 0, sizeof(int) * ((size_t)2 * (n + 1) + 1 + 2 * (size_t)n), stream);
+    } else {
+        (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(n + 1), stream);
+        (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
+        (void)hipMemsetAsync(status, 0, sizeof(int), stream);
+        if (n > 0) (void)hipMemsetAsync(cur, 0, sizeof(int) * 2 * (size_t)n, stream);
+    }
     KernelTimer kt(HEXGNN_K_CSR, stream);
     if (e > 0)
         csr_count_kernel<<<(e + 255) / 256, 256, 0, stream>>>(n, e, src, dst, rowptr, rowptr_t, status);

@@ -261,8 +261,10 @@ __global__ __launch_bounds__(256) void head_value_wgrad_kernel(int b, int H, con
     const int tid = threadIdx.x, cl = tid & 63, ph = tid >> 6;
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
-    if (c < H4)
+    if (c < H4) {
+#pragma unroll 8
         for (int g = ph; g < b; g += 4) s += dz[(size_t)g * H2 + k] * pooled[(size_t)g * H4 + c];
+    }
     if (ph > 0) red[ph - 1][cl] = s;
     __syncthreads();
     if (ph == 0 && c < H4) d_v0_w[(size_t)k * H4 + c] = s + red[0][cl] + red[1][cl] + red[2][cl];

@@ -12,6 +12,7 @@
 //   Per layer the [agg|x] contraction is split in two K phases (W_l half, W_r half); while one half is in use the
 //   other half of the next phase/layer is streamed L2 -> registers -> LDS (two barriers per layer).
 //   fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): exact fmaf chains, deterministic.
+#include <cstdlib>
 #include "hexgnn_internal.h"
 
 namespace hexgnn {
@@ -21,7 +22,7 @@ constexpr int kRows = 128;            // rows per workgroup
 constexpr int kLdsBytes = 160 * 1024;
 
 struct QFwdArgs {
-    int n, b, c_in, H, L, mode, x_stride, need_backward;
+    int n, b, c_in, H, L, mode, x_stride, need_backward, dbg;
     const int* gptr; const int* rowptr; const int* col; const float* invdeg;
     const float* x;
     const char* wpack; size_t fwd_off[kMaxL]; size_t bias_off[kMaxL];
@@ -83,10 +84,57 @@ __device__ __forceinline__ bool load_csr(char* lds, const int* __restrict__ rowp
     for (int i = threadIdx.x; i <= cnt; i += 512) s_rp[i] = (unsigned short)(rowptr[r0 + i] - e0);
     for (int e = threadIdx.x; e < ne; e += 512) {
         const int j = col[e0 + e] - r0;
-        if (j < 0 || j >= cnt) { atomicOr(status, 2); s_col[e] = 0; }
+        if (j < 0 || j >= cnt) { atomicOr(status, 4); s_col[e] = 0; }
         else s_col[e] = (unsigned char)j;
     }
     return true;
+}
+
+
+
+// global -> LDS copy of `count` float4 with all loads of a thread issued before its first LDS write
+template <int kMaxPer>
+__device__ __forceinline__ void copy_f4_to_lds(f32x4* __restrict__ dst, const f32x4* __restrict__ src, int count) {
+    f32x4 tmp[kMaxPer];
+#pragma unroll
+    for (int k = 0; k < kMaxPer; ++k) { const int i = threadIdx.x + 512 * k; if (i < count) tmp[k] = src[i]; }
+#pragma unroll
+    for (int k = 0; k < kMaxPer; ++k) { const int i = threadIdx.x + 512 * k; if (i < count) dst[i] = tmp[k]; }
+}
+
+// acc[t] += W-fragment(c,t) x row-fragment(c), all NT output tiles per k-chunk with the accumulators ROTATING
+// (consecutive v_mfma never touch the same accumulator: 16x16x4 has a 40-cycle dependent latency, 32-cycle issue).
+template <int NT>
+__device__ __forceinline__ void mfma_chunk(const f32x4* __restrict__ wfrag /* &w[(c*NT)*64 + lane] */, const f32x4 a,
+                                           f32x4 (&acc)[NT]) {
+    f32x4 w[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) w[t] = wfrag[t * 64];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = mfma16x16x4(w[t][j], a[j], acc[t]);
+    }
+}
+
+// ag[c] += rows[j][chunk c] for every neighbour j of this lane's row; the NT reads of one neighbour are issued
+// together (distinct registers) and the next neighbour id is fetched one iteration ahead.
+template <int NT, int XS>
+__device__ __forceinline__ void gather_lds(const float* __restrict__ rows, const unsigned char* __restrict__ s_col,
+                                           int eb, int ee, int g, f32x4 (&ag)[NT]) {
+    int e = eb;
+    int jn = e < ee ? (int)s_col[e] : 0;
+    while (e < ee) {
+        const f32x4* xj = reinterpret_cast<const f32x4*>(rows + jn * XS) + g;
+        ++e;
+        jn = e < ee ? (int)s_col[e] : 0;
+        f32x4 tmp[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) tmp[c] = xj[4 * c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] += tmp[c];
+    }
 }
 
 // ================================================= forward =================================================
@@ -105,7 +153,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const int gi = blockIdx.x;
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
-    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 1); return; }
+    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
     const int H = a.H;
     const int lrow = wave * 16 + r;                 // local row of this lane
     const bool rvalid = lrow < cnt;
@@ -115,36 +163,52 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
 
     // ---- stage W_l of layer 1 into half A; first-layer scratch lives in half B ----
-    if (a.L > 1) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]);
-        for (int i = tid; i < kHalf; i += 512) wbuf[i] = src[i];
-    }
+    if (a.L > 1)
+        copy_f4_to_lds<(LD::kHalf + 511) / 512>(wbuf, reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]), kHalf);
     float* s_w0 = reinterpret_cast<float*>(lds + LD::off_scr_first);  // [2][HP][8]
     float* s_f = s_w0 + 2 * HP * kSmallCin;                          // [kRows][16]: agg0 | x0
     {
-        const float* w0 = reinterpret_cast<const float*>(a.wpack + a.fwd_off[0]);
-        for (int i = tid; i < 2 * HP * kSmallCin; i += 512) s_w0[i] = w0[i];
-        if (tid < kRows) {
-            float ag0[kSmallCin], xs0[kSmallCin];
+        // raw features of the graph's rows -> LDS (x0 half of s_f), first-layer weights -> LDS: all independent
+        // global loads, one barrier; the neighbour sums then run on LDS only.
+        copy_f4_to_lds<(2 * HP * kSmallCin / 4 + 511) / 512>(reinterpret_cast<f32x4*>(s_w0),
+                                                              reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[0]),
+                                                              2 * HP * kSmallCin / 4);
 #pragma unroll
-            for (int qq = 0; qq < kSmallCin; ++qq) { ag0[qq] = 0.f; xs0[qq] = 0.f; }
+        for (int i = tid; i < kRows * kSmallCin; i += 512) {
+            const int rr = i / kSmallCin, qq = i % kSmallCin;
+            s_f[rr * 16 + 8 + qq] = (rr < cnt && qq < a.c_in) ? a.x[(size_t)(r0 + rr) * a.x_stride + qq] : 0.f;
+        }
+        __syncthreads();
+        if (tid < kRows) {
+            float ag0[kSmallCin];
+#pragma unroll
+            for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] = 0.f;
             if (tid < cnt) {
                 const int row = r0 + tid;
-                for (int e = a.rowptr[row]; e < a.rowptr[row + 1]; ++e) {
-                    const float* xr = a.x + (size_t)a.col[e] * a.x_stride;
-                    for (int qq = 0; qq < a.c_in; ++qq) ag0[qq] += xr[qq];
+                if (csr_lds) {
+                    for (int e = s_rp[tid]; e < s_rp[tid + 1]; ++e) {
+                        const float* xr = s_f + (int)s_col[e] * 16 + 8;
+#pragma unroll
+                        for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] += xr[qq];
+                    }
+                } else {
+                    for (int e = a.rowptr[row]; e < a.rowptr[row + 1]; ++e) {
+                        const float* xr = s_f + (a.col[e] - r0) * 16 + 8;
+#pragma unroll
+                        for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] += xr[qq];
+                    }
                 }
                 const float sc = a.invdeg[row];
-                const float* xr = a.x + (size_t)row * a.x_stride;
-                for (int qq = 0; qq < a.c_in; ++qq) { ag0[qq] *= sc; xs0[qq] = xr[qq]; }
-                if (a.need_backward) {
-                    float* ao = reinterpret_cast<float*>(a.saved + a.agg_off[0]) + (size_t)row * kSmallCin;
 #pragma unroll
-                    for (int qq = 0; qq < kSmallCin; ++qq) ao[qq] = ag0[qq];
+                for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] *= sc;
+                if (a.need_backward) {
+                    f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[0]) + (size_t)row * kSmallCin);
+                    ao[0] = f32x4{ag0[0], ag0[1], ag0[2], ag0[3]};
+                    ao[1] = f32x4{ag0[4], ag0[5], ag0[6], ag0[7]};
                 }
             }
 #pragma unroll
-            for (int qq = 0; qq < kSmallCin; ++qq) { s_f[tid * 16 + qq] = ag0[qq]; s_f[tid * 16 + 8 + qq] = xs0[qq]; }
+            for (int qq = 0; qq < kSmallCin; ++qq) s_f[tid * 16 + qq] = ag0[qq];
         }
     }
     __syncthreads();
@@ -187,7 +251,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const size_t slab = (size_t)a.n * HP;
     for (int l = 1; l < a.L; ++l) {
         f32x4 stg[kStage];
-        {   // stream W_r(l) towards half B
+        if (!(a.dbg & 4) || l == 1) {   // stream W_r(l) towards half B
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]) + kHalf;
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
@@ -200,14 +264,9 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             f32x4 ag[NT];
 #pragma unroll
             for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid) {
+            if (rvalid && !(a.dbg & 1)) {
                 if (csr_lds) {
-                    const int eb = s_rp[lrow], ee = s_rp[lrow + 1];
-                    for (int e = eb; e < ee; ++e) {
-                        const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (int)s_col[e] * XS) + g;
-#pragma unroll
-                        for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
-                    }
+                    gather_lds<NT, XS>(xbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, ag);
                 } else {
                     for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
                         const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
@@ -218,45 +277,31 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 const float sc = a.invdeg[grow];
 #pragma unroll
                 for (int c = 0; c < NT; ++c) ag[c] *= sc;
-                if (a.need_backward) {
+                if (a.need_backward && !(a.dbg & 2)) {
                     f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
 #pragma unroll
                     for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
                 }
             }
+            if (!(a.dbg & 8))
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 w = wbuf[(c * NT + t) * 64 + lane];
-                    acc[t] = mfma16x16x4(w[0], ag[c][0], acc[t]);
-                    acc[t] = mfma16x16x4(w[1], ag[c][1], acc[t]);
-                    acc[t] = mfma16x16x4(w[2], ag[c][2], acc[t]);
-                    acc[t] = mfma16x16x4(w[3], ag[c][3], acc[t]);
-                }
-            }
+            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, ag[c], acc);
         }
+        if (!(a.dbg & 4) || l == 1) {
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        }
         __syncthreads();   // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
-        if (l + 1 < a.L) {   // stream W_l(l+1) towards half A
+        if (l + 1 < a.L && !(a.dbg & 4)) {   // stream W_l(l+1) towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
         }
         if (wactive) {
             // phase 2: K-half over W_r (half B) with the self rows kept in registers
+            if (!(a.dbg & 8))
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 w = wbuf[kHalf + (c * NT + t) * 64 + lane];
-                    acc[t] = mfma16x16x4(w[0], xs[c][0], acc[t]);
-                    acc[t] = mfma16x16x4(w[1], xs[c][1], acc[t]);
-                    acc[t] = mfma16x16x4(w[2], xs[c][2], acc[t]);
-                    acc[t] = mfma16x16x4(w[3], xs[c][3], acc[t]);
-                }
-            }
+            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, xs[c], acc);
             const f32x4* br = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]) + g;
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
@@ -267,13 +312,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 xs[t] = v;
                 xr[4 * t] = v;
             }
-            if (rvalid) {
+            if (rvalid && !(a.dbg & 2)) {
                 f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
             }
         }
-        if (l + 1 < a.L) {
+        if (l + 1 < a.L && !(a.dbg & 4)) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
         }
@@ -316,6 +361,18 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         v = wsum64(v);
         if (lane == 0) s_red[wave] = v;
     }
+    // value-MLP weights of this wave's hidden units (k = wave + 8i) -> registers now; the loads fly during pooling
+    constexpr int kKI = 8, kCJ = 8;     // up to 64 hidden units, 4H <= 512 columns
+    float wv[kKI][kCJ];
+#pragma unroll
+    for (int i = 0; i < kKI; ++i) {
+        const int k = wave + 8 * i;
+#pragma unroll
+        for (int j = 0; j < kCJ; ++j) {
+            const int c = lane + 64 * j;
+            wv[i][j] = (k < H2 && c < H4) ? a.v0_w[(size_t)k * H4 + c] : 0.f;
+        }
+    }
     // pooling straight from the LDS rows: column c = tid&127, four row phases
     {
         const int c = tid & 127, ph = tid >> 7;
@@ -354,15 +411,22 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         }
     }
     __syncthreads();
-    for (int k = wave; k < H2; k += 8) {
-        const float* wr = a.v0_w + (size_t)k * H4;
-        float p = 0.f;
-        for (int c = lane; c < H4; c += 64) p += wr[c] * s_pool[c];
-        p = wsum64(p);
-        if (lane == 0) {
-            const float zz = fmaxf(p + a.v0_b[k], 0.f);
-            s_z[k] = zz;
-            a.z[(size_t)gi * H2 + k] = zz;
+    {
+        float pl[kCJ];
+#pragma unroll
+        for (int j = 0; j < kCJ; ++j) { const int c = lane + 64 * j; pl[j] = c < H4 ? s_pool[c] : 0.f; }
+#pragma unroll
+        for (int i = 0; i < kKI; ++i) {
+            const int k = wave + 8 * i;
+            float p = 0.f;
+#pragma unroll
+            for (int j = 0; j < kCJ; ++j) p += wv[i][j] * pl[j];     // same column order as the layered kernel
+            p = wsum64(p);
+            if (lane == 0 && k < H2) {
+                const float zz = fmaxf(p + a.v0_b[k], 0.f);
+                s_z[k] = zz;
+                a.z[(size_t)gi * H2 + k] = zz;
+            }
         }
     }
     __syncthreads();
@@ -405,7 +469,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int gi = blockIdx.x;
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
-    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 1); return; }
+    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
     const int H = a.H, L = a.L;
     const int lrow = wave * 16 + r;
     const bool rvalid = lrow < cnt;
@@ -420,10 +484,17 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     // stage both weight halves of the top layer (tiles t < NT -> half A, t >= NT -> half B)
     if (L > 1) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]);
-        for (int i = tid; i < 2 * kHalf; i += 512) {
-            const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
-            const int dst = (t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li;
-            wbuf[dst] = src[i];
+        constexpr int kPer = (2 * LD::kHalf + 511) / 512;
+        f32x4 tmp[kPer];
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) { const int i = tid + 512 * k; if (i < 2 * kHalf) tmp[k] = src[i]; }
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int i = tid + 512 * k;
+            if (i < 2 * kHalf) {
+                const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
+                wbuf[(t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li] = tmp[k];
+            }
         }
     }
 
@@ -468,7 +539,8 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         __syncthreads();
         for (int c = tid; c < H4; c += 512) {
             float p = 0.f;
-            for (int k = 0; k < H2; ++k) p += a.v0_w[(size_t)k * H4 + c] * s_dz[k];
+#pragma unroll 16
+            for (int k = 0; k < H2; ++k) p += a.v0_w[(size_t)k * H4 + c] * s_dz[k];   // independent loads, 16 in flight
             s_dp[c] = p;
         }
     }
@@ -569,16 +641,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             }
             // phase 1: dAggS = (G W_l) / deg     (half A)
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 w = wbuf[(c * NT + t) * 64 + lane];
-                    acc[t] = mfma16x16x4(w[0], gx[c][0], acc[t]);
-                    acc[t] = mfma16x16x4(w[1], gx[c][1], acc[t]);
-                    acc[t] = mfma16x16x4(w[2], gx[c][2], acc[t]);
-                    acc[t] = mfma16x16x4(w[3], gx[c][3], acc[t]);
-                }
-            }
+            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, gx[c], acc);
         }
         __syncthreads();   // barrier A: gathers of the previous layer are done (dbuf free); half A free
         if (more) {
@@ -603,16 +666,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         if (wactive) {
             // phase 2: dXs = G W_r     (half B)
 #pragma unroll
-            for (int c = 0; c < NT; ++c) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 w = wbuf[kHalf + (c * NT + t) * 64 + lane];
-                    dxs[t] = mfma16x16x4(w[0], gx[c][0], dxs[t]);
-                    dxs[t] = mfma16x16x4(w[1], gx[c][1], dxs[t]);
-                    dxs[t] = mfma16x16x4(w[2], gx[c][2], dxs[t]);
-                    dxs[t] = mfma16x16x4(w[3], gx[c][3], dxs[t]);
-                }
-            }
+            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, gx[c], dxs);
         }
         __syncthreads();   // barrier B: dAggS rows + half A visible; half B free
         if (more) {
@@ -624,12 +678,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         for (int t = 0; t < NT; ++t) gx[t] = dxs[t];
         if (rvalid) {
             if (csr_lds) {
-                const int eb = s_rp[lrow], ee = s_rp[lrow + 1];
-                for (int e = eb; e < ee; ++e) {
-                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (int)s_col[e] * XS) + g;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
-                }
+                gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, gx);
             } else {
                 for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
                     const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
@@ -763,6 +812,7 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     QFwdArgs a;
     a.n = n; a.b = b; a.c_in = c_in; a.H = hidden; a.L = total_layers; a.mode = mode; a.x_stride = x_stride;
     a.need_backward = need_backward;
+    { const char* e = getenv("HEXGNN_DBG_ABLATE"); a.dbg = e ? atoi(e) : 0; }   // timing-only ablation (wrong results)
     a.gptr = gptr; a.rowptr = rowptr; a.col = col; a.invdeg = invdeg; a.x = x;
     a.wpack = (const char*)wpack;
     for (int l = 0; l < total_layers; ++l) {

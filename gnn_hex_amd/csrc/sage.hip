@@ -345,22 +345,38 @@ __global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __res
     for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    for (int rc = r_beg; rc < r_end; rc += R) {
-        constexpr int Q = NT * 4;  // float4 pieces per row
-        for (int p = tid; p < R * Q; p += NTHR) {
+    // software pipeline: the global loads of chunk i+1 are in flight while chunk i is multiplied out of LDS
+    constexpr int Q = NT * 4;                       // float4 pieces per row
+    constexpr int kPer = (R * Q + NTHR - 1) / NTHR; // pieces per thread per matrix
+    f32x4 ra[kPer], rx[kPer], rg[kPer];
+    auto issue = [&](int rc) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int p = tid + NTHR * k;
             const int rr = p / Q, q = p % Q;
             const int row = rc + rr;
-            f32x4 va = f32x4{0.f, 0.f, 0.f, 0.f}, vx = va, vg = va;
-            if (row < r_end) {
-                va = reinterpret_cast<const f32x4*>(agg + (size_t)row * HP)[q];
-                vx = reinterpret_cast<const f32x4*>(xin + (size_t)row * HP)[q];
-                vg = reinterpret_cast<const f32x4*>(gg + (size_t)row * HP)[q];
+            ra[k] = f32x4{0.f, 0.f, 0.f, 0.f}; rx[k] = ra[k]; rg[k] = ra[k];
+            if (p < R * Q && row < r_end) {
+                ra[k] = reinterpret_cast<const f32x4*>(agg + (size_t)row * HP)[q];
+                rx[k] = reinterpret_cast<const f32x4*>(xin + (size_t)row * HP)[q];
+                rg[k] = reinterpret_cast<const f32x4*>(gg + (size_t)row * HP)[q];
             }
-            *reinterpret_cast<f32x4*>(&As[rr * AS + 4 * q]) = va;
-            *reinterpret_cast<f32x4*>(&As[rr * AS + HP + 4 * q]) = vx;
-            *reinterpret_cast<f32x4*>(&Gs[rr * GS + 4 * q]) = vg;
+        }
+    };
+    if (r_beg < r_end) issue(r_beg);
+    for (int rc = r_beg; rc < r_end; rc += R) {
+#pragma unroll
+        for (int k = 0; k < kPer; ++k) {
+            const int p = tid + NTHR * k;
+            if (p < R * Q) {
+                const int rr = p / Q, q = p % Q;
+                *reinterpret_cast<f32x4*>(&As[rr * AS + 4 * q]) = ra[k];
+                *reinterpret_cast<f32x4*>(&As[rr * AS + HP + 4 * q]) = rx[k];
+                *reinterpret_cast<f32x4*>(&Gs[rr * GS + 4 * q]) = rg[k];
+            }
         }
         __syncthreads();
+        if (rc + R < r_end) issue(rc + R);
 #pragma unroll
         for (int ks = 0; ks < R / 4; ++ks) {
             const float av = Gs[(4 * ks + kq) * GS + 16 * w + m];
@@ -414,20 +430,32 @@ __global__ void sage_dw_reduce_kernel(DwReduceArgs a, const float* __restrict__ 
 
 // ---- raw first layer weight gradient: partial [S][hp][17] = sum_rows G[row][o] * (agg0[row][0..7] | x0[row][0..7] | 1) ----
 __global__ __launch_bounds__(256) void sage_first_dw_kernel(
-    int n, int c_in, int hp, int rows_per_slice, const float* __restrict__ g, const float* __restrict__ agg0,
+    int n, int c_in, int hp, int rows_per_slice /* == 128 */, const float* __restrict__ g, const float* __restrict__ agg0,
     const float* __restrict__ x, int x_stride, float* __restrict__ part) {
+    __shared__ float s_in[128][16];   // per row: agg0[0..7] | x0[0..7]
     __shared__ float red[128 * 17];
     const int tid = threadIdx.x, o = tid & 127, ph = tid >> 7;
     const int r_beg = blockIdx.x * rows_per_slice, r_end = min(n, r_beg + rows_per_slice);
+    const int rows = r_end - r_beg;
+    for (int i = tid; i < 128 * 16; i += 256) {
+        const int rr = i >> 4, q = i & 15;
+        float v = 0.f;
+        if (rr < rows) {
+            if (q < kSmallCin) v = agg0[(size_t)(r_beg + rr) * kSmallCin + q];
+            else if (q - kSmallCin < c_in) v = x[(size_t)(r_beg + rr) * x_stride + (q - kSmallCin)];
+        }
+        s_in[rr][q] = v;
+    }
+    __syncthreads();
     float acc[17];
 #pragma unroll
     for (int q = 0; q < 17; ++q) acc[q] = 0.f;
     if (o < hp) {
-        for (int row = r_beg + ph; row < r_end; row += 2) {
-            const float gv = g[(size_t)row * hp + o];
+#pragma unroll 4
+        for (int rr = ph; rr < rows; rr += 2) {
+            const float gv = g[(size_t)(r_beg + rr) * hp + o];
 #pragma unroll
-            for (int q = 0; q < kSmallCin; ++q) acc[q] += gv * agg0[(size_t)row * kSmallCin + q];
-            for (int q = 0; q < c_in; ++q) acc[kSmallCin + q] += gv * x[(size_t)row * x_stride + q];
+            for (int q = 0; q < 16; ++q) acc[q] += gv * s_in[rr][q];
             acc[16] += gv;
         }
     }

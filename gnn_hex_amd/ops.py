@@ -59,14 +59,16 @@ class GraphStructure:
         n, e = int(num_nodes), int(edge_index.shape[1])
         L = _lib.lib()
         self.n, self.e = n, e
-        self.rowptr = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        self.rowptr_t = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        ws_bytes = L.hexgnn_csr_workspace_bytes(n, e)
+        # one int32 buffer [rowptr | rowptr_t | status | workspace]: the build zeroes it with a single memset
+        ibuf = torch.empty(2 * (n + 1) + 1 + (ws_bytes + 3) // 4, dtype=torch.int32, device=dev)
+        self.rowptr = ibuf[:n + 1]
+        self.rowptr_t = ibuf[n + 1:2 * (n + 1)]
+        self.status = ibuf[2 * (n + 1):2 * (n + 1) + 1]
+        ws = ibuf[2 * (n + 1) + 1:]
         self.col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
         self.col_t = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
         self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        self.status = torch.empty(1, dtype=torch.int32, device=dev)
-        ws_bytes = L.hexgnn_csr_workspace_bytes(n, e)
-        ws = _bytes(ws_bytes, dev)
         src = edge_index[0]
         dst = edge_index[1]
         _lib.check(L.hexgnn_csr_build(n, e, src.data_ptr(), dst.data_ptr(), self.rowptr.data_ptr(),
@@ -77,7 +79,8 @@ class GraphStructure:
     def check(self) -> None:
         """Host-synchronising validity check (debug aid; not called on the hot path)."""
         if int(self.status.item()) != 0:
-            raise IndexError("edge_index contains node ids outside [0, %d)" % self.n)
+            raise IndexError("invalid batch structure (status=%d): 1 = node id outside [0,%d), 2 = graph larger than "
+                             "128 nodes reached the fused kernel, 4 = an edge connects two graphs" % (int(self.status.item()), self.n))
 
 
 def graph_ptr(graph_indices: Optional[torch.Tensor], ptr: Optional[torch.Tensor], n: int, device):
@@ -309,7 +312,7 @@ class QNetFusedFn(torch.autograd.Function):
         saved = _bytes(L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot), dev)
         q = torch.empty(n, dtype=torch.float32, device=dev)
         out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
-        status = torch.zeros(1, dtype=torch.int32, device=dev)
+        status = gs.status      # shared status word (OR-ed into by the kernels)
         _lib.check(L.hexgnn_qnet_forward(
             n, b, c_in, hidden, tot, mode, gptr.data_ptr(), gs.rowptr.data_ptr(), gs.col.data_ptr(),
             gs.invdeg.data_ptr(), x.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr),

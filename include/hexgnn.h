@@ -47,7 +47,8 @@ int hexgnn_padded_width(int hidden);  /* HP; <0 if unsupported */
  * list is sorted ONCE per batch into a target-major CSR (rowptr/col: in-neighbours of each node,
  * ascending) and its transpose (rowptr_t/col_t: out-neighbours, used by the backward gather).
  * invdeg[i] = 1/max(in_degree(i),1) (torch_scatter mean: count.clamp(min=1)).
- * status[0] is set non-zero if an index was outside [0,n) (such edges are dropped).
+ * status[0] |= 1 if an index was outside [0,n) (such edges are dropped).  When rowptr, rowptr_t, status and
+ * workspace are laid out contiguously in that order the build zeroes them with one memset instead of four.
  * src/dst: the two rows of edge_index (int64, length e). */
 size_t hexgnn_csr_workspace_bytes(int n, int e);
 int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst,
@@ -119,8 +120,9 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
 
 /* ---- fused per-graph path: the WHOLE network (raw first layer, all body + head SAGE layers, head tail) in one
  *      launch per direction, one workgroup per graph with the node features resident in LDS.  Usable when
- *      hexgnn_qnet_supported(): hidden <= 112, c_in <= 8, every graph <= 128 nodes (status bit 0 is set and the
- *      graph skipped otherwise; bit 1: an edge leaves its graph).  wl/bl/wr list the body layers followed by the
+ *      hexgnn_qnet_supported(): hidden <= 112, c_in <= 8, every graph <= 128 nodes (status |= 2 and the graph is
+ *      skipped otherwise; status |= 4: an edge leaves its graph).  status is OR-ed into, never cleared, so the
+ *      word written by hexgnn_csr_build (|= 1: node id out of range) can be shared.  wl/bl/wr list the body layers followed by the
  *      layers of the head that is evaluated (HOST arrays, total_layers entries).  saved/wpack/acts are produced
  *      by the forward call and consumed by the backward call of the same step.  Same results as the
  *      sage_stack + head calls above (same fmaf chains per output element). ------------------------------- */
