@@ -99,9 +99,12 @@ def main():
         batches.append(dict(x=xd, ei=ei.to(dev), bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
 
+    plist = list(hip.parameters())
+
     def step(i):
         bt = batches[i & 1]
-        hip.zero_grad(set_to_none=True)
+        for p in plist:              # optimizer.zero_grad(set_to_none=True) over a cached parameter list
+            p.grad = None
         q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
         loss = torch.nn.functional.mse_loss(q[bt["sel"]], bt["tgt"])
         loss.backward()
@@ -191,7 +194,8 @@ def main():
 
 def step_local(hip, batches, i):
     bt = batches[i & 1]
-    hip.zero_grad(set_to_none=True)
+    for p in hip.parameters():
+        p.grad = None
     q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
     torch.nn.functional.mse_loss(q[bt["sel"]], bt["tgt"]).backward()
 

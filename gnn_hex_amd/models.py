@@ -330,12 +330,7 @@ class DuellingTwoHeaded(torch.nn.Module):
         h = self.gnn.hidden_channels
         if max_nodes is not None and ops.qnet_fused_supported(self.gnn.in_channels, h, max_nodes) \
                 and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels:
-            params = []
-            for conv in list(self.gnn.convs) + list(head.gnn.convs):
-                params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
-            vh = head.value_head
-            params += [head.linear.weight, head.linear.bias, vh.layers[0].weight, vh.layers[0].bias,
-                       vh.layers[1].weight, vh.layers[1].bias]
+            params = self._fused_params(head)
             sink = self.activations_hook if torch.is_grad_enabled() else None
             outs = ops.QNetFusedFn.apply(x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs),
                                          len(head.gnn.convs), mode, sink, *params)
@@ -358,6 +353,29 @@ class DuellingTwoHeaded(torch.nn.Module):
             v, a = head._tail(hx, gptr, b, 1)
             return v.squeeze(), a.squeeze()
         return head._tail(hx, gptr, b, 0).squeeze()
+
+    def _fused_params(self, head):
+        """Parameter list of the fused call (body convs, head convs, head tail), cached per head; rebuilt when the
+        module tree changes (grow_*, parameter replacement by ``.to()`` / ``load_state_dict(assign=True)``)."""
+        cache = self.__dict__.setdefault("_fused_cache", {})
+        key = id(head)
+        ent = cache.get(key)
+        sig = (len(self.gnn.convs), len(head.gnn.convs), id(self.gnn.convs[0].lin_l.weight),
+               id(head.linear.weight), id(self.gnn.convs[-1].lin_r.weight))
+        if ent is None or ent[0] != sig:
+            params = []
+            for conv in list(self.gnn.convs) + list(head.gnn.convs):
+                params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
+            vh = head.value_head
+            params += [head.linear.weight, head.linear.bias, vh.layers[0].weight, vh.layers[0].bias,
+                       vh.layers[1].weight, vh.layers[1].bias]
+            ent = (sig, params)
+            cache[key] = ent
+        return ent[1]
+
+    def _apply(self, fn, *args, **kwargs):
+        self.__dict__.pop("_fused_cache", None)
+        return super()._apply(fn, *args, **kwargs)
 
     def simple_forward(self, data: Union[Data, Batch]):
         if isinstance(data, Batch) or getattr(data, "batch", None) is not None:

@@ -325,7 +325,12 @@ class QNetFusedFn(torch.autograd.Function):
             ctx.gs, ctx.gptr = gs, gptr
             ctx.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride)
             ctx.bufs = (x, acts, saved, wpack, tail, status)
-            ctx.param_shapes = [p.shape for p in params]
+            ctx.params = params
+            offs, o = [], 0
+            for p in params:
+                offs.append(o)
+                o += p.numel()
+            ctx.param_offsets = (offs, o)
             ctx.grad_sink = grad_sink
         if mode == 1:
             return out_v, q, embeds
@@ -344,8 +349,16 @@ class QNetFusedFn(torch.autograd.Function):
         else:
             dq, d_v = gouts[0], None
         dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else dq.float().contiguous()
-        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
-        cg, tg = grads[:3 * tot], grads[3 * tot:]
+        # ONE flat gradient buffer for all parameters (views are handed to autograd): one allocation instead of
+        # 66, and the layout a single RCCL all-reduce wants (gnn_hex_amd.dist.GradSync adopts it without copies).
+        params = ctx.params
+        offs, total = ctx.param_offsets
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        grads = list(torch._C._nn.unflatten_dense_tensors(flat, params))
+        base = flat.data_ptr()
+        ptrs = [base + 4 * o for o in offs]
+        cp, tp = ptrs[:3 * tot], ptrs[3 * tot:]
+        vp_arr = C.c_void_p * tot
         d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if ctx.grad_sink is not None else None
         ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
         ws = _bytes(ws_bytes, dev)
@@ -354,9 +367,9 @@ class QNetFusedFn(torch.autograd.Function):
             gs.col_t.data_ptr(), gs.invdeg.data_ptr(), x.data_ptr(), x_stride, acts.data_ptr(), saved.data_ptr(),
             wpack.data_ptr(), tail[0].data_ptr(), tail[2].data_ptr(), tail[4].data_ptr(), dq.data_ptr(),
             d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
-            _ptr_array(cg[0::3]), _ptr_array(cg[1::3]), _ptr_array(cg[2::3]), tg[0].data_ptr(), tg[1].data_ptr(),
-            tg[2].data_ptr(), tg[3].data_ptr(), tg[4].data_ptr(), tg[5].data_ptr(), ws.data_ptr(), ws_bytes,
-            status.data_ptr(), _stream()), "hexgnn_qnet_backward")
+            vp_arr(*cp[0::3]), vp_arr(*cp[1::3]), vp_arr(*cp[2::3]), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5],
+            ws.data_ptr(), ws_bytes, status.data_ptr(), _stream()), "hexgnn_qnet_backward")
+        cg, tg = grads[:3 * tot], grads[3 * tot:]
         if ctx.grad_sink is not None:
             ctx.grad_sink(d_emb[:, :hidden])
         if mode == 2:
