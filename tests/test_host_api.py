@@ -1,0 +1,125 @@
+"""CPU: the drop-in surface (module tree, state-dict compatibility, grow_*), the Data/Batch stand-ins, and the
+C-ABI library: it loads and exports every symbol include/hexgnn.h declares (no compute calls without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from helpers import batch_tensors, model_args
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from gnn_hex_amd import _lib
+    header = open(os.path.join(ROOT, "include", "hexgnn.h")).read()
+    declared = sorted(set(re.findall(r"\b(hexgnn_[a-z0-9_]+)\s*\(", header)))
+    assert len(declared) >= 25
+    L = _lib.lib()
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), "libhexgnn.so does not export %s" % name
+    assert set(declared) == set(_lib.exported_symbols()), "ctypes signature table out of sync with the header"
+    assert L.hexgnn_abi_version() == 1
+    assert L.hexgnn_padded_width(110) == 112 and L.hexgnn_padded_width(35) == 48 and L.hexgnn_padded_width(129) < 0
+    assert L.hexgnn_strerror(-3).decode() == "workspace too small"
+    assert L.hexgnn_qnet_supported(2, 110, 123) == 1 and L.hexgnn_qnet_supported(2, 110, 146) == 0
+    assert L.hexgnn_qnet_supported(2, 128, 51) == 0
+    # workspace queries are pure host arithmetic
+    assert L.hexgnn_sage_stack_pack_bytes(2, 110, 15) > 14 * 2 * 100352
+    assert L.hexgnn_sage_stack_pack_bytes(2, 129, 3) == 0
+
+
+def test_argument_validation_without_gpu():
+    """Entry points reject bad arguments before touching the device."""
+    from gnn_hex_amd import _lib
+    L = _lib.lib()
+    assert L.hexgnn_csr_build(-1, 0, None, None, None, None, None, None, None, None, None, 0, None) == -1
+    assert L.hexgnn_graph_ptr(4, 2, None, None, None) == -1
+    assert L.hexgnn_pad_rows(4, 200, None, 200, None, None) == -2
+    assert L.hexgnn_profile_enable(99) == -1 and L.hexgnn_profile_enable(-1) == 0
+
+
+def test_model_tree_matches_reference_layout():
+    from gnn_hex_amd.models import get_pre_defined
+    from oracle.model_ref import get_pre_defined_ref
+    for (l, h) in ((10, 35), (15, 110)):
+        a = get_pre_defined("modern_two_headed", model_args(l, h))
+        b = get_pre_defined_ref("modern_two_headed", model_args(l, h))
+        sa, sb = a.state_dict(), b.state_dict()
+        assert list(sa.keys()) == list(sb.keys())
+        assert all(sa[k].shape == sb[k].shape for k in sa)
+        a.load_state_dict(sb)                       # a reference-format checkpoint loads unchanged
+    for attr in ("gnn", "maker_head", "breaker_head", "after_embed_norm", "supports_cache", "value_activation",
+                 "advantage_activation", "final_conv_acts"):
+        assert hasattr(a, attr)
+    assert a.after_embed_norm is None and a.supports_cache
+    for name in ("forward", "simple_forward", "grow_depth", "grow_width", "export_norm_cache", "import_norm_cache"):
+        assert callable(getattr(a, name))
+    assert a.export_norm_cache() == [None, None, None]
+
+
+def test_unsupported_configurations_fail_loudly():
+    from gnn_hex_amd.models import get_pre_defined
+    with pytest.raises(NotImplementedError):
+        get_pre_defined("two_headed", model_args(3, 8))
+    args = model_args(3, 8)
+    args.norm = True
+    with pytest.raises(NotImplementedError):
+        get_pre_defined("modern_two_headed", args)
+    args = model_args(3, 8)
+    args.noisy_dqn = True
+    with pytest.raises(NotImplementedError):
+        get_pre_defined("modern_two_headed", args)
+
+
+def test_cpu_tensors_raise_not_fall_back():
+    from gnn_hex_amd._lib import HexGnnError
+    from gnn_hex_amd.models import get_pre_defined
+    m = get_pre_defined("modern_two_headed", model_args(3, 8))
+    x, ei, batch, ptr = batch_tensors("D0", [5])
+    with pytest.raises(HexGnnError):
+        m(x, ei, batch, ptr)
+
+
+def test_grow_depth_and_width_parameter_surgery():
+    """GN0/models.py:166-238,336-360,494-508: identity layers / zero-padded widening (host logic only)."""
+    from gnn_hex_amd.models import get_pre_defined
+    torch.manual_seed(0)
+    m = get_pre_defined("modern_two_headed", model_args(3, 8))
+    old = {k: v.clone() for k, v in m.state_dict().items()}
+    m.grow_depth(2)
+    assert m.gnn.num_layers == 5 and len(m.gnn.convs) == 5
+    c = m.gnn.convs[4]
+    assert torch.equal(c.lin_r.weight.data, torch.eye(8)) and c.lin_l.weight.abs().sum() == 0 and c.lin_l.bias.abs().sum() == 0
+    m.grow_width(12)
+    sd = m.state_dict()
+    assert sd["gnn.convs.0.lin_l.weight"].shape == (12, 2) and sd["gnn.convs.1.lin_l.weight"].shape == (12, 12)
+    assert torch.equal(sd["gnn.convs.1.lin_l.weight"][:8, :8], old["gnn.convs.1.lin_l.weight"])
+    assert sd["gnn.convs.1.lin_l.weight"][:8, 8:].abs().sum() == 0
+    assert torch.equal(sd["gnn.convs.0.lin_r.weight"][:8], old["gnn.convs.0.lin_r.weight"])
+    assert torch.equal(sd["gnn.convs.2.lin_l.bias"][:8], old["gnn.convs.2.lin_l.bias"])
+    assert sd["maker_head.linear.weight"].shape == (1, 12)
+    assert torch.equal(sd["maker_head.linear.weight"][:, :8], old["maker_head.linear.weight"])
+    assert sd["maker_head.linear.weight"][:, 8:].abs().sum() == 0
+    assert sd["maker_head.value_head.layers.0.weight"].shape == (6, 48)
+    assert torch.equal(sd["maker_head.value_head.layers.0.weight"][:4, :32], old["maker_head.value_head.layers.0.weight"])
+    assert sd["maker_head.gnn.convs.0.lin_l.weight"].shape == (12, 12)
+    assert m.gnn.hidden_channels == 12 and m.maker_head.hidden_channels == 12
+
+
+def test_data_and_batch_stand_ins():
+    from gnn_hex_amd.data import Batch, Data
+    d1 = Data(x=torch.zeros(3, 3), edge_index=torch.tensor([[0, 1], [1, 0]]), backmap=torch.tensor([0, 1, 5]))
+    d2 = Data(x=torch.ones(2, 3), edge_index=torch.tensor([[0], [1]]), backmap=torch.tensor([0, 1]))
+    b = Batch.from_data_list([d1, d2])
+    assert b.num_graphs == 2
+    assert torch.equal(b.ptr, torch.tensor([0, 3, 5]))
+    assert torch.equal(b.batch, torch.tensor([0, 0, 0, 1, 1]))
+    assert torch.equal(b.edge_index, torch.tensor([[0, 1, 3], [1, 0, 4]]))
+    assert torch.equal(b.backmap, torch.tensor([0, 1, 5, 0, 1]))      # concatenated un-offset
+    d1.__delattr__("backmap")                                          # Env_manager.get_transitions does this
+    assert not hasattr(d1, "backmap")
+    assert d1.to("cpu") is d1 and d1.num_nodes == 3 and d1.num_edges == 2

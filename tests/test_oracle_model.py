@@ -1,0 +1,123 @@
+"""CPU: pins the model oracle (oracle/model_ref.py) with hand-derived known-answer tests and the structural
+identities of the dueling head.  The oracle is PARITY-UNPINNED against the real
+torch_geometric path (absent from the image); these tests are what pins it instead."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import batch_tensors, model_args
+from oracle.model_ref import (SAGEConvRef, get_pre_defined_ref, scatter_ref)
+
+
+def test_scatter_ref_kat():
+    src = torch.tensor([[1., 5.], [3., 5.], [2., -1.], [7., 0.]])
+    idx = torch.tensor([0, 0, 2, 2])
+    assert torch.equal(scatter_ref(src, idx, reduce="sum"), torch.tensor([[4., 10.], [0., 0.], [9., -1.]]))
+    assert torch.equal(scatter_ref(src, idx, reduce="mean"), torch.tensor([[2., 5.], [0., 0.], [4.5, -0.5]]))
+    assert torch.equal(scatter_ref(src, idx, reduce="max"), torch.tensor([[3., 5.], [0., 0.], [7., 0.]]))
+    assert torch.equal(scatter_ref(src, idx, reduce="min"), torch.tensor([[1., 5.], [0., 0.], [2., -1.]]))
+
+
+def test_scatter_max_gradient_goes_to_first_index_on_ties():
+    src = torch.tensor([[2.], [2.], [1.], [2.]], requires_grad=True)
+    idx = torch.tensor([0, 0, 0, 0])
+    scatter_ref(src, idx, reduce="max").sum().backward()
+    assert torch.equal(src.grad, torch.tensor([[1.], [0.], [0.], [0.]]))
+    src.grad = None
+    scatter_ref(src, idx, reduce="min").sum().backward()
+    assert torch.equal(src.grad, torch.tensor([[0.], [0.], [1.], [0.]]))
+
+
+def test_sageconv_kat_constant_weights_and_isolated_node():
+    # path 0-1-2 plus isolated node 3; all weights = c, bias = b  =>  y_i = c*sum(mean_nbrs) + b + c*sum(x_i)
+    conv = SAGEConvRef(2, 3)
+    c, b = 0.5, 0.25
+    with torch.no_grad():
+        conv.lin_l.weight.fill_(c); conv.lin_l.bias.fill_(b); conv.lin_r.weight.fill_(c)
+    x = torch.tensor([[1., 2.], [3., 4.], [5., 6.], [7., 8.]])
+    ei = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])
+    y = conv(x, ei)
+    mean = torch.tensor([[3., 4.], [3., 4.], [3., 4.], [0., 0.]])      # node 1: mean of nodes 0,2; node 3: isolated -> 0
+    expect = (c * mean.sum(1) + b + c * x.sum(1)).view(-1, 1).expand(4, 3)
+    assert torch.allclose(y, expect, atol=1e-6)
+
+
+def test_hand_computed_tiny_network():
+    """1 body layer + 1 head layer, hidden 2, a 3-node path graph: every number worked by hand in float64."""
+    args = model_args(1, 2, head_layers=1)
+    m = get_pre_defined_ref("modern_two_headed", args).double()
+    with torch.no_grad():
+        for p in m.parameters():
+            p.fill_(0.1)
+    x = torch.tensor([[1., 1., 1.], [2., 0., 1.], [1., 0., 1.]], dtype=torch.float64)
+    ei = torch.tensor([[0, 1, 1, 2], [1, 0, 2, 1]])
+    q = m(x, ei)
+    w = 0.1
+    X = x[:, :2].numpy()
+    nb = {0: [1], 1: [0, 2], 2: [1]}
+
+    def sage(F):
+        out = np.zeros((3, 2))
+        for i in range(3):
+            mean = np.mean([F[j] for j in nb[i]], axis=0)
+            out[i, :] = w * mean.sum() + w + w * F[i].sum()
+        return np.maximum(out, 0)
+
+    h = sage(sage(X))                      # body layer, then the (maker) head's gnn layer
+    adv = 2 * np.tanh(h.sum(1) * w + w)
+    pooled = np.concatenate([h.sum(0), h.max(0), h.min(0), h.mean(0)])
+    z = max(pooled.sum() * w + w, 0.0)     # value MLP: Linear(8,1) -> relu -> Linear(1,1)
+    v = math.tanh(z * w + w)
+    expect = v + adv - adv.mean()
+    assert np.allclose(q.detach().numpy(), expect, atol=1e-12)
+
+
+@pytest.mark.parametrize("maker", [True, False])
+def test_dueling_identities(maker):
+    torch.manual_seed(0)
+    m = get_pre_defined_ref("modern_two_headed", model_args(4, 12))
+    x, ei, batch, ptr = batch_tensors("D1", [5, 6, 7], maker=maker)
+    q = m(x, ei, batch, ptr)
+    v, a = m(x, ei, batch, ptr, seperate=True)
+    ao = m(x, ei, batch, ptr, advantages_only=True)
+    assert q.shape == (x.shape[0],) and ao.shape == (x.shape[0], 1) and v.shape == (3,)
+    assert q.abs().max() < 5
+    for g in range(3):
+        sl = slice(int(ptr[g]), int(ptr[g + 1]))
+        assert abs(q[sl].mean().item() - v[g].item()) < 1e-6          # mean_g(Q) == tanh(value_g)
+        assert abs(a[sl].mean().item()) < 1e-6
+        assert torch.allclose(ao[sl, 0] - ao[sl, 0].mean(), a[sl], atol=1e-6)
+    # the head is chosen by the side-to-move flag: the other head's parameters get no gradient
+    q.sum().backward()
+    used, unused = ("maker_head", "breaker_head") if maker else ("breaker_head", "maker_head")
+    for k, p in m.named_parameters():
+        if k.startswith(unused):
+            assert p.grad is None
+        elif k.startswith(used) or k.startswith("gnn"):
+            assert p.grad is not None
+
+
+def test_mixed_side_batch_is_rejected():
+    m = get_pre_defined_ref("modern_two_headed", model_args(2, 4))
+    x, ei, batch, ptr = batch_tensors("D0", [5, 5])
+    x[3, 2] = 0.0
+    with pytest.raises(AssertionError):
+        m(x, ei, batch, ptr)
+
+
+def test_parameter_counts_and_state_dict_keys():
+    # GNN-S 37 382 parameters, GNN-L 486 974; key names of section 5 "Checkpoint"
+    s = get_pre_defined_ref("modern_two_headed", model_args(10, 35))
+    l = get_pre_defined_ref("modern_two_headed", model_args(15, 110))
+    assert sum(p.numel() for p in s.parameters()) == 37382
+    assert sum(p.numel() for p in l.parameters()) == 486974
+    keys = set(s.state_dict().keys())
+    for k in ("gnn.convs.0.lin_l.weight", "gnn.convs.9.lin_l.bias", "gnn.convs.3.lin_r.weight",
+              "maker_head.gnn.convs.1.lin_l.weight", "breaker_head.linear.bias",
+              "maker_head.value_head.layers.0.weight", "breaker_head.value_head.layers.1.bias"):
+        assert k in keys
+    assert "gnn.convs.0.lin_r.bias" not in keys
+    assert s.state_dict()["gnn.convs.0.lin_l.weight"].shape == (35, 2)
+    assert s.state_dict()["maker_head.value_head.layers.0.weight"].shape == (17, 140)
