@@ -46,6 +46,15 @@ _SIGS = {
     "hexgnn_qnet_backward_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_backward": (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
+    "hexgnn_env_create": (ci, [ci, ci, vp]),
+    "hexgnn_env_destroy": (None, [vp]),
+    "hexgnn_env_num_vertices": (ci, [vp]),
+    "hexgnn_env_words": (ci, [vp]),
+    "hexgnn_env_reset": (ci, [vp, vp, ci, vp, vp]),
+    "hexgnn_env_set_maker_turn": (ci, [vp, ci, vp]),
+    "hexgnn_env_step": (ci, [vp, vp, ci, ci, ci, vp, vp]),
+    "hexgnn_env_observe": (ci, [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_env_export": (ci, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_profile_enable": (ci, [ci]),
     "hexgnn_profile_read": (ci, [vp, vp]),
     "hexgnn_pad_rows": (ci, [ci, ci, vp, ci, vp, vp]),

@@ -63,6 +63,8 @@ class Batch(Data):
 
     @classmethod
     def from_data_list(cls, data_list: List[Data]) -> "Batch":
+        if hasattr(data_list, "to_batch"):      # an Env_manager observation is already batched on the device
+            return data_list.to_batch()
         out = cls()
         if len(data_list) == 0:
             raise ValueError("empty data_list")
@@ -85,6 +87,11 @@ class Batch(Data):
             else:
                 out.__dict__[k] = vals
         out._num_graphs = len(sizes)
+        # host-known batch metadata spares the model two device->host syncs (side to move, largest graph)
+        sides = {getattr(d.x, "_hex_is_maker", None) for d in data_list}
+        if len(sides) == 1 and None not in sides:
+            out.x._hex_is_maker = sides.pop()
+        out.x._hex_max_nodes = max(sizes)
         return out
 
     @property

@@ -318,7 +318,9 @@ class DuellingTwoHeaded(torch.nn.Module):
         n = x.shape[0]
         x2 = x[:, :2]
 
-        gs = ops.GraphStructure(edge_index, n)           # edge_index CSR-sorted once per batch
+        gs = getattr(edge_index, "_hex_csr", None)          # CSR emitted by the env builder, if any
+        if gs is None or gs.n != n:
+            gs = ops.GraphStructure(edge_index, n)       # edge_index CSR-sorted once per batch
         gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
         head = self.maker_head if is_maker else self.breaker_head
         mode = 2 if advantages_only else (1 if seperate else 0)

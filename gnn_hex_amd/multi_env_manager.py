@@ -1,0 +1,320 @@
+"""Drop-in mirror of ``graph_game.multi_env_manager.Env_manager`` (graph_game/multi_env_manager.py:16-165) on the
+HIP board-graph builder (gnn_hex_amd/csrc/env.hip, C ABI ``hexgnn_env_*``).
+
+Same constructor, attributes and methods; ``step`` returns ``(states, rewards, dones, infos)`` with the reference's
+reward / reset / side-to-move conventions.  ``states`` is an ``ObsList``: it behaves as the reference's
+``List[Data]`` (len / index / iterate -> ``Data(x, edge_index, backmap)`` views) but is backed by ONE batched device
+observation, so ``Batch.from_data_list(states)`` costs nothing and carries the sorted CSR the model kernels consume.
+All game logic runs on the GPU; there is no python/CPU game fallback.  ``cnn_rep=True`` (CNN input planes) is outside
+the hot path and raises NotImplementedError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from typing import List, Tuple, Union
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .data import Batch, Data
+
+
+class ObsList:
+    """List[Data]-compatible view of one batched observation of all envs."""
+
+    def __init__(self, x, edge_local, edge_global, backmap, batch_vec, node_off, edge_off, gs, is_maker, max_nodes):
+        self.x, self.edge_local, self.edge_global, self.backmap = x, edge_local, edge_global, backmap
+        self.batch_vec = batch_vec
+        self.node_off, self.edge_off = node_off, edge_off     # host lists, len num_envs+1
+        self.gs, self.is_maker, self.max_nodes = gs, is_maker, max_nodes
+        self._ptr = None
+        self._items = {}
+
+    def __len__(self):
+        return len(self.node_off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[j] for j in range(*i.indices(len(self)))]
+        if i < 0:
+            i += len(self)
+        d = self._items.get(i)
+        if d is None:
+            n0, n1 = self.node_off[i], self.node_off[i + 1]
+            e0, e1 = self.edge_off[i], self.edge_off[i + 1]
+            d = Data(x=self.x[n0:n1], edge_index=self.edge_local[:, e0:e1], backmap=self.backmap[n0:n1])
+            d.x._hex_is_maker = self.is_maker
+            d.x._hex_max_nodes = n1 - n0
+            self._items[i] = d
+        return d
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    def to_batch(self) -> Batch:
+        """The whole observation as a ``Batch`` (what ``Batch.from_data_list(list(states))`` would build)."""
+        b = Batch()
+        if self._ptr is None:
+            self._ptr = torch.tensor(self.node_off, dtype=torch.long, device=self.x.device)
+        b.x, b.edge_index, b.batch, b.ptr, b.backmap = self.x, self.edge_global, self.batch_vec, self._ptr, self.backmap
+        b._num_graphs = len(self)
+        b.x._hex_is_maker = self.is_maker
+        b.x._hex_max_nodes = self.max_nodes
+        b.edge_index._hex_csr = self.gs
+        return b
+
+
+class _EnvView:
+    """Read-only stand-in for the per-env ``Hex_game`` objects of the reference's ``Env_manager.envs``."""
+
+    def __init__(self, mgr, idx):
+        self._m, self._i = mgr, idx
+
+    @property
+    def onturn(self):
+        return self._m.global_onturn
+
+    @property
+    def not_onturn(self):
+        return "b" if self._m.global_onturn == "m" else "m"
+
+    @property
+    def total_num_moves(self):
+        return int(self._m._state()["total_moves"][self._i])
+
+    @property
+    def creation_time(self):
+        return self._m._creation_time[self._i]
+
+    def get_actions(self):
+        return self._m.get_valid_actions()[self._i]
+
+
+class Env_manager:
+    last_obs: ObsList
+
+    def __init__(self, num_envs, hex_size, gamma=1, n_steps=[1], prune_exploratories=True, cnn_rep=False,
+                 cnn_hex_size=5, gao_mode=False, border_fill=True, device=None):
+        if cnn_rep:
+            raise NotImplementedError("cnn_rep=True (CNN planes) is outside the accelerated hot path")
+        self.num_envs = num_envs
+        self.gamma = gamma
+        self.global_onturn = "m"
+        self.n_steps = n_steps
+        self.prune_exploratories = prune_exploratories
+        self.cnn_rep = cnn_rep
+        self.gao_mode = gao_mode
+        self.border_fill = border_fill
+        self.cnn_hex_size = cnn_hex_size
+        self.device = torch.device(device if device is not None else "cuda")
+        if self.device.type != "cuda":
+            raise _lib.HexGnnError("Env_manager runs only on the MI355X HIP path (no CPU fallback)")
+        self._h = None
+        self._base = None
+        self.change_hex_size(hex_size)
+
+    # ---- handles ---------------------------------------------------------------------------------------
+    def _destroy(self):
+        L = _lib.lib()
+        for name in ("_h", "_base"):
+            h = getattr(self, name, None)
+            if h:
+                L.hexgnn_env_destroy(h)
+                setattr(self, name, None)
+
+    def __del__(self):
+        try:
+            self._destroy()
+        except Exception:
+            pass
+
+    def change_hex_size(self, new_size):
+        L = _lib.lib()
+        self._destroy()
+        self.hex_size = new_size
+        self.global_onturn = "m"
+        with torch.cuda.device(self.device):
+            h, hb = C.c_void_p(), C.c_void_p()
+            _lib.check(L.hexgnn_env_create(self.num_envs, new_size, C.byref(h)), "hexgnn_env_create")
+            _lib.check(L.hexgnn_env_create(1, new_size, C.byref(hb)), "hexgnn_env_create")
+        self._h, self._base = h, hb
+        self._nv = L.hexgnn_env_num_vertices(h)
+        self._words = L.hexgnn_env_words(h)
+        nv, n = self._nv, new_size
+        e_start = 2 * (2 * n + (n - 2) * (n - 1) + n * (n - 1) + (n - 1) ** 2)
+        self._sizes = np.tile(np.array([[nv, e_start]], dtype=np.int64), (self.num_envs, 1))
+        self._base_sizes = np.array([[nv, e_start]], dtype=np.int64)
+        self._creation_time = [time.perf_counter()] * self.num_envs
+        self.envs = [_EnvView(self, i) for i in range(self.num_envs)]
+        self.base_game = None
+        self.last_obs = None
+
+    # ---- observation -----------------------------------------------------------------------------------
+    def _observe_handle(self, h, sizes, is_maker) -> ObsList:
+        L = _lib.lib()
+        dev = self.device
+        k = sizes.shape[0]
+        node_off = np.zeros(k + 1, dtype=np.int64)
+        edge_off = np.zeros(k + 1, dtype=np.int64)
+        np.cumsum(sizes[:, 0], out=node_off[1:])
+        np.cumsum(sizes[:, 1], out=edge_off[1:])
+        N, E = int(node_off[-1]), int(edge_off[-1])
+        offs = torch.from_numpy(np.concatenate([node_off, edge_off]).astype(np.int32)).to(dev, non_blocking=True)
+        x = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        backmap = torch.empty(N, dtype=torch.long, device=dev)
+        batch_vec = torch.empty(N, dtype=torch.long, device=dev)
+        edge_local = torch.empty((2, max(E, 1)), dtype=torch.long, device=dev)[:, :E]
+        edge_global = torch.empty((2, max(E, 1)), dtype=torch.long, device=dev)[:, :E]
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        invdeg = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        if E == 0:
+            edge_local = torch.empty((2, 0), dtype=torch.long, device=dev)
+            edge_global = torch.empty((2, 0), dtype=torch.long, device=dev)
+        el_base = edge_local.data_ptr() if E > 0 else x.data_ptr()
+        eg_base = edge_global.data_ptr() if E > 0 else x.data_ptr()
+        _lib.check(L.hexgnn_env_observe(h, offs.data_ptr(), offs[k + 1:].data_ptr(), E, x.data_ptr(), backmap.data_ptr(),
+                                        el_base, eg_base, rowptr.data_ptr(), col.data_ptr(), invdeg.data_ptr(),
+                                        batch_vec.data_ptr(), ops._stream()), "hexgnn_env_observe")
+        gs = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
+        return ObsList(x, edge_local, edge_global, backmap, batch_vec, node_off.tolist(), edge_off.tolist(), gs,
+                       is_maker, int(sizes[:, 0].max()) if k else 0)
+
+    @property
+    def starting_obs(self) -> Data:
+        """Fresh ``Data`` of the start position with maker to move (multi_env_manager.py:41-49)."""
+        obs = self._observe_handle(self._base, self._base_sizes, True)
+        d = obs[0]
+        return Data(x=d.x.clone(), edge_index=d.edge_index.clone(), backmap=d.backmap.clone())
+
+    def observe(self) -> ObsList:
+        self.last_obs = self._observe_handle(self._h, self._sizes, self.global_onturn == "m")
+        return self.last_obs
+
+    # ---- actions ---------------------------------------------------------------------------------------
+    @staticmethod
+    def validate_actions(states, actions: List[int]):
+        """Node rank -> vertex id through each state's backmap (multi_env_manager.py:62-64)."""
+        if isinstance(states, ObsList):
+            idx = torch.as_tensor([int(a) for a in actions], dtype=torch.long, device=states.x.device)
+            base = torch.as_tensor(states.node_off[:-1], dtype=torch.long, device=states.x.device)
+            return states.backmap[base + idx].tolist()
+        return [state.backmap[action].item() for state, action in zip(states, actions)]
+
+    def get_valid_actions(self) -> List[np.ndarray]:
+        obs = self.last_obs if self.last_obs is not None else self.observe()
+        bm = obs.backmap.cpu().numpy()
+        return [bm[obs.node_off[i] + 2:obs.node_off[i + 1]] for i in range(self.num_envs)]
+
+    def sample(self) -> np.ndarray:
+        return np.array([np.random.choice(x) for x in self.get_valid_actions()])
+
+    # ---- stepping --------------------------------------------------------------------------------------
+    def step(self, actions) -> Tuple[ObsList, np.ndarray, np.ndarray, List[dict]]:
+        L = _lib.lib()
+        if torch.is_tensor(actions):
+            act = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        else:
+            act = torch.as_tensor(np.asarray([int(a) for a in actions], dtype=np.int32)).to(self.device)
+        if act.numel() != self.num_envs:
+            raise ValueError("expected %d actions" % self.num_envs)
+        result = torch.empty((self.num_envs, 5), dtype=torch.int32, device=self.device)
+        reset_maker = self.global_onturn == "b"      # finished envs restart on the side everyone moves to next
+        _lib.check(L.hexgnn_env_step(self._h, act.data_ptr(), 1, 1, int(reset_maker), result.data_ptr(), ops._stream()),
+                   "hexgnn_env_step")
+        res = result.cpu().numpy()
+        if res[:, 4].any():
+            bad = int(np.nonzero(res[:, 4])[0][0])
+            raise ValueError("illegal action %d for env %d" % (int(act[bad]), bad))
+        now = time.perf_counter()
+        rewards = np.zeros(self.num_envs, dtype=float)
+        dones = res[:, 0] >= 0
+        infos = [{} for _ in range(self.num_envs)]
+        mover = self.global_onturn
+        for i in np.nonzero(dones)[0]:
+            winner = "m" if res[i, 0] == 0 else "b"
+            n = int(res[i, 1])
+            infos[i]["episode_metrics"] = {
+                "return": 1 if winner == "m" else -1,
+                "discounted_return": float(1 * self.gamma ** n if winner == "m" else -1 * self.gamma ** n),
+                "length": n,
+                "time": now - self._creation_time[i],
+            }
+            rewards[i] = 1 if winner == mover else -1       # winner == env.not_onturn after the move
+            self._creation_time[i] = now
+        self.global_onturn = "m" if self.global_onturn == "b" else "b"
+        self._sizes = res[:, 2:4].astype(np.int64)
+        states = self.observe()
+        return states, rewards, dones.astype(bool), infos
+
+    def reset(self) -> ObsList:
+        L = _lib.lib()
+        self.global_onturn = "m"
+        _lib.check(L.hexgnn_env_reset(self._h, None, 1, None, ops._stream()), "hexgnn_env_reset")
+        self._sizes = np.tile(self._base_sizes, (self.num_envs, 1))
+        self._creation_time = [time.perf_counter()] * self.num_envs
+        return self.observe()
+
+    # ---- raw state (tests, debugging) ------------------------------------------------------------------
+    def _state(self):
+        L = _lib.lib()
+        dev = self.device
+        adj = torch.empty((self.num_envs, self._nv, self._words), dtype=torch.int64, device=dev)
+        alive = torch.empty((self.num_envs, self._nv), dtype=torch.uint8, device=dev)
+        mt = torch.empty(self.num_envs, dtype=torch.int32, device=dev)
+        tm = torch.empty(self.num_envs, dtype=torch.int32, device=dev)
+        rm = torch.empty((self.num_envs, self._nv), dtype=torch.int16, device=dev)
+        rb = torch.empty((self.num_envs, self._nv), dtype=torch.int16, device=dev)
+        _lib.check(L.hexgnn_env_export(self._h, adj.data_ptr(), alive.data_ptr(), mt.data_ptr(), tm.data_ptr(),
+                                       rm.data_ptr(), rb.data_ptr(), ops._stream()), "hexgnn_env_export")
+        return dict(adj=adj.cpu().numpy().view(np.uint64), alive=alive.cpu().numpy(), maker_turn=mt.cpu().numpy(),
+                    total_moves=tm.cpu().numpy(), resp_maker=rm.cpu().numpy(), resp_breaker=rb.cpu().numpy())
+
+    # ---- transition assembly (host logic, multi_env_manager.py:113-165) ----------------------------------
+    def get_transitions(self, starting_states, state_history: list, action_history: list, reward_history: list,
+                        done_history: list, exploratories_history: list):
+        """n-step, sign-alternating, gamma-discounted two-player transitions ``(s, a, r, s', done)`` split into
+        (maker_transitions, breaker_transitions); exploratory actions after the first step prune a transition."""
+        maker_transitions, breaker_transitions = [], []
+        sh = list(state_history)
+        sh.insert(0, starting_states)
+        side_cache = {}
+
+        def side_of(states):
+            k = id(states)
+            if k not in side_cache:
+                side_cache[k] = states.is_maker if isinstance(states, ObsList) else bool(states[0].x[0, 2] == 1)
+            return side_cache[k]
+
+        for i in range(len(action_history)):
+            start_state = sh[i]
+            action = action_history[i]
+            maker_side = side_of(start_state)
+            transits = maker_transitions if maker_side else breaker_transitions
+            for n_step in self.n_steps:
+                if len(sh) > i + 2 * n_step:
+                    for k in range(len(start_state)):
+                        s_k = start_state[k]
+                        if hasattr(s_k, "backmap"):
+                            s_k.__delattr__("backmap")
+                        assert action[k] < len(s_k.x)
+                        reward = 0
+                        for j in range(i, i + 2 * n_step):
+                            reward += reward_history[j][k] * ((-((j - i) % 2)) * 2 + 1) * (self.gamma ** ((j - i) // 2))
+                            if done_history[j][k]:
+                                sobs = self.starting_obs
+                                sobs.__delattr__("backmap")
+                                sobs.x[:, 2] = 1.0 if maker_side else 0.0
+                                sobs.x._hex_is_maker = maker_side
+                                transits.append((s_k, action[k], reward, sobs, True))
+                                break
+                            if self.prune_exploratories and j > i and exploratories_history[j][k]:
+                                break
+                        else:
+                            nxt = sh[i + 2 * n_step][k]
+                            if hasattr(nxt, "backmap"):
+                                nxt.__delattr__("backmap")
+                            transits.append((s_k, action[k], reward, nxt, False))
+        return maker_transitions, breaker_transitions

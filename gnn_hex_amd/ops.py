@@ -76,6 +76,18 @@ class GraphStructure:
                                       self.invdeg.data_ptr(), self.status.data_ptr(), ws.data_ptr(), ws_bytes,
                                       _stream()), "hexgnn_csr_build")
 
+    @classmethod
+    def from_csr(cls, n: int, e: int, rowptr, col, invdeg, rowptr_t=None, col_t=None) -> "GraphStructure":
+        """Adopt an existing sorted CSR (the env builder emits one).  Without a transpose the graph is taken to be
+        symmetric (board graphs are), i.e. its own transpose."""
+        self = cls.__new__(cls)
+        self.n, self.e = int(n), int(e)
+        self.rowptr, self.col, self.invdeg = rowptr, col, invdeg
+        self.rowptr_t = rowptr if rowptr_t is None else rowptr_t
+        self.col_t = col if col_t is None else col_t
+        self.status = torch.zeros(1, dtype=torch.int32, device=rowptr.device)
+        return self
+
     def check(self) -> None:
         """Host-synchronising validity check (debug aid; not called on the hot path)."""
         if int(self.status.item()) != 0:

@@ -148,6 +148,46 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
                          float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
                          void* workspace, size_t workspace_bytes, int* status, hexgnn_stream_t stream);
 
+/* ---- batched board-graph builder: num_envs lock-stepped Hex / Shannon node-switching games on the device.
+ *      Replaces Hex_game / Node_switching_game (graph_game/graph_tools_games.py:20-29,
+ *      graph_game/shannon_node_switching_game.py:80-205, graph_game/hex_board_game.py:214-233) as driven by
+ *      Env_manager (graph_game/multi_env_manager.py:31-111), and convert_node_switching_game(old_style=True)
+ *      (GN0/util/convert_graph.py:60-130) + Batch.from_data_list for the observation.  Vertex ids: 0,1 terminals,
+ *      i+2 = board cell i.  Iteration order inside dead_and_captured is the canonical ascending order of
+ *      oracle/env_ref.c (the reference's own two implementations disagree on it).
+ *      create/destroy allocate (not stream-ordered); everything else is stream-ordered and non-allocating. ------ */
+typedef struct hexgnn_env hexgnn_env;
+int hexgnn_env_create(int num_envs, int hex_size, hexgnn_env** out);   /* hex_size <= 25; all envs at the start position, maker to move */
+void hexgnn_env_destroy(hexgnn_env* env);
+int hexgnn_env_num_vertices(const hexgnn_env* env);                    /* hex_size^2 + 2 */
+int hexgnn_env_words(const hexgnn_env* env);                           /* 64-bit words per adjacency row */
+/* Hex_game(size) for the envs with mask[i] != 0 (all when mask == NULL), gp["m"] = maker_turn.
+ * sizes (optional, [num_envs][2]): (nodes, directed edges) of the reset envs. */
+int hexgnn_env_reset(hexgnn_env* env, const uint8_t* mask, int maker_turn, int* sizes, hexgnn_stream_t stream);
+int hexgnn_env_set_maker_turn(hexgnn_env* env, int maker_turn, hexgnn_stream_t stream);
+/* make_move(actions[i], remove_dead_and_captured) + who_won for every env (Env_manager.step, multi_env_manager.py:76-103).
+ * actions: vertex ids (int32).  result [num_envs][5] = (winner: -1 none / 0 maker / 1 breaker, total_num_moves at that
+ * point, nodes, directed edges, error: 1 = illegal action, env untouched).  With auto_reset a finished env is replaced by a
+ * fresh start position whose side to move is reset_maker_turn; nodes/edges then describe the fresh graph.  Once a game
+ * is decided only winner and move count are defined: the residual graph of a finished game is unspecified (the maker's
+ * winning move short-cuts the bookkeeping nobody reads). */
+int hexgnn_env_step(hexgnn_env* env, const int* actions, int remove_dead_and_captured, int auto_reset,
+                    int reset_maker_turn, int* result, hexgnn_stream_t stream);
+/* Batched observation.  node_off/edge_off: [num_envs+1] exclusive prefix sums of the per-env (nodes, directed edges)
+ * reported by step/reset; e_total = edge_off[num_envs].
+ *   x [N][3] f32 = (degree, is_terminal, maker_to_move)           backmap [N] i64: rank -> vertex id
+ *   edge_local  [2][e_total] i64: per graph the E_g/2 edges (s > t, sorted) then their flipped copies, LOCAL ranks
+ *   edge_global [2][e_total] i64: the same with the graph's node offset added (== Batch.edge_index)
+ *   rowptr [N+1] / col [e_total] i32 + invdeg [N] f32: the sorted CSR hexgnn_csr_build would produce (symmetric
+ *   graph: it is its own transpose)                                 batch_vec [N] i64: graph id of every node */
+int hexgnn_env_observe(hexgnn_env* env, const int* node_off, const int* edge_off, int64_t e_total, float* x,
+                       int64_t* backmap, int64_t* edge_local, int64_t* edge_global, int* rowptr, int* col,
+                       float* invdeg, int64_t* batch_vec, hexgnn_stream_t stream);
+/* Raw state dump (tests): adj [num_envs][nv][words] u64, alive [num_envs][nv] u8, maker_turn / total_moves [num_envs],
+ * response sets [num_envs][nv] i16 (-1 = none; may be NULL). */
+int hexgnn_env_export(hexgnn_env* env, uint64_t* adj, uint8_t* alive, int* maker_turn, int* total_moves,
+                      int16_t* resp_maker, int16_t* resp_breaker, hexgnn_stream_t stream);
+
 /* ---- in-library kernel timing: HIP events recorded on the launch stream around every launch of ONE
  *      kernel class (bench.py's live roofline measurement; torch.cuda.Event would only see torch's current
  *      stream and whole calls).  Not for use under graph capture. --------------------------------------- */
