@@ -33,7 +33,7 @@ struct QFwdArgs {
 };
 
 struct QBwdArgs {
-    int n, b, H, L, mode, body_layers;
+    int n, b, H, L, mode, body_layers, dbg;
     const int* gptr; const int* rowptr_t; const int* col_t; const float* invdeg;
     const char* wpack; size_t bwd_off[kMaxL];
     const float* acts;
@@ -92,6 +92,14 @@ __device__ __forceinline__ bool load_csr(char* lds, const int* __restrict__ rowp
 
 
 
+
+// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) but NOT for its global
+// stores/loads (vmcnt).  __syncthreads() would drain vmcnt(0) first, exposing the latency of the saved-tensor stores
+// (acts / agg / G are consumed by LATER kernels, never through this barrier) every layer.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // global -> LDS copy of `count` float4 with all loads of a thread issued before its first LDS write
 template <int kMaxPer>
 __device__ __forceinline__ void copy_f4_to_lds(f32x4* __restrict__ dst, const f32x4* __restrict__ src, int count) {
@@ -123,17 +131,31 @@ template <int NT, int XS>
 __device__ __forceinline__ void gather_lds(const float* __restrict__ rows, const unsigned char* __restrict__ s_col,
                                            int eb, int ee, int g, f32x4 (&ag)[NT]) {
     int e = eb;
-    int jn = e < ee ? (int)s_col[e] : 0;
-    while (e < ee) {
-        const f32x4* xj = reinterpret_cast<const f32x4*>(rows + jn * XS) + g;
-        ++e;
-        jn = e < ee ? (int)s_col[e] : 0;
-        f32x4 tmp[NT];
+    // two neighbours per iteration: 2*NT reads of 16 B in flight per lane before the first add
+    while (e + 1 < ee) {
+        const int j0 = (int)s_col[e], j1 = (int)s_col[e + 1];
+        e += 2;
+        const f32x4* x0 = reinterpret_cast<const f32x4*>(rows + j0 * XS) + g;
+        const f32x4* x1 = reinterpret_cast<const f32x4*>(rows + j1 * XS) + g;
+        f32x4 t0[NT], t1[NT];
 #pragma unroll
-        for (int c = 0; c < NT; ++c) tmp[c] = xj[4 * c];
+        for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) ag[c] += tmp[c];
+        for (int c = 0; c < NT; ++c) ag[c] += t0[c];      // ascending neighbour order kept: (.. + x_j0) + x_j1
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] += t1[c];
+    }
+    if (e < ee) {
+        const f32x4* x0 = reinterpret_cast<const f32x4*>(rows + (int)s_col[e] * XS) + g;
+        f32x4 t0[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] += t0[c];
     }
 }
 
@@ -256,9 +278,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
         }
+        // the bias is the accumulator's initial value (loaded now, consumed by the first MFMA of each tile)
         f32x4 acc[NT];
+        {
+            const f32x4* br = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]) + g;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int t = 0; t < NT; ++t) acc[t] = br[4 * t];
+        }
         if (wactive) {
             // phase 1: mean-gather from LDS, then K-half over W_l (half A)
             f32x4 ag[NT];
@@ -280,7 +306,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 if (a.need_backward && !(a.dbg & 2)) {
                     f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
+                    for (int c = 0; c < NT; ++c) { if (a.dbg & 32) ao[4 * c] = ag[c]; else __builtin_nontemporal_store(ag[c], &ao[4 * c]); }
                 }
             }
             if (!(a.dbg & 8))
@@ -291,7 +317,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
         }
-        __syncthreads();   // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
+        lds_barrier();     // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
         if (l + 1 < a.L && !(a.dbg & 4)) {   // stream W_l(l+1) towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
 #pragma unroll
@@ -302,11 +328,10 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, xs[c], acc);
-            const f32x4* br = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]) + g;
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                f32x4 v = acc[t] + br[4 * t];
+                f32x4 v = acc[t];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) v[q4] = (rvalid && v[q4] > 0.f) ? v[q4] : 0.f;
                 xs[t] = v;
@@ -315,14 +340,14 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             if (rvalid && !(a.dbg & 2)) {
                 f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
+                for (int t = 0; t < NT; ++t) { if (a.dbg & 32) yo[4 * t] = xs[t]; else __builtin_nontemporal_store(xs[t], &yo[4 * t]); }
             }
         }
         if (l + 1 < a.L && !(a.dbg & 4)) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
         }
-        __syncthreads();   // barrier 2: new rows + half A visible; half B free
+        lds_barrier();     // barrier 2: new rows + half A visible; half B free
     }
 
     // ---- head tail (scratch aliases the weight halves, free after the last barrier) ----
@@ -607,6 +632,15 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     __syncthreads();   // scratch consumed; dbuf may be overwritten from here on
 
     // ---- layer chain ----
+    // y rows of the layer about to be masked are fetched one layer ahead (global latency off the critical path)
+    f32x4 ycur[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) ycur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (rvalid && L > 1) {
+        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ycur[t] = yr[4 * t];
+    }
     for (int l = L - 1; l >= 1; --l) {
         if (a.d_embeds && l == a.body_layers - 1 && rvalid) {
             f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
@@ -614,7 +648,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
         }
         f32x4 stg[kStage];
-        const bool more = l - 1 >= 1;
+        const bool more = l - 1 >= 1 && !(a.dbg & 4);
         if (more) {   // stream [W_l part] of layer l-1 towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
 #pragma unroll
@@ -629,21 +663,24 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         if (wactive) {
             // mask by this layer's ReLU, publish G_l
             if (rvalid) {
-                const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
                 f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
+                const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const f32x4 yv = yr[4 * t];
+                    const f32x4 yv = ycur[t];
+                    ycur[t] = yn[4 * t];          // layer l-1's rows for the next iteration (layer 0's for the epilogue)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
-                    go[4 * t] = gx[t];
+                    if (a.dbg & 16) reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)(r0 + wave * 16) * HP)[t * 64 + lane] = gx[t];   // timing probe: dense 1 KB stores
+                    else if (!(a.dbg & 2)) { if (a.dbg & 32) go[4 * t] = gx[t]; else __builtin_nontemporal_store(gx[t], &go[4 * t]); }
                 }
             }
             // phase 1: dAggS = (G W_l) / deg     (half A)
+            if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, gx[c], acc);
         }
-        __syncthreads();   // barrier A: gathers of the previous layer are done (dbuf free); half A free
+        lds_barrier();     // barrier A: gathers of the previous layer are done (dbuf free); half A free
         if (more) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
@@ -665,10 +702,11 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         }
         if (wactive) {
             // phase 2: dXs = G W_r     (half B)
+            if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, gx[c], dxs);
         }
-        __syncthreads();   // barrier B: dAggS rows + half A visible; half B free
+        lds_barrier();     // barrier B: dAggS rows + half A visible; half B free
         if (more) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
@@ -676,7 +714,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         // gradient w.r.t. this layer's input = dXs + transposed gather of dAggS
 #pragma unroll
         for (int t = 0; t < NT; ++t) gx[t] = dxs[t];
-        if (rvalid) {
+        if (rvalid && !(a.dbg & 1)) {
             if (csr_lds) {
                 gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, gx);
             } else {
@@ -699,7 +737,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         f32x4* go = reinterpret_cast<f32x4*>(a.G + (size_t)grow * HP) + g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            const f32x4 yv = yr[4 * t];
+            const f32x4 yv = L > 1 ? ycur[t] : yr[4 * t];
             f32x4 v = gx[t];
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) v[q4] = yv[q4] > 0.f ? v[q4] : 0.f;
@@ -875,6 +913,7 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.amin = (const int*)(hsv + qp.hs.amin_off); a.z = (const float*)(hsv + qp.hs.z_off);
     a.vraw = (const float*)(hsv + qp.hs.v_off);
     a.dq = dq; a.d_out_v = d_out_v; a.G = G; a.d_embeds = d_embeds;
+    { const char* e = getenv("HEXGNN_DBG_ABLATE"); a.dbg = e ? atoi(e) : 0; }   // timing-only ablation (wrong results)
     a.dadv = (float*)(hws + qp.hw.dadv_off); a.dz = (float*)(hws + qp.hw.dz_off);
     a.dvr = (float*)(hws + qp.hw.dvr_off); a.lin_part = (float*)(hws + qp.hw.part_off);
     a.status = status;
