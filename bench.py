@@ -163,7 +163,14 @@ def main():
             flops = 2.0 * n * (2 * hidden) * hidden * hidden_layers / (launches / args.steps)
             roof = dict(bound="mfma", achieved=flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # measured HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs,
+        # gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), committed under profiles/; same config only
         roof["traffic"] = None
+        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
+        if args.config == "L256" and args.data == "D0" and B == 256 and os.path.exists(tpath):
+            for k, v in json.load(open(tpath)).items():
+                if KNAMES[dom] in k:
+                    roof["traffic"] = v["hbm_bytes_per_launch"]
         roof["kernel"] = KNAMES[dom]
         roof["avg_launch_us"] = avg_s * 1e6
         roof["launches_per_step"] = launches / args.steps

@@ -12,7 +12,6 @@
 //   Per layer the [agg|x] contraction is split in two K phases (W_l half, W_r half); while one half is in use the
 //   other half of the next phase/layer is streamed L2 -> registers -> LDS (two barriers per layer).
 //   fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): exact fmaf chains, deterministic.
-#include <cstdlib>
 #include "hexgnn_internal.h"
 
 namespace hexgnn {
@@ -22,7 +21,7 @@ constexpr int kRows = 128;            // rows per workgroup
 constexpr int kLdsBytes = 160 * 1024;
 
 struct QFwdArgs {
-    int n, b, c_in, H, L, mode, x_stride, need_backward, dbg;
+    int n, b, c_in, H, L, mode, x_stride, need_backward;
     const int* gptr; const int* rowptr; const int* col; const float* invdeg;
     const float* x;
     const char* wpack; size_t fwd_off[kMaxL]; size_t bias_off[kMaxL];
@@ -33,7 +32,7 @@ struct QFwdArgs {
 };
 
 struct QBwdArgs {
-    int n, b, H, L, mode, body_layers, dbg;
+    int n, b, H, L, mode, body_layers;
     const int* gptr; const int* rowptr_t; const int* col_t; const float* invdeg;
     const char* wpack; size_t bwd_off[kMaxL];
     const float* acts;
@@ -273,7 +272,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const size_t slab = (size_t)a.n * HP;
     for (int l = 1; l < a.L; ++l) {
         f32x4 stg[kStage];
-        if (!(a.dbg & 4) || l == 1) {   // stream W_r(l) towards half B
+        {   // stream W_r(l) towards half B
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]) + kHalf;
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
@@ -290,7 +289,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             f32x4 ag[NT];
 #pragma unroll
             for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid && !(a.dbg & 1)) {
+            if (rvalid) {
                 if (csr_lds) {
                     gather_lds<NT, XS>(xbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, ag);
                 } else {
@@ -303,29 +302,25 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 const float sc = a.invdeg[grow];
 #pragma unroll
                 for (int c = 0; c < NT; ++c) ag[c] *= sc;
-                if (a.need_backward && !(a.dbg & 2)) {
+                if (a.need_backward) {
                     f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) { if (a.dbg & 32) ao[4 * c] = ag[c]; else __builtin_nontemporal_store(ag[c], &ao[4 * c]); }
+                    for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
                 }
             }
-            if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, ag[c], acc);
         }
-        if (!(a.dbg & 4) || l == 1) {
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
-        }
         lds_barrier();     // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
-        if (l + 1 < a.L && !(a.dbg & 4)) {   // stream W_l(l+1) towards half A
+        if (l + 1 < a.L) {   // stream W_l(l+1) towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
         }
         if (wactive) {
             // phase 2: K-half over W_r (half B) with the self rows kept in registers
-            if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, xs[c], acc);
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
@@ -337,13 +332,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 xs[t] = v;
                 xr[4 * t] = v;
             }
-            if (rvalid && !(a.dbg & 2)) {
+            if (rvalid) {
                 f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
 #pragma unroll
-                for (int t = 0; t < NT; ++t) { if (a.dbg & 32) yo[4 * t] = xs[t]; else __builtin_nontemporal_store(xs[t], &yo[4 * t]); }
+                for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
             }
         }
-        if (l + 1 < a.L && !(a.dbg & 4)) {
+        if (l + 1 < a.L) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
         }
@@ -648,7 +643,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
         }
         f32x4 stg[kStage];
-        const bool more = l - 1 >= 1 && !(a.dbg & 4);
+        const bool more = l - 1 >= 1;
         if (more) {   // stream [W_l part] of layer l-1 towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
 #pragma unroll
@@ -671,12 +666,10 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                     ycur[t] = yn[4 * t];          // layer l-1's rows for the next iteration (layer 0's for the epilogue)
 #pragma unroll
                     for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
-                    if (a.dbg & 16) reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)(r0 + wave * 16) * HP)[t * 64 + lane] = gx[t];   // timing probe: dense 1 KB stores
-                    else if (!(a.dbg & 2)) { if (a.dbg & 32) go[4 * t] = gx[t]; else __builtin_nontemporal_store(gx[t], &go[4 * t]); }
+                    go[4 * t] = gx[t];
                 }
             }
             // phase 1: dAggS = (G W_l) / deg     (half A)
-            if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, gx[c], acc);
         }
@@ -702,7 +695,6 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         }
         if (wactive) {
             // phase 2: dXs = G W_r     (half B)
-            if (!(a.dbg & 8))
 #pragma unroll
             for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, gx[c], dxs);
         }
@@ -714,7 +706,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         // gradient w.r.t. this layer's input = dXs + transposed gather of dAggS
 #pragma unroll
         for (int t = 0; t < NT; ++t) gx[t] = dxs[t];
-        if (rvalid && !(a.dbg & 1)) {
+        if (rvalid) {
             if (csr_lds) {
                 gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, gx);
             } else {
@@ -850,7 +842,6 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     QFwdArgs a;
     a.n = n; a.b = b; a.c_in = c_in; a.H = hidden; a.L = total_layers; a.mode = mode; a.x_stride = x_stride;
     a.need_backward = need_backward;
-    { const char* e = getenv("HEXGNN_DBG_ABLATE"); a.dbg = e ? atoi(e) : 0; }   // timing-only ablation (wrong results)
     a.gptr = gptr; a.rowptr = rowptr; a.col = col; a.invdeg = invdeg; a.x = x;
     a.wpack = (const char*)wpack;
     for (int l = 0; l < total_layers; ++l) {
@@ -913,7 +904,6 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.amin = (const int*)(hsv + qp.hs.amin_off); a.z = (const float*)(hsv + qp.hs.z_off);
     a.vraw = (const float*)(hsv + qp.hs.v_off);
     a.dq = dq; a.d_out_v = d_out_v; a.G = G; a.d_embeds = d_embeds;
-    { const char* e = getenv("HEXGNN_DBG_ABLATE"); a.dbg = e ? atoi(e) : 0; }   // timing-only ablation (wrong results)
     a.dadv = (float*)(hws + qp.hw.dadv_off); a.dz = (float*)(hws + qp.hw.dz_off);
     a.dvr = (float*)(hws + qp.hw.dvr_off); a.lin_part = (float*)(hws + qp.hw.part_off);
     a.status = status;
