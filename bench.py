@@ -52,6 +52,8 @@ def main():
     ap.add_argument("--config", default="L256", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--data", default="D0", choices=["D0", "D1"])
+    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
+                    help="contraction arithmetic of the fused kernels: exact fp32 MFMA (default) or split bf16x3")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -69,6 +71,8 @@ def main():
     from helpers import batch_tensors, make_pair, sel_and_targets
     from gnn_hex_amd import _lib
     from gnn_hex_amd.dist import GradSync
+    from gnn_hex_amd import ops as hexops
+    hexops.set_math(args.math)
 
     num_layers, hidden, sizes_fn, label = CONFIGS[args.config]
     B = args.batch
@@ -185,7 +189,9 @@ def main():
         out = {
             "metric": "board-graphs/sec fwd+bwd", "value": value, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.math == "fp32" else "f32 operands split into bf16 hi+lo (bf16x3 MFMA), f32 accumulate",
+            "data": "synthetic",
             "config": {"workload": "%s, %s board graphs, %d graphs per GPU (N=%d nodes, E=%d directed edges)"
                                    % (label, "start-position" if args.data == "D0" else "random-playout",
                                       B, batches[0]["n"], batches[0]["e"]),

@@ -28,7 +28,7 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b);
 
 // pack all layers of a stack (forward + backward fragment order, padded bias) -- one launch
 int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
-                const float* const* wr, void* wpack, hipStream_t st);
+                const float* const* wr, void* wpack, hipStream_t st, int math = 0);
 // batched weight-gradient GEMM + reductions for all layers of a stack, given G (per-layer masked output gradients)
 int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
                         int x_stride, const float* acts, const char* saved, const float* G, float* const* d_wl,

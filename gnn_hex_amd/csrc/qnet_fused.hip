@@ -124,6 +124,64 @@ __device__ __forceinline__ void mfma_chunk(const f32x4* __restrict__ wfrag /* &w
     }
 }
 
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+
+// x = hi + lo (+ O(2^-16 |x|)) with hi, lo in bf16
+__device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)a[j]; hi[4 + j] = (__bf16)b[j]; }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { lo[j] = (__bf16)(a[j] - (float)hi[j]); lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]); }
+}
+__device__ __forceinline__ void split_one(const f32x4 a, bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]); }
+}
+
+// One K-half of a layer: acc[t] += sum_c W(c,t)^T * x[c] over the NT feature chunks of this lane's row.
+//   MATH 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), weights packed as float4 fragments.
+//   MATH 1: split precision ("bf16x3"): W ~ Whi + Wlo, x ~ xhi + xlo in bf16, acc += Wlo*xhi + Whi*xlo + Whi*xhi on
+//           v_mfma_f32_16x16x32_bf16 (chunk pairs) / v_mfma_f32_16x16x16_bf16 (odd last chunk), fp32 accumulate.
+template <int NT, int MATH>
+__device__ __forceinline__ void contract_half(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
+                                              f32x4 (&acc)[NT]) {
+    if constexpr (MATH == 0) {
+#pragma unroll
+        for (int c = 0; c < NT; ++c) mfma_chunk<NT>(whalf + (c * NT) * 64 + lane, x[c], acc);
+    } else {
+        const char* wb = reinterpret_cast<const char*>(whalf);
+#pragma unroll
+        for (int p = 0; p < NT / 2; ++p) {
+            bf16x8 xh, xl;
+            split_pair(x[2 * p], x[2 * p + 1], xh, xl);
+            const char* ub = wb + (2 * p) * NT * 1024 + lane * 16;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(ub + t * 2048);
+                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(ub + t * 2048 + 1024);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+            }
+        }
+        if constexpr (NT & 1) {
+            bf16x4 xh, xl;
+            split_one(x[NT - 1], xh, xl);
+            const char* ub = wb + (NT - 1) * NT * 1024 + lane * 8;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const bf16x4 wh = *reinterpret_cast<const bf16x4*>(ub + t * 1024);
+                const bf16x4 wl = *reinterpret_cast<const bf16x4*>(ub + t * 1024 + 512);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl, xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[t], 0, 0, 0);
+            }
+        }
+    }
+}
+
 // ag[c] += rows[j][chunk c] for every neighbour j of this lane's row; the NT reads of one neighbour are issued
 // together (distinct registers) and the next neighbour id is fetched one iteration ahead.
 template <int NT, int XS>
@@ -159,7 +217,7 @@ __device__ __forceinline__ void gather_lds(const float* __restrict__ rows, const
 }
 
 // ================================================= forward =================================================
-template <int NT>
+template <int NT, int MATH>
 __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     using LD = QLds<NT>;
     constexpr int HP = LD::HP, XS = LD::XS, kHalf = LD::kHalf;
@@ -308,8 +366,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                     for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
                 }
             }
-#pragma unroll
-            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, ag[c], acc);
+            contract_half<NT, MATH>(wbuf, lane, ag, acc);
         }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
@@ -321,8 +378,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         }
         if (wactive) {
             // phase 2: K-half over W_r (half B) with the self rows kept in registers
-#pragma unroll
-            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, xs[c], acc);
+            contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc);
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -474,7 +530,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
 //   G_l = (dXs_{l+1} + sum_{j in T(i)} dAggS_{l+1,j}) * [y_l > 0];  [dAggS_l | dXs_l] = G_l [W_l | W_r]
 // with dAggS rows exchanged through LDS and dXs / G kept in registers.  Writes G_l (all layers) for the batched
 // weight-gradient GEMM, and the head's per-graph partials.
-template <int NT>
+template <int NT, int MATH>
 __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     using LD = QLds<NT>;
     constexpr int HP = LD::HP, XS = LD::XS, kHalf = LD::kHalf;
@@ -512,8 +568,11 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         for (int k = 0; k < kPer; ++k) {
             const int i = tid + 512 * k;
             if (i < 2 * kHalf) {
-                const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
-                wbuf[(t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li] = tmp[k];
+                if constexpr (MATH == 1) wbuf[i] = tmp[k];
+                else {
+                    const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
+                    wbuf[(t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li] = tmp[k];
+                }
             }
         }
     }
@@ -649,7 +708,10 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) {
                 const int i = tid + 512 * k;
-                if (i < kHalf) { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + t) * 64 + li]; }
+                if (i < kHalf) {
+                    if constexpr (MATH == 1) stg[k] = src[i];
+                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + t) * 64 + li]; }
+                }
             }
         }
         f32x4 acc[NT];
@@ -670,8 +732,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 }
             }
             // phase 1: dAggS = (G W_l) / deg     (half A)
-#pragma unroll
-            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + (c * NT) * 64 + lane, gx[c], acc);
+            contract_half<NT, MATH>(wbuf, lane, gx, acc);
         }
         lds_barrier();     // barrier A: gathers of the previous layer are done (dbuf free); half A free
         if (more) {
@@ -681,7 +742,10 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) {   // stream [W_r part] of layer l-1 towards half B
                 const int i = tid + 512 * k;
-                if (i < kHalf) { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
+                if (i < kHalf) {
+                    if constexpr (MATH == 1) stg[k] = src[kHalf + i];
+                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
+                }
             }
         }
         f32x4 dxs[NT];
@@ -695,8 +759,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         }
         if (wactive) {
             // phase 2: dXs = G W_r     (half B)
-#pragma unroll
-            for (int c = 0; c < NT; ++c) mfma_chunk<NT>(wbuf + kHalf + (c * NT) * 64 + lane, gx[c], dxs);
+            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, dxs);
         }
         lds_barrier();     // barrier B: dAggS rows + half A visible; half B free
         if (more) {
@@ -738,27 +801,35 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     }
 }
 
-template <int NT>
-static int launch_qfwd(const QFwdArgs& a, hipStream_t st) {
+template <int NT, int MATH>
+static int launch_qfwd_m(const QFwdArgs& a, hipStream_t st) {
     static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fwd_kernel<NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fwd_kernel<NT, MATH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, QLds<NT>::total);
         return true;
     }();
     (void)once;
-    qnet_fwd_kernel<NT><<<a.b, 512, QLds<NT>::total, st>>>(a);
+    qnet_fwd_kernel<NT, MATH><<<a.b, 512, QLds<NT>::total, st>>>(a);
     return HEXGNN_OK;
 }
 template <int NT>
-static int launch_qbwd(const QBwdArgs& a, hipStream_t st) {
+static int launch_qfwd(const QFwdArgs& a, int math, hipStream_t st) {
+    return math == 1 ? launch_qfwd_m<NT, 1>(a, st) : launch_qfwd_m<NT, 0>(a, st);
+}
+template <int NT, int MATH>
+static int launch_qbwd_m(const QBwdArgs& a, hipStream_t st) {
     static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_bwd_kernel<NT>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_bwd_kernel<NT, MATH>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, QLds<NT>::total);
         return true;
     }();
     (void)once;
-    qnet_bwd_kernel<NT><<<a.b, 512, QLds<NT>::total, st>>>(a);
+    qnet_bwd_kernel<NT, MATH><<<a.b, 512, QLds<NT>::total, st>>>(a);
     return HEXGNN_OK;
+}
+template <int NT>
+static int launch_qbwd(const QBwdArgs& a, int math, hipStream_t st) {
+    return math == 1 ? launch_qbwd_m<NT, 1>(a, st) : launch_qbwd_m<NT, 0>(a, st);
 }
 
 #define HEXGNN_NT_SWITCH7(nt, CALL)                     \
@@ -825,9 +896,9 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
                         const float* const* wl, const float* const* bl, const float* const* wr,
                         const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
                         const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
-                        int need_backward, float* q, float* out_v, int* status, hexgnn_stream_t stream_) {
+                        int need_backward, int math, float* q, float* out_v, int* status, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    if (n < 0 || b < 0 || mode < 0 || mode > 2) return HEXGNN_EINVAL;
+    if (n < 0 || b < 0 || mode < 0 || mode > 2 || math < 0 || math > 1) return HEXGNN_EINVAL;
     QPlan qp;
     int rc = make_qplan(n, b, c_in, hidden, total_layers, &qp);
     if (rc != HEXGNN_OK) return rc;
@@ -836,7 +907,7 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     if (mode == 1 && !out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts || !q)) return HEXGNN_EINVAL;
     if (x_stride < c_in) return HEXGNN_EINVAL;
-    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st);
+    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st, math);
     if (rc != HEXGNN_OK) return rc;
     if (b == 0) return check_launch();
     QFwdArgs a;
@@ -856,7 +927,7 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     a.q = q; a.out_v = out_v; a.status = status;
     {
         KernelTimer kt(HEXGNN_K_QNET_FWD, st);
-        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qfwd<NT_>(a, st)));
+        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qfwd<NT_>(a, math, st)));
     }
     return check_launch();
 }
@@ -867,7 +938,7 @@ size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, 
     return q.ws_total;
 }
 
-int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode,
+int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
                          const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
                          const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
                          const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
@@ -876,7 +947,8 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
                          float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
                          hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    if (n < 0 || b < 0 || mode < 0 || mode > 2 || body_layers < 1 || body_layers > total_layers) return HEXGNN_EINVAL;
+    if (n < 0 || b < 0 || mode < 0 || mode > 2 || math < 0 || math > 1 || body_layers < 1 || body_layers > total_layers)
+        return HEXGNN_EINVAL;
     QPlan qp;
     int rc = make_qplan(n, b, c_in, hidden, total_layers, &qp);
     if (rc != HEXGNN_OK) return rc;
@@ -909,7 +981,7 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.status = status;
     if (b > 0 && n > 0) {
         KernelTimer kt(HEXGNN_K_QNET_BWD, st);
-        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qbwd<NT_>(a, st)));
+        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qbwd<NT_>(a, math, st)));
     } else {
         for (int l = 0; l < total_layers; ++l) {
             const int in = (l == 0) ? c_in : hidden;

@@ -96,6 +96,61 @@ __global__ void sage_pack_kernel(PackArgs a, char* __restrict__ wpack) {
     }
 }
 
+
+// ---- split-precision packing for the fused kernels (math mode 1, "bf16x3"): every fp32 weight w is stored as two
+//      bf16 planes hi = bf16(w), lo = bf16(w - hi); the contraction W*X ~= Whi*Xhi + Whi*Xlo + Wlo*Xhi runs on the bf16
+//      MFMA pipe with fp32 accumulation (product error ~3*2^-16 relative; measured parity in tests/test_gpu_model.py).
+//      Layout per K-half (NT*NT KiB, identical size to the fp32 pack): units u = chunk pairs (2p, 2p+1) [+ one odd
+//      chunk]; unit of s chunks at byte (first_chunk*NT) KiB; tile t at + t*s KiB; plane hi at +0, lo at + s*512 B;
+//      lane l at + l*8*s B holding the k-slots (kq = l>>4): j < 4 -> feature 16*c0 + 4*kq + j, j >= 4 -> 16*(c0+1) + 4*kq + j-4.
+struct Pack16Args {
+    LayerPtrs p;
+    size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers];
+    int nt, L, hidden, first_hidden;
+};
+__device__ __forceinline__ unsigned short bf16_bits(float v) { __bf16 b = (__bf16)v; return __builtin_bit_cast(unsigned short, b); }
+__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+
+__global__ void sage_pack16_kernel(Pack16Args a, char* __restrict__ wpack) {
+    const int l = a.first_hidden + blockIdx.y;
+    const int nt = a.nt, H = a.hidden;
+    const float* wl = a.p.wl[l];
+    const float* wr = a.p.wr[l];
+    // one thread per (direction, half, chunk c, tile t, lane, j<4): 2*2*nt*nt*64*4 elements
+    const int per_dir = 2 * nt * nt * 256;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= 2 * per_dir) return;
+    const int dir = tid / per_dir;              // 0 forward, 1 backward
+    int rem = tid % per_dir;
+    const int half = rem / (nt * nt * 256); rem %= nt * nt * 256;
+    const int c = rem / (nt * 256); rem %= nt * 256;
+    const int t = rem / 256; rem %= 256;
+    const int lane = rem >> 2, j = rem & 3;
+    const int kq = lane >> 4, m = lane & 15;
+    const float* w = half == 0 ? wl : wr;
+    float v;
+    if (dir == 0) {   // forward: k = input feature 16c+4kq+j, output o = 16t+m
+        const int k = 16 * c + 4 * kq + j, o = 16 * t + m;
+        v = (k < H && o < H) ? w[o * H + k] : 0.f;
+    } else {          // backward: k = output o = 16c+4kq+j, produces input feature i = 16t+m
+        const int o = 16 * c + 4 * kq + j, i = 16 * t + m;
+        v = (o < H && i < H) ? w[o * H + i] : 0.f;
+    }
+    const unsigned short hi = bf16_bits(v);
+    const unsigned short lo = bf16_bits(v - bf16_to_f32(hi));
+    const bool paired = (c | 1) < nt;           // chunk belongs to a full pair
+    const int c0 = c & ~1;
+    const int s = paired ? 2 : 1;
+    const int unit_first = paired ? c0 : c;
+    char* base = wpack + (dir == 0 ? a.fwd_off[l] : a.bwd_off[l]) + (size_t)half * nt * nt * 1024
+               + (size_t)unit_first * nt * 1024 + (size_t)t * s * 1024;
+    const int jj = paired ? (c - c0) * 4 + j : j;
+    unsigned short* ph = reinterpret_cast<unsigned short*>(base + lane * 8 * s) + jj;
+    unsigned short* pl = reinterpret_cast<unsigned short*>(base + s * 512 + lane * 8 * s) + jj;
+    *ph = hi;
+    *pl = lo;
+}
+
 // ---- first layer, raw features (c_in <= 8): VALU, HBM-bound ----------------------------------------
 // 32 rows per 256-thread workgroup.  Saves the aggregated raw features [n][8] for the backward pass.
 __global__ __launch_bounds__(256) void sage_first_fwd_kernel(
@@ -565,7 +620,7 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
 }
 
 int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
-                const float* const* wr, void* wpack, hipStream_t st) {
+                const float* const* wr, void* wpack, hipStream_t st, int math) {
     PackArgs pa;
     for (int l = 0; l < p.L; ++l) {
         if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
@@ -575,6 +630,15 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
     pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
     const int pack_elems = 2 * p.nt * p.nt * 256;
     sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
+    if (math == 1) {   // overwrite the hidden layers' weight packs with the split-bf16 layout (biases / raw layer stay fp32)
+        Pack16Args pb;
+        pb.p = pa.p;
+        for (int l = 0; l < p.L; ++l) { pb.fwd_off[l] = p.fwd_off[l]; pb.bwd_off[l] = p.bwd_off[l]; }
+        pb.nt = p.nt; pb.L = p.L; pb.hidden = hidden; pb.first_hidden = p.small_first ? 1 : 0;
+        const int nh = p.L - pb.first_hidden;
+        const int elems = 2 * 2 * p.nt * p.nt * 256;
+        if (nh > 0) sage_pack16_kernel<<<dim3((elems + 255) / 256, nh), 256, 0, st>>>(pb, (char*)wpack);
+    }
     return HEXGNN_OK;
 }
 
@@ -641,7 +705,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     if (need_backward && !saved) return HEXGNN_EINVAL;
     if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
 
-    rc = launch_pack(p, c_in, hidden, wl, bl, wr, wpack, st);
+    rc = launch_pack(p, c_in, hidden, wl, bl, wr, wpack, st, 0);
     if (rc != HEXGNN_OK) return rc;
     if (n == 0) return check_launch();
 

@@ -286,6 +286,18 @@ class HeadTailFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 
 _FUSED_ENABLED = True
+_MATH = 0     # 0 = exact fp32 MFMA, 1 = split precision "bf16x3" (fused kernels only)
+
+
+def set_math(mode) -> None:
+    """Arithmetic of the fused kernels' contractions: "fp32" (exact, default) or "bf16x3" (fp32 operands split into
+    bf16 hi+lo pairs, three bf16 MFMAs per product block, fp32 accumulation; ~1e-5 relative)."""
+    global _MATH
+    _MATH = {"fp32": 0, 0: 0, "bf16x3": 1, 1: 1}[mode]
+
+
+def get_math() -> str:
+    return "bf16x3" if _MATH == 1 else "fp32"
 
 
 def set_fused(enabled: bool) -> None:
@@ -329,13 +341,14 @@ class QNetFusedFn(torch.autograd.Function):
             n, b, c_in, hidden, tot, mode, gptr.data_ptr(), gs.rowptr.data_ptr(), gs.col.data_ptr(),
             gs.invdeg.data_ptr(), x.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr),
             tail[0].data_ptr(), tail[1].data_ptr(), tail[2].data_ptr(), tail[3].data_ptr(), tail[4].data_ptr(),
-            tail[5].data_ptr(), wpack.data_ptr(), acts.data_ptr(), saved.data_ptr(), int(need_bwd), q.data_ptr(),
+            tail[5].data_ptr(), wpack.data_ptr(), acts.data_ptr(), saved.data_ptr(), int(need_bwd), _MATH, q.data_ptr(),
             out_v.data_ptr() if out_v is not None else None, status.data_ptr(), _stream()), "hexgnn_qnet_forward")
         embeds = acts[body_layers - 1][:, :hidden]
         ctx.mark_non_differentiable(embeds)
         if need_bwd:
             ctx.gs, ctx.gptr = gs, gptr
             ctx.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride)
+            ctx.math = _MATH
             ctx.bufs = (x, acts, saved, wpack, tail, status)
             ctx.params = params
             offs, o = [], 0
@@ -375,7 +388,7 @@ class QNetFusedFn(torch.autograd.Function):
         ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
         ws = _bytes(ws_bytes, dev)
         _lib.check(L.hexgnn_qnet_backward(
-            n, b, c_in, hidden, tot, body_layers, mode, gptr.data_ptr(), gs.rowptr_t.data_ptr(),
+            n, b, c_in, hidden, tot, body_layers, mode, ctx.math, gptr.data_ptr(), gs.rowptr_t.data_ptr(),
             gs.col_t.data_ptr(), gs.invdeg.data_ptr(), x.data_ptr(), x_stride, acts.data_ptr(), saved.data_ptr(),
             wpack.data_ptr(), tail[0].data_ptr(), tail[2].data_ptr(), tail[4].data_ptr(), dq.data_ptr(),
             d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,

@@ -125,7 +125,11 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
  *      word written by hexgnn_csr_build (|= 1: node id out of range) can be shared.  wl/bl/wr list the body layers followed by the
  *      layers of the head that is evaluated (HOST arrays, total_layers entries).  saved/wpack/acts are produced
  *      by the forward call and consumed by the backward call of the same step.  Same results as the
- *      sage_stack + head calls above (same fmaf chains per output element). ------------------------------- */
+ *      sage_stack + head calls above.
+ *      math: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; same fmaf chains as the layered kernels);
+ *            1 = split precision "bf16x3": every fp32 operand a = hi + lo (bf16 pair), W*x ~= Whi*xhi + Whi*xlo + Wlo*xhi on
+ *                the bf16 MFMA pipe with fp32 accumulation (relative product error ~3*2^-16; Q / gradients stay within the
+ *                1e-4 parity bar, see tests/test_gpu_model.py).  The backward call must use the math of its forward. ---- */
 int hexgnn_qnet_supported(int c_in, int hidden, int max_nodes_per_graph);
 size_t hexgnn_qnet_saved_bytes(int n, int b, int c_in, int hidden, int total_layers);
 int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,
@@ -134,12 +138,12 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
                         const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
                         const float* v1_w, const float* v1_b,
                         void* wpack /* hexgnn_sage_stack_pack_bytes(c_in, hidden, total_layers) */,
-                        float* acts /*[total_layers][n][HP]*/, void* saved, int need_backward,
+                        float* acts /*[total_layers][n][HP]*/, void* saved, int need_backward, int math,
                         float* q /*[n]*/, float* out_v /*[b] (mode 1) or NULL*/, int* status /*[1], caller-zeroed*/,
                         hexgnn_stream_t stream);
 size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, int total_layers);
 /* d_embeds: optional [n][HP] gradient w.r.t. the output of body layer body_layers-1 (final_conv_grads). */
-int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode,
+int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
                          const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
                          const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
                          const float* lin_w, const float* v0_w, const float* v1_w,
