@@ -1,836 +1,7 @@
-// Whole modern_two_headed Q-network per launch: one 512-thread workgroup per board graph (<= 128 nodes).
-//
-// Reference path: DuellingTwoHeaded.forward (GN0/models.py:537-584) = CachifiedGNN body (261-294) -> head gnn ->
-// HeadNetwork tail (374-384) -> dueling combine (571-584), and its autograd backward.
-//
-// MI355X design.  A Hex-11 graph is 123 x 110 fp32 = 54 KB: the node features of ALL layers stay in the CU's
-// 160 KB LDS, so neighbour gathers are LDS reads and nothing but the saved activations goes to HBM.
-//   LDS:  [ W half A | W half B | node rows 128 x (HP+4) | CSR (u16 rowptr, u8 col) ]
-//   wave w owns rows 16w..16w+15; lane (r = l&15, g = l>>4) holds, for its row r, the 4-float feature chunks
-//   {16c+4g..+3}, c < NT.  MFMAs run with SWAPPED operands (a = packed weights, b = row fragment): the tile comes
-//   out transposed, i.e. in the SAME lane layout, so a layer's output registers are the next layer's self operand.
-//   Per layer the [agg|x] contraction is split in two K phases (W_l half, W_r half); while one half is in use the
-//   other half of the next phase/layer is streamed L2 -> registers -> LDS (two barriers per layer).
-//   fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): exact fmaf chains, deterministic.
-#include "hexgnn_internal.h"
+// C ABI of the fused per-graph path + the exact-fp32 instantiations (kernels: qnet_fused_kernels.h).
+#include "qnet_fused_kernels.h"
 
 namespace hexgnn {
-
-constexpr int kMaxL = kMaxLayers;
-constexpr int kRows = 128;            // rows per workgroup
-constexpr int kLdsBytes = 160 * 1024;
-
-struct QFwdArgs {
-    int n, b, c_in, H, L, mode, x_stride, need_backward;
-    const int* gptr; const int* rowptr; const int* col; const float* invdeg;
-    const float* x;
-    const char* wpack; size_t fwd_off[kMaxL]; size_t bias_off[kMaxL];
-    float* acts; char* saved; size_t agg_off[kMaxL];
-    const float* lin_w; const float* lin_b; const float* v0_w; const float* v0_b; const float* v1_w; const float* v1_b;
-    float* adv_raw; float* pooled; int* amax; int* amin; float* z; float* vraw;
-    float* q; float* out_v; int* status;
-};
-
-struct QBwdArgs {
-    int n, b, H, L, mode, body_layers;
-    const int* gptr; const int* rowptr_t; const int* col_t; const float* invdeg;
-    const char* wpack; size_t bwd_off[kMaxL];
-    const float* acts;
-    const float* lin_w; const float* v0_w; const float* v1_w;
-    const float* adv_raw; const int* amax; const int* amin; const float* z; const float* vraw;
-    const float* dq; const float* d_out_v;
-    float* G; float* d_embeds;
-    float* dadv; float* dz; float* dvr; float* lin_part;
-    int* status;
-};
-
-template <int NT> struct QLds {
-    static constexpr int HP = 16 * NT;
-    static constexpr int XS = HP + 4;                       // row stride (floats): (4NT+1) 16-B slots, odd
-    static constexpr int kHalf = NT * NT * 64;              // float4 per weight half
-    static constexpr int off_w = 0;
-    static constexpr int off_x = 2 * kHalf * 16;
-    static constexpr int off_rp = off_x + kRows * XS * 4;
-    static constexpr int off_col = off_rp + 272;            // (kRows+2) u16, padded
-    static constexpr int col_cap = (kLdsBytes - off_col) < 8192 ? (kLdsBytes - off_col) : 8192;
-    // 16 KB of scratch (first-layer operands, head-tail reductions): aliases the weight halves when they are
-    // large enough (NT >= 4), otherwise a region of its own (small widths leave plenty of LDS)
-    static constexpr bool scr_alias = NT >= 4;
-    static constexpr int scr_bytes = 16384;
-    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_col + col_cap;   // half B
-    static constexpr int off_scr_tail = scr_alias ? off_w : off_col + col_cap;
-    static constexpr int total = off_col + col_cap + (scr_alias ? 0 : scr_bytes);
-    static_assert(col_cap >= 1024 && total <= kLdsBytes, "LDS budget");
-    static_assert(!scr_alias || kHalf * 16 >= scr_bytes, "scratch must fit one weight half");
-};
-
-__device__ __forceinline__ float wsum64(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-    return v;
-}
-
-// CSR of the workgroup's graph -> LDS (u16 row offsets, u8 local column ids).  Returns false when it does not fit
-// (the caller then walks the global CSR).
-template <int NT>
-__device__ __forceinline__ bool load_csr(char* lds, const int* __restrict__ rowptr, const int* __restrict__ col,
-                                         int r0, int cnt, int e0, int ne, int* status) {
-    using LD = QLds<NT>;
-    unsigned short* s_rp = reinterpret_cast<unsigned short*>(lds + LD::off_rp);
-    unsigned char* s_col = reinterpret_cast<unsigned char*>(lds + LD::off_col);
-    const bool fits = ne <= LD::col_cap;
-    if (!fits) return false;
-    for (int i = threadIdx.x; i <= cnt; i += 512) s_rp[i] = (unsigned short)(rowptr[r0 + i] - e0);
-    for (int e = threadIdx.x; e < ne; e += 512) {
-        const int j = col[e0 + e] - r0;
-        if (j < 0 || j >= cnt) { atomicOr(status, 4); s_col[e] = 0; }
-        else s_col[e] = (unsigned char)j;
-    }
-    return true;
-}
-
-
-
-
-// Workgroup barrier for LDS hand-offs only: waits for this wave's LDS traffic (lgkmcnt) but NOT for its global
-// stores/loads (vmcnt).  __syncthreads() would drain vmcnt(0) first, exposing the latency of the saved-tensor stores
-// (acts / agg / G are consumed by LATER kernels, never through this barrier) every layer.
-__device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-}
-
-// global -> LDS copy of `count` float4 with all loads of a thread issued before its first LDS write
-template <int kMaxPer>
-__device__ __forceinline__ void copy_f4_to_lds(f32x4* __restrict__ dst, const f32x4* __restrict__ src, int count) {
-    f32x4 tmp[kMaxPer];
-#pragma unroll
-    for (int k = 0; k < kMaxPer; ++k) { const int i = threadIdx.x + 512 * k; if (i < count) tmp[k] = src[i]; }
-#pragma unroll
-    for (int k = 0; k < kMaxPer; ++k) { const int i = threadIdx.x + 512 * k; if (i < count) dst[i] = tmp[k]; }
-}
-
-// acc[t] += W-fragment(c,t) x row-fragment(c), all NT output tiles per k-chunk with the accumulators ROTATING
-// (consecutive v_mfma never touch the same accumulator: 16x16x4 has a 40-cycle dependent latency, 32-cycle issue).
-template <int NT>
-__device__ __forceinline__ void mfma_chunk(const f32x4* __restrict__ wfrag /* &w[(c*NT)*64 + lane] */, const f32x4 a,
-                                           f32x4 (&acc)[NT]) {
-    f32x4 w[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) w[t] = wfrag[t * 64];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16x16x4(w[t][j], a[j], acc[t]);
-    }
-}
-
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-// x = hi + lo (+ O(2^-16 |x|)) with hi, lo in bf16
-__device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)a[j]; hi[4 + j] = (__bf16)b[j]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { lo[j] = (__bf16)(a[j] - (float)hi[j]); lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]); }
-}
-__device__ __forceinline__ void split_one(const f32x4 a, bf16x4& hi, bf16x4& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]); }
-}
-
-// One K-half of a layer: acc[t] += sum_c W(c,t)^T * x[c] over the NT feature chunks of this lane's row.
-//   MATH 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), weights packed as float4 fragments.
-//   MATH 1: split precision ("bf16x3"): W ~ Whi + Wlo, x ~ xhi + xlo in bf16, acc += Wlo*xhi + Whi*xlo + Whi*xhi on
-//           v_mfma_f32_16x16x32_bf16 (chunk pairs) / v_mfma_f32_16x16x16_bf16 (odd last chunk), fp32 accumulate.
-template <int NT, int MATH>
-__device__ __forceinline__ void contract_half(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
-                                              f32x4 (&acc)[NT]) {
-    if constexpr (MATH == 0) {
-#pragma unroll
-        for (int c = 0; c < NT; ++c) mfma_chunk<NT>(whalf + (c * NT) * 64 + lane, x[c], acc);
-    } else {
-        const char* wb = reinterpret_cast<const char*>(whalf);
-#pragma unroll
-        for (int p = 0; p < NT / 2; ++p) {
-            bf16x8 xh, xl;
-            split_pair(x[2 * p], x[2 * p + 1], xh, xl);
-            const char* ub = wb + (2 * p) * NT * 1024 + lane * 16;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(ub + t * 2048);
-                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(ub + t * 2048 + 1024);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
-            }
-        }
-        if constexpr (NT & 1) {
-            bf16x4 xh, xl;
-            split_one(x[NT - 1], xh, xl);
-            const char* ub = wb + (NT - 1) * NT * 1024 + lane * 8;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const bf16x4 wh = *reinterpret_cast<const bf16x4*>(ub + t * 1024);
-                const bf16x4 wl = *reinterpret_cast<const bf16x4*>(ub + t * 1024 + 512);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl, xh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[t], 0, 0, 0);
-            }
-        }
-    }
-}
-
-// ag[c] += rows[j][chunk c] for every neighbour j of this lane's row; the NT reads of one neighbour are issued
-// together (distinct registers) and the next neighbour id is fetched one iteration ahead.
-template <int NT, int XS>
-__device__ __forceinline__ void gather_lds(const float* __restrict__ rows, const unsigned char* __restrict__ s_col,
-                                           int eb, int ee, int g, f32x4 (&ag)[NT]) {
-    int e = eb;
-    // two neighbours per iteration: 2*NT reads of 16 B in flight per lane before the first add
-    while (e + 1 < ee) {
-        const int j0 = (int)s_col[e], j1 = (int)s_col[e + 1];
-        e += 2;
-        const f32x4* x0 = reinterpret_cast<const f32x4*>(rows + j0 * XS) + g;
-        const f32x4* x1 = reinterpret_cast<const f32x4*>(rows + j1 * XS) + g;
-        f32x4 t0[NT], t1[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) ag[c] += t0[c];      // ascending neighbour order kept: (.. + x_j0) + x_j1
-#pragma unroll
-        for (int c = 0; c < NT; ++c) ag[c] += t1[c];
-    }
-    if (e < ee) {
-        const f32x4* x0 = reinterpret_cast<const f32x4*>(rows + (int)s_col[e] * XS) + g;
-        f32x4 t0[NT];
-#pragma unroll
-        for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int c = 0; c < NT; ++c) ag[c] += t0[c];
-    }
-}
-
-// ================================================= forward =================================================
-template <int NT, int MATH>
-__global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
-    using LD = QLds<NT>;
-    constexpr int HP = LD::HP, XS = LD::XS, kHalf = LD::kHalf;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    f32x4* wbuf = reinterpret_cast<f32x4*>(lds + LD::off_w);       // [2][kHalf]
-    float* xbuf = reinterpret_cast<float*>(lds + LD::off_x);       // [kRows][XS]
-    const unsigned short* s_rp = reinterpret_cast<const unsigned short*>(lds + LD::off_rp);
-    const unsigned char* s_col = reinterpret_cast<const unsigned char*>(lds + LD::off_col);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int gi = blockIdx.x;
-    const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
-    const int cnt = r1 - r0;
-    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
-    const int H = a.H;
-    const int lrow = wave * 16 + r;                 // local row of this lane
-    const bool rvalid = lrow < cnt;
-    const bool wactive = wave * 16 < cnt;           // wave-uniform
-    const int grow = r0 + lrow;
-    const int e0 = a.rowptr[r0], ne = a.rowptr[r1] - e0;
-    const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
-
-    // ---- stage W_l of layer 1 into half A; first-layer scratch lives in half B ----
-    if (a.L > 1)
-        copy_f4_to_lds<(LD::kHalf + 511) / 512>(wbuf, reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]), kHalf);
-    float* s_w0 = reinterpret_cast<float*>(lds + LD::off_scr_first);  // [2][HP][8]
-    float* s_f = s_w0 + 2 * HP * kSmallCin;                          // [kRows][16]: agg0 | x0
-    {
-        // raw features of the graph's rows -> LDS (x0 half of s_f), first-layer weights -> LDS: all independent
-        // global loads, one barrier; the neighbour sums then run on LDS only.
-        copy_f4_to_lds<(2 * HP * kSmallCin / 4 + 511) / 512>(reinterpret_cast<f32x4*>(s_w0),
-                                                              reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[0]),
-                                                              2 * HP * kSmallCin / 4);
-#pragma unroll
-        for (int i = tid; i < kRows * kSmallCin; i += 512) {
-            const int rr = i / kSmallCin, qq = i % kSmallCin;
-            s_f[rr * 16 + 8 + qq] = (rr < cnt && qq < a.c_in) ? a.x[(size_t)(r0 + rr) * a.x_stride + qq] : 0.f;
-        }
-        __syncthreads();
-        if (tid < kRows) {
-            float ag0[kSmallCin];
-#pragma unroll
-            for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] = 0.f;
-            if (tid < cnt) {
-                const int row = r0 + tid;
-                if (csr_lds) {
-                    for (int e = s_rp[tid]; e < s_rp[tid + 1]; ++e) {
-                        const float* xr = s_f + (int)s_col[e] * 16 + 8;
-#pragma unroll
-                        for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] += xr[qq];
-                    }
-                } else {
-                    for (int e = a.rowptr[row]; e < a.rowptr[row + 1]; ++e) {
-                        const float* xr = s_f + (a.col[e] - r0) * 16 + 8;
-#pragma unroll
-                        for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] += xr[qq];
-                    }
-                }
-                const float sc = a.invdeg[row];
-#pragma unroll
-                for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] *= sc;
-                if (a.need_backward) {
-                    f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[0]) + (size_t)row * kSmallCin);
-                    ao[0] = f32x4{ag0[0], ag0[1], ag0[2], ag0[3]};
-                    ao[1] = f32x4{ag0[4], ag0[5], ag0[6], ag0[7]};
-                }
-            }
-#pragma unroll
-            for (int qq = 0; qq < kSmallCin; ++qq) s_f[tid * 16 + qq] = ag0[qq];
-        }
-    }
-    __syncthreads();
-
-    // ---- layer 0 (raw features): every lane produces its own row chunks, already in the chained layout ----
-    f32x4 xs[NT];
-    {
-        const float* b0 = reinterpret_cast<const float*>(a.wpack + a.bias_off[0]);
-        float f[16];
-#pragma unroll
-        for (int qq = 0; qq < 16; ++qq) f[qq] = s_f[lrow * 16 + qq];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 v = reinterpret_cast<const f32x4*>(b0)[4 * t + g];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int o = 16 * t + 4 * g + q4;
-                const float* wl0 = s_w0 + o * kSmallCin;
-                const float* wr0 = s_w0 + HP * kSmallCin + o * kSmallCin;
-                float s = v[q4];
-#pragma unroll
-                for (int qq = 0; qq < kSmallCin; ++qq) s += wl0[qq] * f[qq] + wr0[qq] * f[8 + qq];
-                v[q4] = rvalid ? fmaxf(s, 0.f) : 0.f;
-            }
-            xs[t] = v;
-        }
-        f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) xr[4 * t] = xs[t];
-        if (rvalid) {
-            f32x4* yo = reinterpret_cast<f32x4*>(a.acts + (size_t)grow * HP) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
-        }
-    }
-    __syncthreads();   // xbuf + half A visible; half B (scratch) free
-
-    // ---- hidden layers ----
-    constexpr int kStage = (kHalf + 511) / 512;
-    const size_t slab = (size_t)a.n * HP;
-    for (int l = 1; l < a.L; ++l) {
-        f32x4 stg[kStage];
-        {   // stream W_r(l) towards half B
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]) + kHalf;
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
-        }
-        // the bias is the accumulator's initial value (loaded now, consumed by the first MFMA of each tile)
-        f32x4 acc[NT];
-        {
-            const f32x4* br = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = br[4 * t];
-        }
-        if (wactive) {
-            // phase 1: mean-gather from LDS, then K-half over W_l (half A)
-            f32x4 ag[NT];
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid) {
-                if (csr_lds) {
-                    gather_lds<NT, XS>(xbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, ag);
-                } else {
-                    for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
-                        const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
-#pragma unroll
-                        for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
-                    }
-                }
-                const float sc = a.invdeg[grow];
-#pragma unroll
-                for (int c = 0; c < NT; ++c) ag[c] *= sc;
-                if (a.need_backward) {
-                    f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
-                }
-            }
-            contract_half<NT, MATH>(wbuf, lane, ag, acc);
-        }
-#pragma unroll
-        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
-        lds_barrier();     // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
-        if (l + 1 < a.L) {   // stream W_l(l+1) towards half A
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
-        }
-        if (wactive) {
-            // phase 2: K-half over W_r (half B) with the self rows kept in registers
-            contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc);
-            f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                f32x4 v = acc[t];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) v[q4] = (rvalid && v[q4] > 0.f) ? v[q4] : 0.f;
-                xs[t] = v;
-                xr[4 * t] = v;
-            }
-            if (rvalid) {
-                f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
-            }
-        }
-        if (l + 1 < a.L) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-        }
-        lds_barrier();     // barrier 2: new rows + half A visible; half B free
-    }
-
-    // ---- head tail (scratch aliases the weight halves, free after the last barrier) ----
-    float* sc = reinterpret_cast<float*>(lds + LD::off_scr_tail);
-    float* s_w = sc;                 // [128] advantage weights
-    float* s_pool = sc + 128;        // [4*128]
-    float* s_z = sc + 640;           // [64]
-    float* s_red = sc + 704;         // [8]
-    float* s_misc = sc + 712;        // [0] = tanh(v)
-    float* s_mx = sc + 768;          // [3][128]
-    float* s_mn = sc + 1152;         // [3][128]
-    float* s_sm = sc + 1536;         // [3][128]
-    int* s_ax = reinterpret_cast<int*>(sc + 1920);   // [3][128]
-    int* s_an = reinterpret_cast<int*>(sc + 2304);   // [3][128]
-    const int H2 = H / 2, H4 = 4 * H;
-    if (tid < 128) s_w[tid] = tid < H ? a.lin_w[tid] : 0.f;
-    __syncthreads();
-    // advantages from the registers: partial dot over this lane's chunks, reduce over the 4 lanes of the row
-    float adv = 0.f;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
-        adv += xs[t][0] * w[0] + xs[t][1] * w[1] + xs[t][2] * w[2] + xs[t][3] * w[3];
-    }
-    adv += __shfl_xor(adv, 16);
-    adv += __shfl_xor(adv, 32);
-    adv += a.lin_b[0];
-    const float tadv = 2.f * tanhf(adv);
-    if (g == 0 && rvalid) {
-        a.adv_raw[grow] = adv;
-        if (a.mode == 2) a.q[grow] = tadv;
-    }
-    if (a.mode == 2) return;
-    {   // sum of 2tanh(adv) over the graph: lanes g==0 of valid rows; fixed-shape tree
-        float v = (g == 0 && rvalid) ? tadv : 0.f;
-        v = wsum64(v);
-        if (lane == 0) s_red[wave] = v;
-    }
-    // value-MLP weights of this wave's hidden units (k = wave + 8i) -> registers now; the loads fly during pooling
-    constexpr int kKI = 8, kCJ = 8;     // up to 64 hidden units, 4H <= 512 columns
-    float wv[kKI][kCJ];
-#pragma unroll
-    for (int i = 0; i < kKI; ++i) {
-        const int k = wave + 8 * i;
-#pragma unroll
-        for (int j = 0; j < kCJ; ++j) {
-            const int c = lane + 64 * j;
-            wv[i][j] = (k < H2 && c < H4) ? a.v0_w[(size_t)k * H4 + c] : 0.f;
-        }
-    }
-    // pooling straight from the LDS rows: column c = tid&127, four row phases
-    {
-        const int c = tid & 127, ph = tid >> 7;
-        float sum = 0.f, mx = -INFINITY, mn = INFINITY;
-        int ax = -1, an = -1;
-        if (c < H) {
-            for (int row = ph; row < cnt; row += 4) {
-                const float v = xbuf[row * XS + c];
-                sum += v;
-                if (v > mx) { mx = v; ax = row; }
-                if (v < mn) { mn = v; an = row; }
-            }
-        }
-        if (ph > 0) {
-            const int o = (ph - 1) * 128 + c;
-            s_sm[o] = sum; s_mx[o] = mx; s_mn[o] = mn; s_ax[o] = ax; s_an[o] = an;
-        }
-        __syncthreads();
-        if (ph == 0 && c < H) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-                const int o = p * 128 + c;
-                sum += s_sm[o];
-                const float mx1 = s_mx[o], mn1 = s_mn[o];
-                const int ax1 = s_ax[o], an1 = s_an[o];
-                if (ax1 >= 0 && (ax < 0 || mx1 > mx || (mx1 == mx && ax1 < ax))) { mx = mx1; ax = ax1; }
-                if (an1 >= 0 && (an < 0 || mn1 < mn || (mn1 == mn && an1 < an))) { mn = mn1; an = an1; }
-            }
-            if (cnt == 0) { mx = 0.f; mn = 0.f; }
-            const float mean = sum / (float)max(cnt, 1);
-            s_pool[c] = sum; s_pool[H + c] = mx; s_pool[2 * H + c] = mn; s_pool[3 * H + c] = mean;
-            float* pg = a.pooled + (size_t)gi * H4;
-            pg[c] = sum; pg[H + c] = mx; pg[2 * H + c] = mn; pg[3 * H + c] = mean;
-            a.amax[(size_t)gi * H + c] = ax >= 0 ? r0 + ax : -1;
-            a.amin[(size_t)gi * H + c] = an >= 0 ? r0 + an : -1;
-        }
-    }
-    __syncthreads();
-    {
-        float pl[kCJ];
-#pragma unroll
-        for (int j = 0; j < kCJ; ++j) { const int c = lane + 64 * j; pl[j] = c < H4 ? s_pool[c] : 0.f; }
-#pragma unroll
-        for (int i = 0; i < kKI; ++i) {
-            const int k = wave + 8 * i;
-            float p = 0.f;
-#pragma unroll
-            for (int j = 0; j < kCJ; ++j) p += wv[i][j] * pl[j];     // same column order as the layered kernel
-            p = wsum64(p);
-            if (lane == 0 && k < H2) {
-                const float zz = fmaxf(p + a.v0_b[k], 0.f);
-                s_z[k] = zz;
-                a.z[(size_t)gi * H2 + k] = zz;
-            }
-        }
-    }
-    __syncthreads();
-    if (wave == 0) {
-        float p = lane < H2 ? a.v1_w[lane] * s_z[lane] : 0.f;
-        p = wsum64(p);
-        if (lane == 0) {
-            const float v = p + a.v1_b[0];
-            a.vraw[gi] = v;
-            s_misc[0] = tanhf(v);
-        }
-    }
-    __syncthreads();
-    float adv_total = 0.f;
-#pragma unroll
-    for (int w = 0; w < 8; ++w) adv_total += s_red[w];
-    const float mean_adv = adv_total / (float)max(cnt, 1);
-    const float V = s_misc[0];
-    if (a.mode == 1 && tid == 0) a.out_v[gi] = V;
-    if (g == 0 && rvalid) a.q[grow] = (a.mode == 0 ? V : 0.f) + tadv - mean_adv;
-}
-
-// ================================================= backward =================================================
-// Data-gradient chain of the whole network for one graph: head tail backward, then per layer
-//   G_l = (dXs_{l+1} + sum_{j in T(i)} dAggS_{l+1,j}) * [y_l > 0];  [dAggS_l | dXs_l] = G_l [W_l | W_r]
-// with dAggS rows exchanged through LDS and dXs / G kept in registers.  Writes G_l (all layers) for the batched
-// weight-gradient GEMM, and the head's per-graph partials.
-template <int NT, int MATH>
-__global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
-    using LD = QLds<NT>;
-    constexpr int HP = LD::HP, XS = LD::XS, kHalf = LD::kHalf;
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    f32x4* wbuf = reinterpret_cast<f32x4*>(lds + LD::off_w);
-    float* dbuf = reinterpret_cast<float*>(lds + LD::off_x);
-    const unsigned short* s_rp = reinterpret_cast<const unsigned short*>(lds + LD::off_rp);
-    const unsigned char* s_col = reinterpret_cast<const unsigned char*>(lds + LD::off_col);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = lane & 15, g = lane >> 4;
-    const int gi = blockIdx.x;
-    const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
-    const int cnt = r1 - r0;
-    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
-    const int H = a.H, L = a.L;
-    const int lrow = wave * 16 + r;
-    const bool rvalid = lrow < cnt;
-    const bool wactive = wave * 16 < cnt;
-    const int grow = r0 + lrow;
-    const int e0 = a.rowptr_t[r0], ne = a.rowptr_t[r1] - e0;
-    const bool csr_lds = load_csr<NT>(lds, a.rowptr_t, a.col_t, r0, cnt, e0, ne, a.status);
-    const size_t slab = (size_t)a.n * HP;
-    const int H2 = H / 2, H4 = 4 * H;
-    constexpr int kStage = (kHalf + 511) / 512;
-
-    // stage both weight halves of the top layer (tiles t < NT -> half A, t >= NT -> half B)
-    if (L > 1) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]);
-        constexpr int kPer = (2 * LD::kHalf + 511) / 512;
-        f32x4 tmp[kPer];
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) { const int i = tid + 512 * k; if (i < 2 * kHalf) tmp[k] = src[i]; }
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int i = tid + 512 * k;
-            if (i < 2 * kHalf) {
-                if constexpr (MATH == 1) wbuf[i] = tmp[k];
-                else {
-                    const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
-                    wbuf[(t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li] = tmp[k];
-                }
-            }
-        }
-    }
-
-    // ---- head tail backward; scratch aliases dbuf (not written before the first barrier A) ----
-    float* sc = dbuf;
-    float* s_w = sc;                  // [128]
-    float* s_dp = sc + 128;           // [4*128]
-    float* s_dz = sc + 640;           // [64]
-    float* s_red = sc + 704;          // [8]
-    float* s_dar = sc + 768;          // [128]
-    int* s_ax = reinterpret_cast<int*>(sc + 896);    // [128] local row of the max
-    int* s_an = reinterpret_cast<int*>(sc + 1024);
-    float* s_lin = sc + 1152;         // [8][HP+1]
-    if (tid < 128) s_w[tid] = tid < H ? a.lin_w[tid] : 0.f;
-    float mean_dq = 0.f;
-    const float inv_cnt = 1.f / (float)max(cnt, 1);
-    if (a.mode != 2) {
-        float ps = 0.f;
-        if (tid < cnt) ps = a.dq[r0 + tid];
-        ps = wsum64(ps);
-        if (lane == 0) s_red[wave] = ps;
-        if (tid < H) {
-            const int ax = a.amax[(size_t)gi * H + tid], an = a.amin[(size_t)gi * H + tid];
-            s_ax[tid] = ax >= 0 ? ax - r0 : -1;
-            s_an[tid] = an >= 0 ? an - r0 : -1;
-        }
-        __syncthreads();
-        float sdq = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) sdq += s_red[w];
-        mean_dq = sdq * inv_cnt;
-        const float dV = a.mode == 0 ? sdq : a.d_out_v[gi];
-        const float V = tanhf(a.vraw[gi]);
-        const float dv = dV * (1.f - V * V);
-        if (tid == 0) a.dvr[gi] = dv;
-        if (tid < H2) {
-            const float zz = a.z[(size_t)gi * H2 + tid];
-            const float d = zz > 0.f ? a.v1_w[tid] * dv : 0.f;
-            s_dz[tid] = d;
-            a.dz[(size_t)gi * H2 + tid] = d;
-        }
-        __syncthreads();
-        for (int c = tid; c < H4; c += 512) {
-            float p = 0.f;
-#pragma unroll 16
-            for (int k = 0; k < H2; ++k) p += a.v0_w[(size_t)k * H4 + c] * s_dz[k];   // independent loads, 16 in flight
-            s_dp[c] = p;
-        }
-    }
-    if (tid < kRows) {
-        float dar = 0.f;
-        if (tid < cnt) {
-            const float t = tanhf(a.adv_raw[r0 + tid]);
-            dar = (a.dq[r0 + tid] - mean_dq) * 2.f * (1.f - t * t);
-            a.dadv[r0 + tid] = dar;
-        }
-        s_dar[tid] = dar;
-    }
-    __syncthreads();
-
-    // gradient w.r.t. the top layer's output, in the chained lane layout; advantage-linear partial alongside
-    f32x4 gx[NT];
-    {
-        const float dar = s_dar[lrow];
-        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
-        float lacc[NT * 4];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
-            f32x4 yv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid) yv = yr[4 * t];
-            f32x4 v;
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const int c = 16 * t + 4 * g + q4;
-                float s = dar * w[q4];
-                if (a.mode != 2 && c < H) {
-                    s += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
-                    if (s_ax[c] == lrow) s += s_dp[H + c];
-                    if (s_an[c] == lrow) s += s_dp[2 * H + c];
-                }
-                v[q4] = (rvalid && c < H) ? s : 0.f;
-                lacc[4 * t + q4] = dar * yv[q4];
-            }
-            gx[t] = v;
-        }
-        // d lin_w[c] partial = sum_rows dar*h[row][c]: reduce over the 16 rows of the wave, then over waves
-        float bacc = g == 0 ? dar : 0.f;
-#pragma unroll
-        for (int off = 1; off <= 8; off <<= 1) {
-#pragma unroll
-            for (int k = 0; k < NT * 4; ++k) lacc[k] += __shfl_xor(lacc[k], off);
-            bacc += __shfl_xor(bacc, off);
-        }
-        if (r == 0) {
-#pragma unroll
-            for (int t = 0; t < NT; ++t)
-#pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) s_lin[wave * (HP + 1) + 16 * t + 4 * g + q4] = lacc[4 * t + q4];
-            if (g == 0) s_lin[wave * (HP + 1) + HP] = bacc;
-        }
-    }
-    __syncthreads();
-    if (tid <= HP) {
-        float s = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) s += s_lin[w * (HP + 1) + tid];
-        a.lin_part[(size_t)gi * (HP + 1) + tid] = s;
-    }
-    __syncthreads();   // scratch consumed; dbuf may be overwritten from here on
-
-    // ---- layer chain ----
-    // y rows of the layer about to be masked are fetched one layer ahead (global latency off the critical path)
-    f32x4 ycur[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) ycur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (rvalid && L > 1) {
-        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) ycur[t] = yr[4 * t];
-    }
-    for (int l = L - 1; l >= 1; --l) {
-        if (a.d_embeds && l == a.body_layers - 1 && rvalid) {
-            f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
-        }
-        f32x4 stg[kStage];
-        const bool more = l - 1 >= 1;
-        if (more) {   // stream [W_l part] of layer l-1 towards half A
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) {
-                const int i = tid + 512 * k;
-                if (i < kHalf) {
-                    if constexpr (MATH == 1) stg[k] = src[i];
-                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + t) * 64 + li]; }
-                }
-            }
-        }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (wactive) {
-            // mask by this layer's ReLU, publish G_l
-            if (rvalid) {
-                f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
-                const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 yv = ycur[t];
-                    ycur[t] = yn[4 * t];          // layer l-1's rows for the next iteration (layer 0's for the epilogue)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
-                    go[4 * t] = gx[t];
-                }
-            }
-            // phase 1: dAggS = (G W_l) / deg     (half A)
-            contract_half<NT, MATH>(wbuf, lane, gx, acc);
-        }
-        lds_barrier();     // barrier A: gathers of the previous layer are done (dbuf free); half A free
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) {   // stream [W_r part] of layer l-1 towards half B
-                const int i = tid + 512 * k;
-                if (i < kHalf) {
-                    if constexpr (MATH == 1) stg[k] = src[kHalf + i];
-                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
-                }
-            }
-        }
-        f32x4 dxs[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) dxs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            const float scl = rvalid ? a.invdeg[grow] : 0.f;
-            f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) dr[4 * t] = acc[t] * scl;
-        }
-        if (wactive) {
-            // phase 2: dXs = G W_r     (half B)
-            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, dxs);
-        }
-        lds_barrier();     // barrier B: dAggS rows + half A visible; half B free
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
-        }
-        // gradient w.r.t. this layer's input = dXs + transposed gather of dAggS
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gx[t] = dxs[t];
-        if (rvalid) {
-            if (csr_lds) {
-                gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, gx);
-            } else {
-                for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
-                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
-                }
-            }
-        }
-    }
-    // ---- layer 0: G_0 = grad * [y_0 > 0] (its weight gradient is a separate VALU kernel) ----
-    if (a.d_embeds && a.body_layers - 1 == 0 && rvalid) {
-        f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
-    }
-    if (rvalid) {
-        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + (size_t)grow * HP) + g;
-        f32x4* go = reinterpret_cast<f32x4*>(a.G + (size_t)grow * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 yv = L > 1 ? ycur[t] : yr[4 * t];
-            f32x4 v = gx[t];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] = yv[q4] > 0.f ? v[q4] : 0.f;
-            go[4 * t] = v;
-        }
-    }
-}
-
-template <int NT, int MATH>
-static int launch_qfwd_m(const QFwdArgs& a, hipStream_t st) {
-    static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_fwd_kernel<NT, MATH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLds<NT>::total);
-        return true;
-    }();
-    (void)once;
-    qnet_fwd_kernel<NT, MATH><<<a.b, 512, QLds<NT>::total, st>>>(a);
-    return HEXGNN_OK;
-}
-template <int NT>
-static int launch_qfwd(const QFwdArgs& a, int math, hipStream_t st) {
-    return math == 1 ? launch_qfwd_m<NT, 1>(a, st) : launch_qfwd_m<NT, 0>(a, st);
-}
-template <int NT, int MATH>
-static int launch_qbwd_m(const QBwdArgs& a, hipStream_t st) {
-    static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&qnet_bwd_kernel<NT, MATH>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, QLds<NT>::total);
-        return true;
-    }();
-    (void)once;
-    qnet_bwd_kernel<NT, MATH><<<a.b, 512, QLds<NT>::total, st>>>(a);
-    return HEXGNN_OK;
-}
-template <int NT>
-static int launch_qbwd(const QBwdArgs& a, int math, hipStream_t st) {
-    return math == 1 ? launch_qbwd_m<NT, 1>(a, st) : launch_qbwd_m<NT, 0>(a, st);
-}
 
 #define HEXGNN_NT_SWITCH7(nt, CALL)                     \
     switch (nt) {                                      \
@@ -843,6 +14,17 @@ static int launch_qbwd(const QBwdArgs& a, int math, hipStream_t st) {
         case 7: { constexpr int NT_ = 7; CALL; } break; \
         default: return HEXGNN_EUNSUPPORTED;           \
     }
+
+int launch_qfwd_math(int nt, int math, const QFwdArgs& a, hipStream_t st) {
+    if (math == 1) return launch_qfwd_split(nt, a, st);
+    HEXGNN_NT_SWITCH7(nt, (launch_qfwd_m<NT_, 0>(a, st)));
+    return HEXGNN_OK;
+}
+int launch_qbwd_math(int nt, int math, const QBwdArgs& a, hipStream_t st) {
+    if (math == 1) return launch_qbwd_split(nt, a, st);
+    HEXGNN_NT_SWITCH7(nt, (launch_qbwd_m<NT_, 0>(a, st)));
+    return HEXGNN_OK;
+}
 
 }  // namespace hexgnn
 
@@ -927,7 +109,8 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     a.q = q; a.out_v = out_v; a.status = status;
     {
         KernelTimer kt(HEXGNN_K_QNET_FWD, st);
-        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qfwd<NT_>(a, math, st)));
+        rc = launch_qfwd_math(qp.sp.nt, math, a, st);
+        if (rc != HEXGNN_OK) return rc;
     }
     return check_launch();
 }
@@ -981,7 +164,8 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.status = status;
     if (b > 0 && n > 0) {
         KernelTimer kt(HEXGNN_K_QNET_BWD, st);
-        HEXGNN_NT_SWITCH7(qp.sp.nt, (launch_qbwd<NT_>(a, math, st)));
+        rc = launch_qbwd_math(qp.sp.nt, math, a, st);
+        if (rc != HEXGNN_OK) return rc;
     } else {
         for (int l = 0; l < total_layers; ++l) {
             const int in = (l == 0) ? c_in : hidden;
