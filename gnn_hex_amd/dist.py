@@ -40,6 +40,25 @@ class GradSync:
             self._key = key
         return self._flat
 
+    @staticmethod
+    def _adopt_flat(active: List[torch.nn.Parameter]) -> Optional[torch.Tensor]:
+        """If the gradients already are consecutive views of ONE fp32 buffer (the fused backward allocates them
+        that way), return that buffer as a 1-D tensor: the all-reduce then needs no copy in or out."""
+        g0 = active[0].grad
+        if g0.dtype != torch.float32:
+            return None
+        st = g0.untyped_storage()
+        base = st.data_ptr()
+        off = g0.storage_offset()
+        start = off
+        for p in active:
+            g = p.grad
+            if g.dtype != torch.float32 or not g.is_contiguous() or g.untyped_storage().data_ptr() != base \
+                    or g.storage_offset() != off:
+                return None
+            off += g.numel()
+        return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, start, (off - start,))
+
     def all_reduce(self) -> int:
         """Sum (or average) gradients over the process group in place.  Returns the bucket size in elements."""
         active = [p for p in self.params if p.grad is not None]
@@ -48,6 +67,12 @@ class GradSync:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
             return sum(p.numel() for p in active)
+        flat = self._adopt_flat(active)
+        if flat is not None:            # zero-copy: one collective on the buffer the backward wrote
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                flat.mul_(1.0 / world)
+            return flat.numel()
         flat = self._bucket(active)
         off = 0
         views = []

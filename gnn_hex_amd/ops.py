@@ -351,11 +351,15 @@ class QNetFusedFn(torch.autograd.Function):
             ctx.math = _MATH
             ctx.bufs = (x, acts, saved, wpack, tail, status)
             ctx.params = params
-            offs, o = [], 0
-            for p in params:
-                offs.append(o)
-                o += p.numel()
-            ctx.param_offsets = (offs, o)
+            # flat gradient layout follows model.parameters() order (convs..., value_head.layers.*, linear.*) so that
+            # GradSync can all-reduce the buffer in place; the call's tail order is (lin_w, lin_b, v0_w, v0_b, v1_w, v1_b)
+            nconv = 3 * tot
+            flat_order = list(range(nconv)) + [nconv + 2, nconv + 3, nconv + 4, nconv + 5, nconv + 0, nconv + 1]
+            offs, o = [0] * len(params), 0
+            for i in flat_order:
+                offs[i] = o
+                o += params[i].numel()
+            ctx.param_offsets = (offs, o, flat_order)
             ctx.grad_sink = grad_sink
         if mode == 1:
             return out_v, q, embeds
@@ -377,9 +381,12 @@ class QNetFusedFn(torch.autograd.Function):
         # ONE flat gradient buffer for all parameters (views are handed to autograd): one allocation instead of
         # 66, and the layout a single RCCL all-reduce wants (gnn_hex_amd.dist.GradSync adopts it without copies).
         params = ctx.params
-        offs, total = ctx.param_offsets
+        offs, total, flat_order = ctx.param_offsets
         flat = torch.empty(total, dtype=torch.float32, device=dev)
-        grads = list(torch._C._nn.unflatten_dense_tensors(flat, params))
+        ordered = torch._C._nn.unflatten_dense_tensors(flat, [params[i] for i in flat_order])
+        grads = [None] * len(params)
+        for i, gview in zip(flat_order, ordered):
+            grads[i] = gview
         base = flat.data_ptr()
         ptrs = [base + 4 * o for o in offs]
         cp, tp = ptrs[:3 * tot], ptrs[3 * tot:]

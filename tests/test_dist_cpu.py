@@ -60,6 +60,19 @@ def _worker(rank, world, port, q):
             ok = ok and p.grad is None
         else:
             ok = ok and torch.allclose(p.grad, torch.full(p.shape, 1.5))
+    # third step: gradients that already live in ONE flat buffer (what the fused backward produces) are reduced in
+    # place, without the copy in / copy out
+    for p in model.parameters():
+        p.grad = None
+    active = [p for k, p in model.named_parameters() if not k.startswith("breaker_head")]
+    flat = torch.full((sum(p.numel() for p in active),), float(rank + 1))
+    views = torch._C._nn.unflatten_dense_tensors(flat, active)
+    for p, v in zip(active, views):
+        p.grad = v
+    ok = ok and sync._adopt_flat(active) is not None
+    sync.all_reduce()
+    ok = ok and torch.allclose(flat, torch.full_like(flat, 1.5))
+    ok = ok and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(active, views))
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()

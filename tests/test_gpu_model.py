@@ -51,7 +51,10 @@ def _compare(hip, ref, x, ei, batch, ptr, tol=TOL):
             continue
         assert g_hip[k] is not None, "%s: missing grad" % k
         gerr = (g_hip[k].cpu() - g_ref[k]).abs().max().item()
-        assert gerr < tol, "%s grad max abs err %g" % (k, gerr)
+        # 1e-4 absolute while the gradient tensor is O(1) (every board-graph case); relative to its largest entry when
+        # that exceeds 1 (synthetic dense graphs push pooled sums, hence value-head gradients, into the hundreds)
+        scale = max(1.0, g_ref[k].abs().max().item())
+        assert gerr < tol * scale, "%s grad max abs err %g (scale %g)" % (k, gerr, scale)
     return err
 
 
@@ -184,3 +187,78 @@ def test_cpu_tensors_fail_loudly():
     x, ei, batch, ptr = batch_tensors("D0", [5])
     with pytest.raises(HexGnnError):
         hip(x, ei, batch, ptr)
+
+
+def test_gradients_form_one_flat_buffer():
+    """The fused backward writes every parameter gradient into ONE buffer in model.parameters() order, which is what
+    lets gnn_hex_amd.dist.GradSync all-reduce it in place (no flatten / unflatten copies)."""
+    from gnn_hex_amd import ops
+    from gnn_hex_amd.dist import GradSync
+    if not ops._FUSED_ENABLED:
+        pytest.skip("layered path allocates per-stack gradients")
+    hip, _ = make_pair(4, 35, seed=1)
+    x, ei, batch, ptr = batch_tensors("D1", [7] * 4)
+    q = hip(x.cuda(), ei.cuda(), batch.cuda(), ptr.cuda())
+    q.sum().backward()
+    active = [p for p in hip.parameters() if p.grad is not None]
+    flat = GradSync._adopt_flat(active)
+    assert flat is not None and flat.numel() == sum(p.numel() for p in active)
+    assert torch.equal(flat, torch.cat([p.grad.reshape(-1) for p in active]))
+
+
+def _random_batch(sizes, seed, directed=True, p_edge=0.08):
+    """Arbitrary (non-board) graphs: directed edges, duplicate edges, isolated nodes -- the reference model accepts any
+    edge_index (torch_geometric semantics: mean over in-edges, duplicates counted, isolated -> 0)."""
+    rng = np.random.default_rng(seed)
+    xs, eis, bv, ptr, off = [], [], [], [0], 0
+    for g, n in enumerate(sizes):
+        x = np.zeros((n, 3), np.float32)
+        x[:, 0] = rng.integers(0, 9, n)
+        x[: min(2, n), 1] = 1
+        x[:, 2] = 1.0
+        m = rng.random((n, n)) < p_edge
+        np.fill_diagonal(m, False)
+        if n > 3:
+            m[:, n - 1] = False          # node n-1 has no in-edges
+            m[n - 2, :] = False          # node n-2 has no out-edges
+        src, dst = np.nonzero(m)
+        if not directed:
+            src, dst = np.concatenate([src, dst]), np.concatenate([dst, src])
+        if len(src) > 4:                 # duplicate a few edges
+            dup = rng.integers(0, len(src), 3)
+            src, dst = np.concatenate([src, src[dup]]), np.concatenate([dst, dst[dup]])
+        perm = rng.permutation(len(src))
+        xs.append(x)
+        eis.append(np.stack([src[perm], dst[perm]]).astype(np.int64) + off)
+        bv.append(np.full(n, g, np.int64))
+        off += n
+        ptr.append(off)
+    return (torch.from_numpy(np.concatenate(xs)), torch.from_numpy(np.concatenate(eis, 1)),
+            torch.from_numpy(np.concatenate(bv)), torch.tensor(ptr, dtype=torch.long))
+
+
+@pytest.mark.parametrize("directed", [True, False])
+def test_arbitrary_graphs_directed_duplicates_isolated(directed):
+    hip, ref = make_pair(4, 35, seed=21)
+    x, ei, batch, ptr = _random_batch([1, 2, 17, 40, 64, 128, 5, 90], seed=3, directed=directed)
+    _compare(hip, ref, x, ei, batch, ptr)
+
+
+def test_graph_size_boundary_128_129():
+    """128 nodes still fits a workgroup's LDS (fused path); one 129-node graph sends the batch down the layered path."""
+    hip, ref = make_pair(3, 35, seed=22)
+    x, ei, batch, ptr = _random_batch([128, 127, 16], seed=5, directed=False, p_edge=0.04)
+    _compare(hip, ref, x, ei, batch, ptr)
+    x, ei, batch, ptr = _random_batch([129, 16, 200], seed=6, directed=False, p_edge=0.03)
+    _compare(hip, ref, x, ei, batch, ptr)
+
+
+def test_dense_graph_exceeds_lds_csr_capacity():
+    """A graph whose edge list does not fit the LDS CSR cache (u8 columns, ~3.8 KB at hidden 110) walks the global CSR."""
+    hip, ref = make_pair(3, 110, seed=23)
+    from gnn_hex_amd import ops
+    x, ei, batch, ptr = _random_batch([100, 100], seed=7, directed=True, p_edge=0.6)
+    assert ei.shape[1] > 2 * 3800
+    # degree-60 random graphs with features up to 8 are far outside the board-graph domain (degree <= ~12): the exact
+    # fp32 paths still meet 1e-4; the split-precision math (relative error ~1e-5 of the summed magnitudes) gets 5e-4 here
+    _compare(hip, ref, x, ei, batch, ptr, tol=5e-4 if ops.get_math() == "bf16x3" else TOL)
