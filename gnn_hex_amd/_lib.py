@@ -55,6 +55,10 @@ _SIGS = {
     "hexgnn_env_step": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "hexgnn_env_observe": (ci, [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_env_export": (ci, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_states_observe": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_per_init": (ci, [ci, vp, vp, vp]),
+    "hexgnn_per_update": (ci, [ci, ci, vp, vp, vp, vp, vp]),
+    "hexgnn_per_sample": (ci, [ci, ci, ci, C.c_double, vp, vp, vp, vp, vp, vp]),
     "hexgnn_profile_enable": (ci, [ci]),
     "hexgnn_profile_read": (ci, [vp, vp]),
     "hexgnn_pad_rows": (ci, [ci, ci, vp, ci, vp, vp]),

@@ -284,6 +284,16 @@ struct Game {
     }
 };
 
+// observation source: an array of board states (the live envs, or a replay ring) + which of them to emit
+struct StateSrc {
+    int nv, W, K;
+    const uint64_t* adj;      // [num_states][nv][W]
+    const uint8_t* alive;     // [num_states][nv]
+    const int* maker_turn;    // [num_states] int32 side flags, or null
+    const uint8_t* side_u8;   // [num_states] u8 side flags (used when maker_turn is null)
+    const int* index;         // [k] state picked for output graph i, or null (identity)
+};
+
 __device__ __forceinline__ void load_game(Game& g, const EnvDev& d, int env, char* lds) {
     g.nv = d.nv; g.W = d.W; g.K = d.K; g.lane = threadIdx.x; g.maker_won = false;
     g.adj = reinterpret_cast<uint64_t*>(lds);
@@ -396,7 +406,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev d, const int* __res
 //   edge_global [2][E]: the same with the graph's node offset added (Batch.edge_index)
 //   rowptr [N+1], col [E]: sorted CSR over global node ids (== what hexgnn_csr_build would produce), invdeg [N]
 // node_off / edge_off: exclusive prefix sums of the per-env sizes (computed by the caller from the step result).
-__global__ __launch_bounds__(64) void env_observe_kernel(EnvDev d, const int* __restrict__ node_off,
+__global__ __launch_bounds__(64) void env_observe_kernel(StateSrc d, const int* __restrict__ node_off,
                                                        const int* __restrict__ edge_off, float* __restrict__ x,
                                                        int64_t* __restrict__ backmap, int64_t* __restrict__ edge_local,
                                                        int64_t* __restrict__ edge_global, int64_t e_total,
@@ -404,9 +414,19 @@ __global__ __launch_bounds__(64) void env_observe_kernel(EnvDev d, const int* __
                                                        float* __restrict__ invdeg, int64_t* __restrict__ batch_vec,
                                                        int write_rowptr_end) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int env = blockIdx.x;
+    const int env = blockIdx.x;                               // output graph
+    const int src = d.index ? d.index[env] : env;             // state it is built from
     Game g;
-    load_game(g, d, env, lds);
+    g.nv = d.nv; g.W = d.W; g.K = d.K; g.lane = threadIdx.x; g.maker_won = false;
+    g.adj = reinterpret_cast<uint64_t*>(lds);
+    g.scr = g.adj + (size_t)d.nv * d.W;
+    g.alive = reinterpret_cast<uint8_t*>(g.scr + 4 * kMaxW);
+    {
+        const uint64_t* sa = d.adj + (size_t)src * d.nv * d.W;
+        for (int i = threadIdx.x; i < d.nv * d.W; i += 64) g.adj[i] = sa[i];
+        for (int i = threadIdx.x; i < d.nv; i += 64) g.alive[i] = d.alive[(size_t)src * d.nv + i];
+        __syncthreads();
+    }
     short* rank = reinterpret_cast<short*>(g.alive + ((d.nv + 15) / 16) * 16);   // [nv]
     int* lowoff = reinterpret_cast<int*>(rank + ((d.nv + 7) / 8) * 8);           // [nv]: offset of the (s>t) edges of s
     int* rowoff = lowoff + d.nv;                                                    // [nv]: CSR row start (local)
@@ -414,7 +434,7 @@ __global__ __launch_bounds__(64) void env_observe_kernel(EnvDev d, const int* __
     const int n0 = node_off[env], e0 = edge_off[env];
     const int ne = edge_off[env + 1] - e0;       // directed edges of this graph
     const int half = ne / 2;
-    const float side = d.maker_turn[env] ? 1.f : 0.f;
+    const float side = (d.maker_turn ? d.maker_turn[src] != 0 : d.side_u8[src] != 0) ? 1.f : 0.f;
     // ranks + per-vertex counts via running prefix over 64-vertex groups
     int run_rank = 0, run_low = 0, run_row = 0;
     for (int k = 0; k < g.K; ++k) {
@@ -622,8 +642,37 @@ int hexgnn_env_observe(hexgnn_env* h, const int* node_off, const int* edge_off, 
         return true;
     }();
     (void)once;
+    StateSrc src;
+    src.nv = e->d.nv; src.W = e->d.W; src.K = e->d.K;
+    src.adj = e->d.adj; src.alive = e->d.alive; src.maker_turn = e->d.maker_turn; src.side_u8 = nullptr; src.index = nullptr;
     env_observe_kernel<<<e->d.num_envs, 64, env_lds_bytes(e->d), (hipStream_t)stream_>>>(
-        e->d, node_off, edge_off, x, backmap, edge_local, edge_global, e_total, rowptr, col, invdeg, batch_vec, 1);
+        src, node_off, edge_off, x, backmap, edge_local, edge_global, e_total, rowptr, col, invdeg, batch_vec, 1);
+    return check_launch();
+}
+
+int hexgnn_states_observe(int hex_size, int k, const uint64_t* adj, const uint8_t* alive, const uint8_t* side,
+                          const int* index, const int* node_off, const int* edge_off, int64_t e_total, float* x,
+                          int64_t* backmap, int64_t* edge_local, int64_t* edge_global, int* rowptr, int* col,
+                          float* invdeg, int64_t* batch_vec, hexgnn_stream_t stream_) {
+    if (hex_size < 2 || k < 0 || !adj || !alive || !side || !node_off || !edge_off || !x || !backmap || !edge_local ||
+        !edge_global || !rowptr || !col || !invdeg || !batch_vec || e_total < 0)
+        return HEXGNN_EINVAL;
+    const int nv = hex_size * hex_size + 2, W = (nv + 63) / 64;
+    if (W > kMaxW) return HEXGNN_EUNSUPPORTED;
+    if (k == 0) return HEXGNN_OK;
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&env_observe_kernel),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        return true;
+    }();
+    (void)once;
+    EnvDev tmp;
+    tmp.nv = nv; tmp.W = W; tmp.K = (nv + 63) / 64;
+    StateSrc src;
+    src.nv = nv; src.W = W; src.K = tmp.K;
+    src.adj = adj; src.alive = alive; src.maker_turn = nullptr; src.side_u8 = side; src.index = index;
+    env_observe_kernel<<<k, 64, env_lds_bytes(tmp), (hipStream_t)stream_>>>(
+        src, node_off, edge_off, x, backmap, edge_local, edge_global, e_total, rowptr, col, invdeg, batch_vec, 1);
     return check_launch();
 }
 

@@ -1,0 +1,99 @@
+// Prioritized experience replay on the device: proportional prioritisation (Schaul et al. 2016) over a sum tree and
+// a min tree kept in HBM, stratified sampling, importance weights.
+//
+// Reference: the RainbowDQN replay buffer lives in the un-vendored submodule GN0/RainbowDQN/Rainbow (.gitmodules:1-4,
+// fork of schmidtdominik/Rainbow); only its flags are visible (README.md:5,7: --prioritized_er=True
+// --prioritized_er_beta0=0.6 --buffer_size=260000 --n_step=2).  PARITY UNPINNED: this follows the published
+// segment-tree algorithm (OpenAI-baselines form: priorities p^alpha in a sum tree and a min tree of capacity 2^k;
+// batch sample i draws mass = (i + u_i) * total / B and descends the sum tree; weight_i = (N * p_i / total)^-beta /
+// (N * p_min / total)^-beta) and is checked bit for bit against oracle/replay_ref.py.
+// Trees are fp64 (deterministic parent = left + right), node 1 is the root, leaves at [cap, 2cap).
+#include "hexgnn_common.h"
+
+namespace hexgnn {
+
+// set leaves then rebuild the touched ancestors level by level; one workgroup (updates per call <= a few thousand)
+__global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const int* __restrict__ idx,
+                                                         const double* __restrict__ prio_alpha,
+                                                         double* __restrict__ sum_tree, double* __restrict__ min_tree) {
+    for (int i = threadIdx.x; i < k; i += 1024) {
+        if (idx[i] < 0 || idx[i] >= cap) continue;          // out-of-range slots are ignored
+        const int leaf = cap + idx[i];
+        sum_tree[leaf] = prio_alpha[i];
+        min_tree[leaf] = prio_alpha[i];
+    }
+    __syncthreads();
+    for (int width = cap >> 1, shift = 1; width >= 1; width >>= 1, ++shift) {
+        for (int i = threadIdx.x; i < k; i += 1024) {
+            if (idx[i] < 0 || idx[i] >= cap) continue;
+            const int node = (cap + idx[i]) >> shift;       // duplicates recompute the same value
+            const double l = sum_tree[2 * node], r = sum_tree[2 * node + 1];
+            sum_tree[node] = l + r;
+            const double ml = min_tree[2 * node], mr = min_tree[2 * node + 1];
+            min_tree[node] = ml < mr ? ml : mr;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void per_sample_kernel(int cap, int size, int b, double beta, const double* __restrict__ u,
+                                  const double* __restrict__ sum_tree, const double* __restrict__ min_tree,
+                                  int* __restrict__ out_idx, float* __restrict__ out_w) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= b) return;
+    const double total = sum_tree[1];
+    double mass = ((double)i + u[i]) * (total / (double)b);
+    int node = 1;
+    while (node < cap) {                                     // find_prefixsum_idx
+        const double l = sum_tree[2 * node];
+        if (l > mass) node = 2 * node;
+        else { mass -= l; node = 2 * node + 1; }
+    }
+    int leaf = node - cap;
+    if (leaf >= size) leaf = size - 1;                       // rounding at the right edge
+    out_idx[i] = leaf;
+    const double p_min = min_tree[1] / total;
+    const double max_w = pow(p_min * (double)size, -beta);
+    const double p = sum_tree[cap + leaf] / total;
+    out_w[i] = (float)(pow(p * (double)size, -beta) / max_w);
+}
+
+__global__ void per_fill_kernel(int n, double v_sum, double v_min, double* __restrict__ sum_tree,
+                                double* __restrict__ min_tree) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { sum_tree[i] = v_sum; min_tree[i] = v_min; }
+}
+
+}  // namespace hexgnn
+
+using namespace hexgnn;
+
+extern "C" {
+
+int hexgnn_per_init(int capacity_pow2, double* sum_tree, double* min_tree, hexgnn_stream_t stream_) {
+    if (capacity_pow2 < 1 || (capacity_pow2 & (capacity_pow2 - 1)) || !sum_tree || !min_tree) return HEXGNN_EINVAL;
+    const int n = 2 * capacity_pow2;
+    per_fill_kernel<<<(n + 255) / 256, 256, 0, (hipStream_t)stream_>>>(n, 0.0, INFINITY, sum_tree, min_tree);
+    return check_launch();
+}
+
+int hexgnn_per_update(int capacity_pow2, int k, const int* idx, const double* prio_alpha, double* sum_tree,
+                      double* min_tree, hexgnn_stream_t stream_) {
+    if (capacity_pow2 < 1 || (capacity_pow2 & (capacity_pow2 - 1)) || k < 0 || !sum_tree || !min_tree) return HEXGNN_EINVAL;
+    if (k == 0) return HEXGNN_OK;
+    if (!idx || !prio_alpha) return HEXGNN_EINVAL;
+    per_update_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(capacity_pow2, k, idx, prio_alpha, sum_tree, min_tree);
+    return check_launch();
+}
+
+int hexgnn_per_sample(int capacity_pow2, int size, int b, double beta, const double* u, const double* sum_tree,
+                      const double* min_tree, int* out_idx, float* out_w, hexgnn_stream_t stream_) {
+    if (capacity_pow2 < 1 || (capacity_pow2 & (capacity_pow2 - 1)) || size < 1 || size > capacity_pow2 || b < 1 || !u ||
+        !sum_tree || !min_tree || !out_idx || !out_w)
+        return HEXGNN_EINVAL;
+    per_sample_kernel<<<(b + 255) / 256, 256, 0, (hipStream_t)stream_>>>(capacity_pow2, size, b, beta, u, sum_tree,
+                                                                         min_tree, out_idx, out_w);
+    return check_launch();
+}
+
+}  // extern "C"

@@ -24,7 +24,9 @@ from .data import Batch, Data
 class ObsList:
     """List[Data]-compatible view of one batched observation of all envs."""
 
-    def __init__(self, x, edge_local, edge_global, backmap, batch_vec, node_off, edge_off, gs, is_maker, max_nodes):
+    def __init__(self, x, edge_local, edge_global, backmap, batch_vec, node_off, edge_off, gs, is_maker, max_nodes,
+                 snap=None):
+        self._snap = snap          # (adj [k,nv,W] i64, alive [k,nv] u8) board snapshot the replay buffer stores
         self.x, self.edge_local, self.edge_global, self.backmap = x, edge_local, edge_global, backmap
         self.batch_vec = batch_vec
         self.node_off, self.edge_off = node_off, edge_off     # host lists, len num_envs+1
@@ -47,8 +49,14 @@ class ObsList:
             d = Data(x=self.x[n0:n1], edge_index=self.edge_local[:, e0:e1], backmap=self.backmap[n0:n1])
             d.x._hex_is_maker = self.is_maker
             d.x._hex_max_nodes = n1 - n0
+            d._hex_src = (self, i)
             self._items[i] = d
         return d
+
+    def snapshot(self):
+        if self._snap is None:
+            raise ValueError("this observation was taken without board snapshots (Env_manager.record_snapshots=False)")
+        return self._snap
 
     def __iter__(self):
         return (self[i] for i in range(len(self)))
@@ -108,6 +116,7 @@ class Env_manager:
         self.gao_mode = gao_mode
         self.border_fill = border_fill
         self.cnn_hex_size = cnn_hex_size
+        self.record_snapshots = True     # keep the 2 KB/env board snapshot with every observation (replay storage)
         self.device = torch.device(device if device is not None else "cuda")
         if self.device.type != "cuda":
             raise _lib.HexGnnError("Env_manager runs only on the MI355X HIP path (no CPU fallback)")
@@ -152,6 +161,17 @@ class Env_manager:
         self.last_obs = None
 
     # ---- observation -----------------------------------------------------------------------------------
+    def _snapshot_handle(self, h, k):
+        L = _lib.lib()
+        dev = self.device
+        adj = torch.empty((k, self._nv, self._words), dtype=torch.int64, device=dev)
+        alive = torch.empty((k, self._nv), dtype=torch.uint8, device=dev)
+        mt = torch.empty(k, dtype=torch.int32, device=dev)
+        tm = torch.empty(k, dtype=torch.int32, device=dev)
+        _lib.check(L.hexgnn_env_export(h, adj.data_ptr(), alive.data_ptr(), mt.data_ptr(), tm.data_ptr(), None, None,
+                                       ops._stream()), "hexgnn_env_export")
+        return adj, alive
+
     def _observe_handle(self, h, sizes, is_maker) -> ObsList:
         L = _lib.lib()
         dev = self.device
@@ -179,15 +199,18 @@ class Env_manager:
                                         el_base, eg_base, rowptr.data_ptr(), col.data_ptr(), invdeg.data_ptr(),
                                         batch_vec.data_ptr(), ops._stream()), "hexgnn_env_observe")
         gs = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
+        snap = self._snapshot_handle(h, k) if self.record_snapshots else None
         return ObsList(x, edge_local, edge_global, backmap, batch_vec, node_off.tolist(), edge_off.tolist(), gs,
-                       is_maker, int(sizes[:, 0].max()) if k else 0)
+                       is_maker, int(sizes[:, 0].max()) if k else 0, snap)
 
     @property
     def starting_obs(self) -> Data:
         """Fresh ``Data`` of the start position with maker to move (multi_env_manager.py:41-49)."""
         obs = self._observe_handle(self._base, self._base_sizes, True)
         d = obs[0]
-        return Data(x=d.x.clone(), edge_index=d.edge_index.clone(), backmap=d.backmap.clone())
+        out = Data(x=d.x.clone(), edge_index=d.edge_index.clone(), backmap=d.backmap.clone())
+        out._hex_src = (obs, 0)
+        return out
 
     def observe(self) -> ObsList:
         self.last_obs = self._observe_handle(self._h, self._sizes, self.global_onturn == "m")

@@ -1,0 +1,193 @@
+"""Device-resident n-step replay for the RainbowDQN loop: transitions as produced by ``Env_manager.get_transitions``
+are stored in HBM as fixed-size board-state snapshots (the env's adjacency bit matrix: 2 KB per Hex-11 state), sampled
+uniformly or with proportional prioritisation (sum / min trees on the device, ``hexgnn_per_*``), and the sampled
+states are rebuilt into ``Batch`` objects by the same observation kernel the env uses (``hexgnn_states_observe``) --
+sorted CSR, side to move and largest graph size attached, no host-side collation.
+
+The reference's buffer lives in the un-vendored submodule ``GN0/RainbowDQN/Rainbow`` (.gitmodules:1-4); only its flags
+are known (README.md:5,7: ``--buffer_size=260000 --burnin=20000 --prioritized_er=True --prioritized_er_beta0=0.6
+--n_step=2``).  PARITY UNPINNED: this class follows the published algorithm (oracle/replay_ref.py) and is checked
+against that oracle; method names follow the upstream buffer (``put`` / ``sample`` / ``update_priorities``).
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .data import Batch
+
+
+def _pow2_at_least(n: int) -> int:
+    p = 1
+    while p < n:
+        p *= 2
+    return p
+
+
+class GraphReplayBuffer:
+    """Ring of ``capacity`` transitions ``(state, action, reward, next_state, done)`` for one side (the loop keeps one
+    buffer for maker and one for breaker transitions, multi_env_manager.py:139)."""
+
+    def __init__(self, capacity: int, hex_size: int, prioritized: bool = True, alpha: float = 0.5, eps: float = 1e-6,
+                 burnin: int = 0, device="cuda"):
+        self.capacity, self.hex_size = int(capacity), int(hex_size)
+        self.prioritized, self.alpha, self.eps, self.burnin = prioritized, float(alpha), float(eps), int(burnin)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.HexGnnError("GraphReplayBuffer lives in HBM (no CPU fallback)")
+        nv = hex_size * hex_size + 2
+        self.nv, self.words = nv, (nv + 63) // 64
+        dev, C = self.device, self.capacity
+        z = lambda *shape, dtype: torch.zeros(shape, dtype=dtype, device=dev)
+        # states and next states share one array pair: slot i = state of transition i, slot C + i = its next state
+        self.adj = z(2 * C, nv, self.words, dtype=torch.int64)
+        self.alive = z(2 * C, nv, dtype=torch.uint8)
+        self.side = z(2 * C, dtype=torch.uint8)
+        self.action = z(C, dtype=torch.long)
+        self.reward = z(C, dtype=torch.float32)
+        self.done = z(C, dtype=torch.bool)
+        self.n_nodes = np.zeros(2 * C, dtype=np.int64)      # host copies of the graph sizes (known when stored)
+        self.n_edges = np.zeros(2 * C, dtype=np.int64)
+        self.pos, self.size = 0, 0
+        self.cap2 = _pow2_at_least(C)
+        self.sum_tree = torch.empty(2 * self.cap2, dtype=torch.float64, device=dev)
+        self.min_tree = torch.empty(2 * self.cap2, dtype=torch.float64, device=dev)
+        _lib.check(_lib.lib().hexgnn_per_init(self.cap2, self.sum_tree.data_ptr(), self.min_tree.data_ptr(), ops._stream()),
+                   "hexgnn_per_init")
+        self.max_priority = torch.ones((), dtype=torch.float64, device=dev)
+
+    def __len__(self):
+        return self.size
+
+    @property
+    def burnedin(self) -> bool:
+        return self.size >= self.burnin
+
+    # ---- insertion ---------------------------------------------------------------------------------------
+    @staticmethod
+    def _source(d):
+        src = getattr(d, "_hex_src", None)
+        if src is None:
+            raise ValueError("GraphReplayBuffer stores states observed by gnn_hex_amd.Env_manager (they carry the "
+                             "board snapshot); got a Data object without one")
+        return src
+
+    def _store_states(self, datas, slots: np.ndarray):
+        groups = {}
+        for d, slot in zip(datas, slots):
+            obs, i = self._source(d)
+            g = groups.setdefault(id(obs), (obs, [], [], []))
+            g[1].append(i)
+            g[2].append(int(slot))
+            hint = getattr(d.x, "_hex_is_maker", None)
+            g[3].append(int(obs.is_maker if hint is None else hint))
+            self.n_nodes[slot] = obs.node_off[i + 1] - obs.node_off[i]
+            self.n_edges[slot] = obs.edge_off[i + 1] - obs.edge_off[i]
+        dev = self.device
+        for obs, idx, slot, side in groups.values():
+            it = torch.as_tensor(idx, dtype=torch.long, device=dev)
+            st = torch.as_tensor(slot, dtype=torch.long, device=dev)
+            snap_adj, snap_alive = obs.snapshot()
+            self.adj[st] = snap_adj[it]
+            self.alive[st] = snap_alive[it]
+            self.side[st] = torch.as_tensor(side, dtype=torch.uint8, device=dev)
+
+    def put(self, transitions: List[tuple]) -> None:
+        """Append transitions ``(state, action, reward, next_state, done)`` as returned by
+        ``Env_manager.get_transitions``; new entries get the running maximum priority."""
+        k = len(transitions)
+        if k == 0:
+            return
+        if k > self.capacity:
+            transitions = transitions[-self.capacity:]
+            k = self.capacity
+        C = self.capacity
+        slots = (self.pos + np.arange(k)) % C
+        self._store_states([t[0] for t in transitions], slots)
+        self._store_states([t[3] for t in transitions], slots + C)
+        dev = self.device
+        st = torch.as_tensor(slots, dtype=torch.long, device=dev)
+        self.action[st] = torch.as_tensor([int(t[1]) for t in transitions], dtype=torch.long, device=dev)
+        self.reward[st] = torch.as_tensor([float(t[2]) for t in transitions], dtype=torch.float32, device=dev)
+        self.done[st] = torch.as_tensor([bool(t[4]) for t in transitions], dtype=torch.bool, device=dev)
+        self.pos = int((self.pos + k) % C)
+        self.size = min(C, self.size + k)
+        if self.prioritized:
+            pa = (self.max_priority ** self.alpha).expand(k).contiguous()
+            self._tree_update(st.to(torch.int32), pa)
+
+    def _tree_update(self, idx32: torch.Tensor, prio_alpha: torch.Tensor):
+        _lib.check(_lib.lib().hexgnn_per_update(self.cap2, int(idx32.numel()), idx32.data_ptr(), prio_alpha.data_ptr(),
+                                                self.sum_tree.data_ptr(), self.min_tree.data_ptr(), ops._stream()),
+                   "hexgnn_per_update")
+
+    # ---- sampling ----------------------------------------------------------------------------------------
+    def _build_batch(self, slots_dev: torch.Tensor, slots_host: np.ndarray) -> Batch:
+        L = _lib.lib()
+        dev = self.device
+        k = len(slots_host)
+        node_off = np.zeros(k + 1, dtype=np.int64)
+        edge_off = np.zeros(k + 1, dtype=np.int64)
+        np.cumsum(self.n_nodes[slots_host], out=node_off[1:])
+        np.cumsum(self.n_edges[slots_host], out=edge_off[1:])
+        N, E = int(node_off[-1]), int(edge_off[-1])
+        offs = torch.from_numpy(np.concatenate([node_off, edge_off]).astype(np.int32)).to(dev, non_blocking=True)
+        x = torch.empty((N, 3), dtype=torch.float32, device=dev)
+        backmap = torch.empty(N, dtype=torch.long, device=dev)
+        batch_vec = torch.empty(N, dtype=torch.long, device=dev)
+        edge_local = torch.empty((2, max(E, 1)), dtype=torch.long, device=dev)
+        edge_global = torch.empty((2, max(E, 1)), dtype=torch.long, device=dev)
+        rowptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+        invdeg = torch.empty(max(N, 1), dtype=torch.float32, device=dev)
+        idx32 = slots_dev.to(torch.int32)
+        _lib.check(L.hexgnn_states_observe(self.hex_size, k, self.adj.data_ptr(), self.alive.data_ptr(),
+                                           self.side.data_ptr(), idx32.data_ptr(), offs.data_ptr(),
+                                           offs[k + 1:].data_ptr(), E, x.data_ptr(), backmap.data_ptr(),
+                                           edge_local.data_ptr(), edge_global.data_ptr(), rowptr.data_ptr(),
+                                           col.data_ptr(), invdeg.data_ptr(), batch_vec.data_ptr(), ops._stream()),
+                   "hexgnn_states_observe")
+        b = Batch()
+        b.x, b.edge_index, b.batch = x, edge_global[:, :E], batch_vec
+        b.ptr = torch.from_numpy(node_off).to(dev, non_blocking=True)
+        b._num_graphs = k
+        b.x._hex_max_nodes = int(self.n_nodes[slots_host].max()) if k else 0
+        b.edge_index._hex_csr = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
+        return b
+
+    def sample(self, batch_size: int, beta: Optional[float] = None, generator: Optional[torch.Generator] = None):
+        """Returns ``(indices, weights, state, next_state, action, reward, done)`` (weights all one when the buffer is
+        not prioritized), states as device ``Batch`` objects.  One device->host copy of the sampled indices is needed
+        to size the batches (the graph sizes live on the host)."""
+        if self.size == 0:
+            raise ValueError("empty buffer")
+        dev = self.device
+        if self.prioritized:
+            u = torch.rand(batch_size, dtype=torch.float64, device=dev, generator=generator)
+            idx = torch.empty(batch_size, dtype=torch.int32, device=dev)
+            w = torch.empty(batch_size, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().hexgnn_per_sample(self.cap2, self.size, batch_size, float(beta if beta is not None else 0.4),
+                                                    u.data_ptr(), self.sum_tree.data_ptr(), self.min_tree.data_ptr(),
+                                                    idx.data_ptr(), w.data_ptr(), ops._stream()), "hexgnn_per_sample")
+            idx = idx.long()
+        else:
+            idx = torch.randint(0, self.size, (batch_size,), device=dev, generator=generator)
+            w = torch.ones(batch_size, dtype=torch.float32, device=dev)
+        host = idx.cpu().numpy()
+        state = self._build_batch(idx, host)
+        nxt = self._build_batch(idx + self.capacity, host + self.capacity)
+        # all stored states of one buffer share the mover's side (maker / breaker buffers are separate)
+        side = bool(self.side[int(host[0])].item()) if batch_size else True
+        state.x._hex_is_maker = side
+        nxt.x._hex_is_maker = bool(self.side[int(host[0]) + self.capacity].item())
+        return idx, w, state, nxt, self.action[idx], self.reward[idx], self.done[idx]
+
+    def update_priorities(self, indices: torch.Tensor, td_errors: torch.Tensor) -> None:
+        if not self.prioritized:
+            return
+        p = td_errors.detach().abs().to(torch.float64).flatten() + self.eps
+        self.max_priority = torch.maximum(self.max_priority, p.max())
+        self._tree_update(indices.to(device=self.device, dtype=torch.int32).contiguous(), (p ** self.alpha).contiguous())

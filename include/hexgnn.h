@@ -192,6 +192,28 @@ int hexgnn_env_observe(hexgnn_env* env, const int* node_off, const int* edge_off
 int hexgnn_env_export(hexgnn_env* env, uint64_t* adj, uint8_t* alive, int* maker_turn, int* total_moves,
                       int16_t* resp_maker, int16_t* resp_breaker, hexgnn_stream_t stream);
 
+/* Same observation, built from ANY array of board states (the replay ring) for the k states listed in `index`
+ * (NULL = the first k): adj [num_states][nv][words] u64, alive [num_states][nv] u8, side [num_states] u8 (1 = maker
+ * to move).  Replaces re-collating stored torch_geometric Data objects with Batch.from_data_list in the (absent)
+ * replay buffer's sample(). */
+int hexgnn_states_observe(int hex_size, int k, const uint64_t* adj, const uint8_t* alive, const uint8_t* side,
+                          const int* index, const int* node_off, const int* edge_off, int64_t e_total, float* x,
+                          int64_t* backmap, int64_t* edge_local, int64_t* edge_global, int* rowptr, int* col,
+                          float* invdeg, int64_t* batch_vec, hexgnn_stream_t stream);
+
+/* ---- prioritized replay sampler (RainbowDQN --prioritized_er=True, README.md:5,7; the buffer itself is in the
+ *      un-vendored submodule GN0/RainbowDQN/Rainbow, .gitmodules:1-4 -- PARITY UNPINNED, see replay.hip).
+ *      Trees: fp64 arrays of 2*capacity entries (capacity a power of two), node 1 = root, leaves [capacity, 2*capacity).
+ *      hexgnn_per_update writes prio_alpha[i] (= priority^alpha, computed by the caller) to leaf idx[i] of both trees and
+ *      rebuilds the ancestors.  hexgnn_per_sample: stratified proportional sampling with the caller's uniforms u[b] in
+ *      [0,1): out_idx[i] = prefix-sum search of (i + u[i]) * total / b; out_w[i] = importance weight normalised by the
+ *      largest possible weight (size = number of valid leaves). ---------------------------------------------------- */
+int hexgnn_per_init(int capacity_pow2, double* sum_tree, double* min_tree, hexgnn_stream_t stream);
+int hexgnn_per_update(int capacity_pow2, int k, const int* idx, const double* prio_alpha, double* sum_tree,
+                      double* min_tree, hexgnn_stream_t stream);
+int hexgnn_per_sample(int capacity_pow2, int size, int b, double beta, const double* u, const double* sum_tree,
+                      const double* min_tree, int* out_idx, float* out_w, hexgnn_stream_t stream);
+
 /* ---- in-library kernel timing: HIP events recorded on the launch stream around every launch of ONE
  *      kernel class (bench.py's live roofline measurement; torch.cuda.Event would only see torch's current
  *      stream and whole calls).  Not for use under graph capture. --------------------------------------- */

@@ -1,0 +1,130 @@
+"""GPU: device-resident replay -- tree maintenance and stratified sampling bit-exact against oracle/replay_ref.py,
+sampled batches identical to collating the stored observations, end-to-end with Env_manager.get_transitions."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_per_trees_and_sampling_match_oracle():
+    from gnn_hex_amd import _lib, ops
+    from oracle.replay_ref import SegmentTreePER
+    L = _lib.lib()
+    cap = 64
+    st = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+    mt = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+    _lib.check(L.hexgnn_per_init(cap, st.data_ptr(), mt.data_ptr(), ops._stream()))
+    ref = SegmentTreePER(cap)
+    rng = np.random.default_rng(0)
+    size = 0
+    for rnd in range(6):
+        k = 17
+        idx = rng.choice(50, k, replace=False).astype(np.int32)
+        pa = rng.random(k) ** 0.5 + 1e-3
+        ref.update(idx, pa)
+        size = max(size, int(idx.max()) + 1)
+        di, dp = torch.from_numpy(idx).cuda(), torch.from_numpy(pa).cuda()
+        _lib.check(L.hexgnn_per_update(cap, k, di.data_ptr(), dp.data_ptr(), st.data_ptr(), mt.data_ptr(), ops._stream()))
+        torch.cuda.synchronize()
+        assert np.array_equal(st.cpu().numpy()[1:], ref.sum[1:])          # fp64 sums in the same order: bit-exact
+        fin = np.isfinite(ref.min)
+        assert np.array_equal(mt.cpu().numpy()[fin], ref.min[fin])
+    # every leaf < size must hold a priority for the weights to be defined: fill the gaps
+    missing = np.array([i for i in range(size) if ref.sum[cap + i] == 0], dtype=np.int32)
+    if len(missing):
+        pa = np.full(len(missing), 0.25)
+        ref.update(missing, pa)
+        dm, dpa = torch.from_numpy(missing).cuda(), torch.from_numpy(pa).cuda()     # keep alive until the launch
+        _lib.check(L.hexgnn_per_update(cap, len(missing), dm.data_ptr(), dpa.data_ptr(), st.data_ptr(), mt.data_ptr(),
+                                       ops._stream()))
+        torch.cuda.synchronize()
+    for b, beta in ((32, 0.6), (7, 0.4), (64, 1.0)):
+        u = rng.random(b)
+        ri, rw = ref.sample(u, size, beta)
+        oi = torch.empty(b, dtype=torch.int32, device="cuda")
+        ow = torch.empty(b, dtype=torch.float32, device="cuda")
+        du = torch.from_numpy(u).cuda()
+        _lib.check(L.hexgnn_per_sample(cap, size, b, beta, du.data_ptr(), st.data_ptr(), mt.data_ptr(), oi.data_ptr(),
+                                       ow.data_ptr(), ops._stream()))
+        assert np.array_equal(oi.cpu().numpy(), ri)
+        assert np.allclose(ow.cpu().numpy(), rw, rtol=1e-6, atol=0)
+
+
+def _play(mgr, steps, rng):
+    obs0 = mgr.reset()
+    states, actions, rewards, dones, expl = [], [], [], [], []
+    obs = obs0
+    for _ in range(steps):
+        acts_rank = [int(rng.integers(2, obs.node_off[i + 1] - obs.node_off[i])) for i in range(mgr.num_envs)]
+        obs2, r, d, _ = mgr.step(mgr.validate_actions(obs, acts_rank))
+        states.append(obs2); actions.append(acts_rank); rewards.append(r); dones.append(d)
+        expl.append(np.zeros(mgr.num_envs, dtype=bool))
+        obs = obs2
+    return obs0, states, actions, rewards, dones, expl
+
+
+def test_replay_round_trip_with_env_transitions():
+    from gnn_hex_amd.data import Batch
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    from gnn_hex_amd.replay import GraphReplayBuffer
+    rng = np.random.default_rng(3)
+    mgr = Env_manager(12, 5, gamma=0.97, n_steps=[2])
+    obs0, states, actions, rewards, dones, expl = _play(mgr, 14, rng)
+    # keep plain copies of what the transitions look like before the buffer sees them
+    maker, breaker = mgr.get_transitions(obs0, states, actions, rewards, dones, expl)
+    assert len(maker) > 10 and len(breaker) > 10
+    buf = GraphReplayBuffer(64, 5, prioritized=True, alpha=0.5)
+    buf.put(maker)
+    assert len(buf) == min(64, len(maker))
+    kept = maker[-64:] if len(maker) > 64 else maker
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    idx, w, s, s2, a, r, d = buf.sample(16, beta=0.6, generator=gen)
+    assert torch.all(w == 1.0)                      # all priorities equal so far
+    ih = idx.cpu().tolist()
+    ref_s = Batch.from_data_list([kept[i][0] for i in ih])
+    ref_s2 = Batch.from_data_list([kept[i][3] for i in ih])
+    for got, want in ((s, ref_s), (s2, ref_s2)):
+        assert torch.equal(got.x, want.x) and torch.equal(got.edge_index, want.edge_index)
+        assert torch.equal(got.ptr, want.ptr) and torch.equal(got.batch, want.batch)
+    assert a.cpu().tolist() == [int(kept[i][1]) for i in ih]
+    assert np.allclose(r.cpu().numpy(), [kept[i][2] for i in ih])
+    assert d.cpu().tolist() == [bool(kept[i][4]) for i in ih]
+    assert s.x._hex_is_maker is True and s2.x._hex_is_maker is True
+    # terminal transitions point at the start position
+    for i in ih:
+        if kept[i][4]:
+            j = ih.index(i)
+            assert int(s2.ptr[j + 1] - s2.ptr[j]) == 27
+    # priorities: |td| = 50 -> p^alpha = sqrt(50 + eps) = 7.07 against 63 entries at 1: drawn with probability
+    # 7.07 / 70.07 = 10 %, importance weight (p/p_min)^-beta = 7.07^-0.6 = 0.309
+    buf.update_priorities(idx[:1], torch.tensor([50.0], device="cuda"))
+    idx2, w2, *_ = buf.sample(64, beta=0.6, generator=gen)
+    top = int(idx[0])
+    frac = (idx2 == top).float().mean().item()
+    assert 0.07 < frac < 0.15
+    assert abs(float(w2[idx2 == top][0]) - 50.000001 ** (-0.3)) < 1e-4 and float(w2[idx2 != top][0]) == 1.0
+    # wrap-around keeps the newest transitions
+    buf.put(breaker)
+    assert len(buf) == 64
+
+
+def test_sampled_batch_drives_the_model():
+    from helpers import make_pair
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    from gnn_hex_amd.replay import GraphReplayBuffer
+    rng = np.random.default_rng(5)
+    mgr = Env_manager(8, 7, gamma=0.97, n_steps=[1])
+    obs0, states, actions, rewards, dones, expl = _play(mgr, 8, rng)
+    maker, _ = mgr.get_transitions(obs0, states, actions, rewards, dones, expl)
+    buf = GraphReplayBuffer(128, 7, prioritized=False)
+    buf.put(maker)
+    hip, ref = make_pair(4, 35, seed=4)
+    idx, w, s, s2, a, r, d = buf.sample(8)
+    q = hip.simple_forward(s)
+    q_ref = ref(s.x.cpu(), s.edge_index.cpu(), s.batch.cpu(), s.ptr.cpu())
+    assert (q.detach().cpu() - q_ref.detach()).abs().max() < 1e-4
+    qa = q[s.ptr[:-1] + a]                             # Q(s, a): action = node rank inside its graph
+    loss = ((qa - r) ** 2 * w).mean()
+    loss.backward()
+    assert all(p.grad is not None for k, p in hip.named_parameters() if k.startswith("gnn"))
