@@ -306,11 +306,60 @@ int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const 
     return HEXGNN_OK;
 }
 
+
+// ---- acting: per-graph epsilon-greedy / argmax over the non-terminal nodes, mapped to vertex ids ----------------------
+// One wave per graph.  Greedy = first node attaining the maximum of q[gptr[g]+2 : gptr[g+1]] (torch.argmax tie rule;
+// GN0/RainbowDQN/evaluate_elo.py:253-266); with u given, env g explores when u[2g] < eps and then plays node
+// 2 + floor(u[2g+1] * (n_g - 2)).  Outputs the node rank inside its graph, the vertex id (backmap, what
+// Env_manager.validate_actions returns, multi_env_manager.py:62-64) and the exploratory flag.
+__global__ __launch_bounds__(64) void select_actions_kernel(int b, const int* __restrict__ gptr, const float* __restrict__ q,
+                                                          const int64_t* __restrict__ backmap, float eps,
+                                                          const float* __restrict__ u, int* __restrict__ act_vertex,
+                                                          int* __restrict__ act_rank, unsigned char* __restrict__ expl) {
+    const int g = blockIdx.x, lane = threadIdx.x;
+    const int r0 = gptr[g], r1 = gptr[g + 1];
+    float best = -INFINITY;
+    int arg = 0x7fffffff;
+    for (int i = r0 + 2 + lane; i < r1; i += 64) {
+        const float v = q[i];
+        if (v > best || (v == best && i < arg)) { best = v; arg = i; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off);
+        const int oa = __shfl_xor(arg, off);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) {
+        int rank = arg == 0x7fffffff ? -1 : arg - r0;      // -1: graph without a legal move
+        unsigned char ex = 0;
+        const int nact = r1 - r0 - 2;
+        if (u && nact > 0 && u[2 * g] < eps) {
+            int k = (int)(u[2 * g + 1] * (float)nact);
+            if (k >= nact) k = nact - 1;
+            rank = 2 + k;
+            ex = 1;
+        }
+        act_rank[g] = rank;
+        act_vertex[g] = rank >= 0 ? (int)backmap[r0 + rank] : -1;
+        if (expl) expl[g] = ex;
+    }
+}
+
 }  // namespace hexgnn
 
 using namespace hexgnn;
 
 extern "C" {
+
+int hexgnn_select_actions(int b, const int* gptr, const float* q, const int64_t* backmap, float eps, const float* u,
+                          int* action_vertex, int* action_rank, uint8_t* exploratory, hexgnn_stream_t stream_) {
+    if (b < 0 || (b > 0 && (!gptr || !q || !backmap || !action_vertex || !action_rank))) return HEXGNN_EINVAL;
+    if (b == 0) return HEXGNN_OK;
+    select_actions_kernel<<<b, 64, 0, (hipStream_t)stream_>>>(b, gptr, q, backmap, eps, u, action_vertex, action_rank,
+                                                              exploratory);
+    return check_launch();
+}
 
 size_t hexgnn_head_saved_bytes(int n, int b, int hidden) {
     if (n < 0 || b < 0 || padded_width(hidden) < 0) return 0;

@@ -226,6 +226,27 @@ class Env_manager:
             return states.backmap[base + idx].tolist()
         return [state.backmap[action].item() for state, action in zip(states, actions)]
 
+    def select_actions(self, q: torch.Tensor, states: "ObsList" = None, eps: float = 0.0, generator=None):
+        """Device-side acting: epsilon-greedy over each env's non-terminal nodes given the model output for the batched
+        observation (``Q`` or ``advantages_only`` values).  Returns ``(vertex_actions int32 [num_envs] on the device --
+        ready for ``step`` --, node ranks, exploratory flags)``; nothing is copied to the host."""
+        states = states if states is not None else self.last_obs
+        dev = self.device
+        k = len(states)
+        if states._ptr is None:
+            states._ptr = torch.tensor(states.node_off, dtype=torch.long, device=dev)
+        gptr = states._ptr.to(torch.int32)
+        qf = q.reshape(-1).float().contiguous()
+        vert = torch.empty(k, dtype=torch.int32, device=dev)
+        rank = torch.empty(k, dtype=torch.int32, device=dev)
+        expl = torch.empty(k, dtype=torch.uint8, device=dev)
+        u = torch.rand((k, 2), dtype=torch.float32, device=dev, generator=generator) if eps > 0 else None
+        _lib.check(_lib.lib().hexgnn_select_actions(k, gptr.data_ptr(), qf.data_ptr(), states.backmap.data_ptr(),
+                                                    float(eps), u.data_ptr() if u is not None else None, vert.data_ptr(),
+                                                    rank.data_ptr(), expl.data_ptr(), ops._stream()),
+                   "hexgnn_select_actions")
+        return vert, rank, expl.bool()
+
     def get_valid_actions(self) -> List[np.ndarray]:
         obs = self.last_obs if self.last_obs is not None else self.observe()
         bm = obs.backmap.cpu().numpy()

@@ -232,6 +232,14 @@ int hexgnn_profile_enable(int kernel_class); /* -1: off.  Clears earlier samples
 /* Waits for the recorded events; returns the number of launches and their summed duration. */
 int hexgnn_profile_read(int* launches, float* total_ms);
 
+/* ---- acting: epsilon-greedy action per graph straight from the Q / advantage vector (replaces the per-graph python
+ *      argmax over action_values[ptr[g]+2 : ptr[g+1]] of GN0/RainbowDQN/evaluate_elo.py:253-266 and the backmap lookup
+ *      of Env_manager.validate_actions, graph_game/multi_env_manager.py:62-64).  u: [b][2] uniforms in [0,1) or NULL for
+ *      pure greedy.  action_vertex feeds hexgnn_env_step without leaving the device. ---------------------------------- */
+int hexgnn_select_actions(int b, const int* gptr, const float* q, const int64_t* backmap, float eps, const float* u,
+                          int* action_vertex /*[b]*/, int* action_rank /*[b]*/, uint8_t* exploratory /*[b] or NULL*/,
+                          hexgnn_stream_t stream);
+
 /* ---- layout helpers (host tensors <-> padded layout) ---------------------------------------- */
 /* dst[n][HP] <- src[n][hidden] (row stride src_stride floats), pad columns zeroed; and back. */
 int hexgnn_pad_rows(int n, int hidden, const float* src, int src_stride, float* dst, hexgnn_stream_t stream);

@@ -148,3 +148,31 @@ def test_env_to_model_closed_loop(hexref):
         ptr = b.ptr.tolist()
         acts = [int(torch.argmax(q[ptr[g] + 2:ptr[g + 1]])) + 2 for g in range(16)]   # evaluate_elo.py:253-266
         obs, rew, done, infos = mgr.step(mgr.validate_actions(obs, acts))
+
+
+def test_select_actions_greedy_and_exploratory():
+    """hexgnn_select_actions vs the reference's per-graph torch.argmax over values[ptr[g]+2 : ptr[g+1]] + backmap."""
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    mgr = Env_manager(20, 7)
+    obs = mgr.reset()
+    rng = np.random.default_rng(2)
+    for _ in range(5):
+        obs, *_ = mgr.step([int(v[rng.integers(len(v))]) for v in mgr.get_valid_actions()])
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    q = torch.randn(obs.x.shape[0], device="cuda", generator=gen)
+    q[obs.node_off[3] + 5] = q[obs.node_off[3] + 9] = 100.0            # a tie: the first index wins
+    vert, rank, expl = mgr.select_actions(q, obs, eps=0.0)
+    bm = obs.backmap.cpu()
+    for g in range(20):
+        n0, n1 = obs.node_off[g], obs.node_off[g + 1]
+        want = int(torch.argmax(q[n0 + 2:n1])) + 2
+        assert int(rank[g]) == want and int(vert[g]) == int(bm[n0 + want])
+    assert int(rank[3]) == 5 and not expl.any()
+    assert vert.tolist() == mgr.validate_actions(obs, rank.tolist())
+    # eps = 1: every env explores, uniformly over its legal nodes, and the move is legal
+    vert, rank, expl = mgr.select_actions(q, obs, eps=1.0, generator=gen)
+    assert expl.all()
+    for g in range(20):
+        assert 2 <= int(rank[g]) < obs.node_off[g + 1] - obs.node_off[g]
+    obs2, rew, done, infos = mgr.step(vert)                              # device actions go straight into the step
+    assert len(obs2) == 20
