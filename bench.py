@@ -54,6 +54,10 @@ def main():
     ap.add_argument("--data", default="D0", choices=["D0", "D1"])
     ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
                     help="contraction arithmetic of the fused kernels: exact fp32 MFMA (default) or split bf16x3")
+    ap.add_argument("--mode", default="train", choices=["train", "selfplay"],
+                    help="train: the BASELINE metric (default).  selfplay: closed device loop env -> Q-network -> "
+                         "epsilon-greedy -> env step, reports frames/s (secondary metric, SURVEY 8d)")
+    ap.add_argument("--envs", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -75,6 +79,8 @@ def main():
     hexops.set_math(args.math)
 
     num_layers, hidden, sizes_fn, label = CONFIGS[args.config]
+    if args.mode == "selfplay":
+        return selfplay(args, num_layers, hidden, label, dev)
     B = args.batch
     hip, ref = make_pair(num_layers, hidden, seed=0, device=dev)   # identical replicas on every rank
     sync = GradSync(hip.parameters())
@@ -202,6 +208,42 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def selfplay(args, num_layers, hidden, label, dev):
+    """Closed device loop on one GPU: observation (HIP builder) -> Q-network forward (advantages only) -> epsilon-greedy
+    (eps 0.05) -> env step with dead/captured removal and auto reset.  One step = one move in every env."""
+    from helpers import make_pair
+    from gnn_hex_amd.data import Batch
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    size = 11 if args.config != "S256" else 7
+    hip, _ = make_pair(num_layers, hidden, seed=0, device=dev)
+    mgr = Env_manager(args.envs, size, gamma=0.97, device=dev)
+    obs = mgr.reset()
+
+    def one(obs):
+        b = Batch.from_data_list(obs)
+        with torch.no_grad():
+            adv = hip(b.x, b.edge_index, b.batch, b.ptr, advantages_only=True)
+        vert, _, _ = mgr.select_actions(adv, obs, eps=0.05)
+        return mgr.step(vert)[0]
+
+    for _ in range(args.warmup):
+        obs = one(obs)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        obs = one(obs)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    out = {"metric": "self-play frames/sec (env step + observation + Q forward + action selection)",
+           "value": args.envs * args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
+           "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+           "vs_baseline": None, "dtype": "f32", "data": "synthetic (self-generated games)",
+           "config": {"workload": "%s acting, Hex-%d, %d parallel envs" % (label.split(" batch")[0], size, args.envs),
+                      "parallelism": "dp1"}}
+    print(json.dumps(out))
     return out
 
 
