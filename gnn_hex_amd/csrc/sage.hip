@@ -200,6 +200,41 @@ __global__ __launch_bounds__(256) void sage_first_fwd_kernel(
     }
 }
 
+
+// acc[c] += rows[j][chunk c] over the CSR row [e0,e1): two neighbours per iteration, all 2*NT 16-byte loads issued
+// before the first add (the column ids of the next pair are fetched ahead); ascending neighbour order is kept.
+template <int NT>
+__device__ __forceinline__ void gather_rows_global(const float* __restrict__ rows, const int* __restrict__ col, int e0,
+                                                   int e1, int g, f32x4 (&acc)[NT]) {
+    constexpr int HP = 16 * NT;
+    int e = e0;
+    while (e + 1 < e1) {
+        const int j0 = col[e], j1 = col[e + 1];
+        e += 2;
+        const f32x4* x0 = reinterpret_cast<const f32x4*>(rows + (size_t)j0 * HP) + g;
+        const f32x4* x1 = reinterpret_cast<const f32x4*>(rows + (size_t)j1 * HP) + g;
+        f32x4 t0[NT], t1[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] += t0[c];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] += t1[c];
+    }
+    if (e < e1) {
+        const f32x4* x0 = reinterpret_cast<const f32x4*>(rows + (size_t)col[e] * HP) + g;
+        f32x4 t0[NT];
+#pragma unroll
+        for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) acc[c] += t0[c];
+    }
+}
+
 // ---- hidden layer forward ----------------------------------------------------------------------------
 template <int NT>
 __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
@@ -221,12 +256,7 @@ __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * HP) + g;
 #pragma unroll
         for (int c = 0; c < NT; ++c) xs[c] = xr[4 * c];
-        const int e0 = rowptr[row], e1 = rowptr[row + 1];
-        for (int e = e0; e < e1; ++e) {
-            const f32x4* xj = reinterpret_cast<const f32x4*>(x + (size_t)col[e] * HP) + g;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
-        }
+        gather_rows_global<NT>(x, col, rowptr[row], rowptr[row + 1], g, ag);
         const float sc = invdeg[row];
 #pragma unroll
         for (int c = 0; c < NT; ++c) ag[c] *= sc;
@@ -300,14 +330,7 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
         const f32x4* dr = reinterpret_cast<const f32x4*>(dxs_in + (size_t)row * HP) + g;
 #pragma unroll
         for (int c = 0; c < NT; ++c) gx[c] = dr[4 * c];
-        if (dagg_in) {
-            const int e0 = rowptr_t[row], e1 = rowptr_t[row + 1];
-            for (int e = e0; e < e1; ++e) {
-                const f32x4* dj = reinterpret_cast<const f32x4*>(dagg_in + (size_t)col_t[e] * HP) + g;
-#pragma unroll
-                for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
-            }
-        }
+        if (dagg_in) gather_rows_global<NT>(dagg_in, col_t, rowptr_t[row], rowptr_t[row + 1], g, gx);
         const f32x4* yr = reinterpret_cast<const f32x4*>(y + (size_t)row * HP) + g;
         f32x4* go = reinterpret_cast<f32x4*>(g_out + (size_t)row * HP) + g;
 #pragma unroll
