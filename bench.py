@@ -58,6 +58,9 @@ def main():
                     help="train: the BASELINE metric (default).  selfplay: closed device loop env -> Q-network -> "
                          "epsilon-greedy -> env step, reports frames/s (secondary metric, SURVEY 8d)")
     ap.add_argument("--envs", type=int, default=128)
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path "
+                         "on a box with fewer GPUs than ranks)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -66,11 +69,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    if args.backend == "nccl" and world > ndev:
+        raise SystemExit("%d ranks but %d GPUs (RCCL needs one GPU per rank)" % (world, ndev))
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from helpers import batch_tensors, make_pair, sel_and_targets
     from gnn_hex_amd import _lib
