@@ -74,6 +74,20 @@ class ObsList:
         return b
 
 
+class TransitionBlock:
+    """Array form of a list of transitions ``(s, a, r, s', done)`` of ONE side: states are referenced as
+    ``(index into obs_list, env)`` instead of being materialised as ``Data`` objects; ``next_step == -1`` means the
+    start position (terminal transitions, multi_env_manager.py:150-158).  Consumed by ``GraphReplayBuffer.put_block``."""
+
+    def __init__(self, obs_list, start_obs, maker_side, src_step, env, action, reward, next_step, done):
+        self.obs_list, self.start_obs, self.maker_side = obs_list, start_obs, maker_side
+        self.src_step, self.env, self.action = src_step, env, action
+        self.reward, self.next_step, self.done = reward, next_step, done
+
+    def __len__(self):
+        return int(self.env.shape[0])
+
+
 class _EnvView:
     """Read-only stand-in for the per-env ``Hex_game`` objects of the reference's ``Env_manager.envs``."""
 
@@ -315,6 +329,65 @@ class Env_manager:
                                        rm.data_ptr(), rb.data_ptr(), ops._stream()), "hexgnn_env_export")
         return dict(adj=adj.cpu().numpy().view(np.uint64), alive=alive.cpu().numpy(), maker_turn=mt.cpu().numpy(),
                     total_moves=tm.cpu().numpy(), resp_maker=rm.cpu().numpy(), resp_breaker=rb.cpu().numpy())
+
+    # ---- transition assembly, array form (same semantics as get_transitions below, no per-transition objects) --
+    def assemble_transitions(self, starting_states, state_history: list, action_history: list, reward_history: list,
+                             done_history: list, exploratories_history: list):
+        """``get_transitions`` (multi_env_manager.py:113-165) vectorised over the envs: returns
+        ``(maker_block, breaker_block)`` of ``TransitionBlock`` whose entries appear in exactly the order the list
+        form emits them.  Histories may hold ``ObsList`` observations (states stay on the device as board snapshots)."""
+        sh = list(state_history)
+        sh.insert(0, starting_states)
+        T = len(action_history)
+        A = np.asarray([np.asarray(a, dtype=np.int64) for a in action_history]).reshape(T, -1)
+        R = np.asarray(reward_history, dtype=np.float64).reshape(T, -1)
+        D = np.asarray(done_history, dtype=bool).reshape(T, -1)
+        X = np.asarray(exploratories_history, dtype=bool).reshape(T, -1)
+        E = A.shape[1]
+        ks = np.arange(E)
+        out = {True: [], False: []}
+        for i in range(T):
+            start_state = sh[i]
+            maker_side = start_state.is_maker if isinstance(start_state, ObsList) else bool(start_state[0].x[0, 2] == 1)
+            for n_step in self.n_steps:
+                if not len(sh) > i + 2 * n_step:
+                    continue
+                w = 2 * n_step
+                jj = np.arange(w)
+                coef = ((-(jj % 2)) * 2 + 1) * (float(self.gamma) ** (jj // 2))          # sign * gamma^((j-i)//2)
+                r = R[i:i + w] * coef[:, None]
+                csum = np.cumsum(r, axis=0)                                                # reward through window step j
+                d = D[i:i + w]
+                first_done = np.where(d.any(0), d.argmax(0), w)                           # w = none
+                if self.prune_exploratories:
+                    x = X[i:i + w].copy()
+                    x[0] = False                                                           # only j > i prunes
+                    first_expl = np.where(x.any(0), x.argmax(0), w)
+                else:
+                    first_expl = np.full(E, w)
+                terminal = (first_done < w) & (first_done <= first_expl)
+                pruned = (first_expl < w) & (first_expl < first_done)
+                full = ~terminal & ~pruned
+                emit = terminal | full
+                jend = np.where(terminal, first_done, w - 1)
+                reward = csum[jend, ks]
+                nxt = np.where(terminal, -1, i + w)
+                sel = ks[emit]
+                out[maker_side].append((np.full(sel.shape, i), sel, A[i, sel], reward[sel], nxt[sel], terminal[sel]))
+        blocks = []
+        start_obs = None
+        for side in (True, False):
+            if out[side]:
+                cat = [np.concatenate(c) for c in zip(*out[side])]
+            else:
+                cat = [np.zeros(0, dtype=np.int64)] * 3 + [np.zeros(0)] + [np.zeros(0, dtype=np.int64), np.zeros(0, dtype=bool)]
+            if start_obs is None and len(cat[1]) and (cat[4] < 0).any():
+                start_obs = self._observe_handle(self._base, self._base_sizes, True)
+            blocks.append(TransitionBlock(sh, start_obs, side, *cat))
+        if start_obs is not None:
+            for b in blocks:
+                b.start_obs = start_obs
+        return blocks[0], blocks[1]
 
     # ---- transition assembly (host logic, multi_env_manager.py:113-165) ----------------------------------
     def get_transitions(self, starting_states, state_history: list, action_history: list, reward_history: list,

@@ -119,6 +119,50 @@ class GraphReplayBuffer:
             pa = (self.max_priority ** self.alpha).expand(k).contiguous()
             self._tree_update(st.to(torch.int32), pa)
 
+    def _store_indexed(self, obs_list, start_obs, steps: np.ndarray, envs: np.ndarray, slots: np.ndarray, side: bool):
+        """Copy board snapshots ``obs_list[steps[i]][envs[i]]`` (``steps[i] == -1``: the start position) into ring
+        slots; one batched device copy per distinct observation."""
+        dev = self.device
+        for st in np.unique(steps):
+            m = steps == st
+            obs = start_obs if st < 0 else obs_list[int(st)]
+            idx = np.zeros(int(m.sum()), dtype=np.int64) if st < 0 else envs[m]
+            sl = slots[m]
+            noff, eoff = np.asarray(obs.node_off), np.asarray(obs.edge_off)
+            self.n_nodes[sl] = noff[idx + 1] - noff[idx]
+            self.n_edges[sl] = eoff[idx + 1] - eoff[idx]
+            it = torch.from_numpy(idx).to(dev)
+            sd = torch.from_numpy(sl).to(dev)
+            snap_adj, snap_alive = obs.snapshot()
+            self.adj[sd] = snap_adj[it]
+            self.alive[sd] = snap_alive[it]
+        self.side[torch.from_numpy(slots).to(dev)] = 1 if side else 0
+
+    def put_block(self, block) -> None:
+        """Append a ``TransitionBlock`` from ``Env_manager.assemble_transitions`` (array form of ``put``)."""
+        k = len(block)
+        if k == 0:
+            return
+        C = self.capacity
+        src, env, act = block.src_step, block.env, block.action
+        rew, nxt, done = block.reward, block.next_step, block.done
+        if k > C:
+            src, env, act, rew, nxt, done = (v[-C:] for v in (src, env, act, rew, nxt, done))
+            k = C
+        slots = (self.pos + np.arange(k)) % C
+        self._store_indexed(block.obs_list, block.start_obs, src, env, slots, block.maker_side)
+        self._store_indexed(block.obs_list, block.start_obs, nxt, env, slots + C, block.maker_side)
+        dev = self.device
+        st = torch.from_numpy(slots).to(dev)
+        self.action[st] = torch.from_numpy(np.ascontiguousarray(act)).to(dev)
+        self.reward[st] = torch.from_numpy(np.ascontiguousarray(rew, dtype=np.float32)).to(dev)
+        self.done[st] = torch.from_numpy(np.ascontiguousarray(done)).to(dev)
+        self.pos = int((self.pos + k) % C)
+        self.size = min(C, self.size + k)
+        if self.prioritized:
+            pa = (self.max_priority ** self.alpha).expand(k).contiguous()
+            self._tree_update(st.to(torch.int32), pa)
+
     def _tree_update(self, idx32: torch.Tensor, prio_alpha: torch.Tensor):
         _lib.check(_lib.lib().hexgnn_per_update(self.cap2, int(idx32.numel()), idx32.data_ptr(), prio_alpha.data_ptr(),
                                                 self.sum_tree.data_ptr(), self.min_tree.data_ptr(), ops._stream()),

@@ -128,3 +128,33 @@ def test_sampled_batch_drives_the_model():
     loss = ((qa - r) ** 2 * w).mean()
     loss.backward()
     assert all(p.grad is not None for k, p in hip.named_parameters() if k.startswith("gnn"))
+
+
+@pytest.mark.parametrize("prune", [True, False])
+def test_vectorised_transition_assembly_equals_list_form(prune):
+    """assemble_transitions + put_block must leave the replay ring exactly as get_transitions + put does, including
+    exploratory pruning, terminal transitions pointing at the start position and multi-n-step ordering."""
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    from gnn_hex_amd.replay import GraphReplayBuffer
+    rng = np.random.default_rng(9)
+    mgr = Env_manager(10, 5, gamma=0.9, n_steps=[1, 2], prune_exploratories=prune)
+    obs0, states, actions, rewards, dones, expl = _play(mgr, 16, rng)
+    expl = [rng.random(10) < 0.2 for _ in range(16)]
+    mb, bb = mgr.assemble_transitions(obs0, states, actions, rewards, dones, expl)
+    maker, breaker = mgr.get_transitions(obs0, states, actions, rewards, dones, expl)
+    assert len(mb) == len(maker) and len(bb) == len(breaker) and len(mb) > 20
+    for block, lst in ((mb, maker), (bb, breaker)):
+        assert block.action.tolist() == [int(t[1]) for t in lst]
+        assert np.allclose(block.reward, [t[2] for t in lst])
+        assert block.done.tolist() == [bool(t[4]) for t in lst]
+        a, b = GraphReplayBuffer(512, 5, prioritized=False), GraphReplayBuffer(512, 5, prioritized=False)
+        a.put_block(block)
+        b.put(lst)
+        k = len(lst)
+        assert len(a) == len(b) == k
+        for name in ("adj", "alive", "side"):
+            va, vb = getattr(a, name), getattr(b, name)
+            assert torch.equal(va[:k], vb[:k]) and torch.equal(va[512:512 + k], vb[512:512 + k]), name
+        for name in ("action", "reward", "done"):
+            assert torch.equal(getattr(a, name)[:k], getattr(b, name)[:k]), name
+        assert np.array_equal(a.n_nodes, b.n_nodes) and np.array_equal(a.n_edges, b.n_edges)
