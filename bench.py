@@ -52,8 +52,8 @@ def main():
     ap.add_argument("--config", default="L256", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--data", default="D0", choices=["D0", "D1"])
-    ap.add_argument("--math", default="fp32", choices=["fp32", "bf16x3"],
-                    help="contraction arithmetic of the fused kernels: exact fp32 MFMA (default) or split bf16x3")
+    ap.add_argument("--math", default="fp32", choices=["fp32", "f16x3"],
+                    help="contraction arithmetic of the fused kernels: exact fp32 MFMA (default) or split f16x3")
     ap.add_argument("--mode", default="train", choices=["train", "selfplay"],
                     help="train: the BASELINE metric (default).  selfplay: closed device loop env -> Q-network -> "
                          "epsilon-greedy -> env step, reports frames/s (secondary metric, SURVEY 8d)")
@@ -205,7 +205,7 @@ def main():
             "metric": "board-graphs/sec fwd+bwd", "value": value, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.math == "fp32" else "f32 operands split into bf16 hi+lo (bf16x3 MFMA), f32 accumulate",
+            "dtype": "f32" if args.math == "fp32" else "f32 operands split into scaled f16 hi+lo (f16x3 MFMA, 22-bit products), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": "%s, %s board graphs, %d graphs per GPU (N=%d nodes, E=%d directed edges)"
                                    % (label, "start-position" if args.data == "D0" else "random-playout",

@@ -185,8 +185,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         mean_dq = sdq * inv_cnt;
         if (tid < H) { s_ax[tid] = amax[(size_t)g * H + tid]; s_an[tid] = amin[(size_t)g * H + tid]; }
         const float dV = mode == 0 ? sdq : d_out_v[g];
-        const float V = tanhf(vraw[g]);
-        const float dv = dV * (1.f - V * V);
+        const float dv = dV * sech2f(vraw[g]);
         if (tid == 0) dvr[g] = dv;
         if (tid < H2) {
             const float zz = z[(size_t)g * H2 + tid];
@@ -203,8 +202,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     }
     // per-row advantage gradient: thread per row
     for (int row = r0 + tid; row < r1; row += 256) {
-        const float t = tanhf(adv_raw[row]);
-        const float dar = (dq[row] - mean_dq) * 2.f * (1.f - t * t);
+        const float dar = (dq[row] - mean_dq) * 2.f * sech2f(adv_raw[row]);
         dadv[row] = dar;
         if (row - r0 < 1024) s_dar[row - r0] = dar;
     }

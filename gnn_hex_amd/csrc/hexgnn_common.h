@@ -43,4 +43,21 @@ __device__ __forceinline__ f32x4 mfma16x16x4(float a, float b, f32x4 acc) {
     return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
 }
 
+// Power-of-two scale for a block of values whose largest magnitude is m >= 0: m*s lies in [2^14, 2^15), so the fp16 hi
+// part never overflows and the lo parts of all but negligible elements stay normal (split-precision "f16x3" math).
+__device__ __forceinline__ void pow2_scale(const float m, float& s, float& inv) {
+    const unsigned e = __builtin_bit_cast(unsigned, m) >> 23;    // biased exponent
+    const bool ok = e >= 64u && e <= 190u;                       // 2^-63 <= m < 2^64; anything else stays unscaled
+    s = ok ? __builtin_bit_cast(float, (268u - e) << 23) : 1.f;
+    inv = ok ? __builtin_bit_cast(float, (e - 14u) << 23) : 1.f;
+}
+
+// d/dx tanh(x) = sech^2(x) = 4e/(1+e)^2 with e = exp(-2|x|): no cancellation, so saturated advantages / values keep
+// a few-ulp derivative (1 - tanh(x)^2 loses all relative accuracy as |tanh| -> 1).
+__device__ __forceinline__ float sech2f(float x) {
+    const float e = expf(-2.f * fabsf(x));
+    const float d = 1.f + e;
+    return 4.f * e / (d * d);
+}
+
 }  // namespace hexgnn

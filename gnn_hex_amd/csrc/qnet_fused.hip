@@ -34,10 +34,10 @@ namespace {
 struct QPlan {
     StackPlan sp;
     HeadSaved hs;
-    size_t head_saved_off, saved_total;
+    size_t head_saved_off, xmax_off, saved_total;
     BwdPlan bp;
     HeadWs hw;
-    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_total;
+    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_gmax_off, ws_total;
 };
 int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     int rc = make_plan(n, c_in, hidden, L, &q->sp);
@@ -45,7 +45,8 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     if (!q->sp.small_first || q->sp.nt > 7 || hidden < 2) return HEXGNN_EUNSUPPORTED;
     q->hs = head_saved_plan(n, b, hidden);
     q->head_saved_off = align_up(q->sp.saved_bytes, 256);
-    q->saved_total = q->head_saved_off + q->hs.total;
+    q->xmax_off = align_up(q->head_saved_off + q->hs.total, 256);     // per-layer maxima (math 1), kMaxLayers words
+    q->saved_total = q->xmax_off + sizeof(unsigned) * kMaxLayers;
     make_bwd_plan(n, q->sp, &q->bp);
     q->hw = head_ws_plan(n, b, hidden);
     const size_t slab = align_up(sizeof(float) * (size_t)n * q->sp.hp, 256);
@@ -54,6 +55,7 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     q->ws_part_off = off; off += align_up(sizeof(float) * (size_t)L * q->bp.S * q->sp.hp * (2 * q->sp.hp + 1), 256);
     q->ws_part0_off = off; off += align_up(sizeof(float) * (size_t)q->bp.S0 * q->sp.hp * 17, 256);
     q->ws_head_off = off; off += q->hw.total;
+    q->ws_gmax_off = align_up(off, 256); off = q->ws_gmax_off + sizeof(unsigned) * kMaxLayers;
     q->ws_total = off;
     return HEXGNN_OK;
 }
@@ -107,6 +109,11 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     a.amax = (int*)(hsv + qp.hs.amax_off); a.amin = (int*)(hsv + qp.hs.amin_off);
     a.z = (float*)(hsv + qp.hs.z_off); a.vraw = (float*)(hsv + qp.hs.v_off);
     a.q = q; a.out_v = out_v; a.status = status;
+    a.xmax = nullptr;
+    if (math == 1 && need_backward) {
+        a.xmax = (unsigned*)((char*)saved + qp.xmax_off);
+        (void)hipMemsetAsync(a.xmax, 0, sizeof(unsigned) * kMaxLayers, st);
+    }
     {
         KernelTimer kt(HEXGNN_K_QNET_FWD, st);
         rc = launch_qfwd_math(qp.sp.nt, math, a, st);
@@ -153,7 +160,7 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.n = n; a.b = b; a.H = hidden; a.L = total_layers; a.mode = mode; a.body_layers = body_layers;
     a.gptr = gptr; a.rowptr_t = rowptr_t; a.col_t = col_t; a.invdeg = invdeg;
     a.wpack = (const char*)wpack;
-    for (int l = 0; l < total_layers; ++l) a.bwd_off[l] = qp.sp.bwd_off[l];
+    for (int l = 0; l < total_layers; ++l) { a.bwd_off[l] = qp.sp.bwd_off[l]; a.bias_off[l] = qp.sp.bias_off[l]; }
     a.acts = acts; a.lin_w = lin_w; a.v0_w = v0_w; a.v1_w = v1_w;
     a.adv_raw = (const float*)(hsv + qp.hs.adv_off); a.amax = (const int*)(hsv + qp.hs.amax_off);
     a.amin = (const int*)(hsv + qp.hs.amin_off); a.z = (const float*)(hsv + qp.hs.z_off);
@@ -162,6 +169,11 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.dadv = (float*)(hws + qp.hw.dadv_off); a.dz = (float*)(hws + qp.hw.dz_off);
     a.dvr = (float*)(hws + qp.hw.dvr_off); a.lin_part = (float*)(hws + qp.hw.part_off);
     a.status = status;
+    a.gmax = nullptr;
+    if (math == 1) {
+        a.gmax = (unsigned*)(ws + qp.ws_gmax_off);
+        (void)hipMemsetAsync(a.gmax, 0, sizeof(unsigned) * kMaxLayers, st);
+    }
     if (b > 0 && n > 0) {
         KernelTimer kt(HEXGNN_K_QNET_BWD, st);
         rc = launch_qbwd_math(qp.sp.nt, math, a, st);
@@ -179,7 +191,7 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     }
     if (n > 0) {
         rc = launch_weight_grads(n, c_in, hidden, qp.sp, qp.bp, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part,
-                                 part0, st);
+                                 part0, st, math, (const unsigned*)(sv + qp.xmax_off), a.gmax);
         if (rc != HEXGNN_OK) return rc;
     }
     launch_head_param_grads(b, hidden, mode, a.dz, a.dvr, (const float*)(hsv + qp.hs.pooled_off),

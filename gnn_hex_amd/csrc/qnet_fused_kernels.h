@@ -30,12 +30,13 @@ struct QFwdArgs {
     const float* lin_w; const float* lin_b; const float* v0_w; const float* v0_b; const float* v1_w; const float* v1_b;
     float* adv_raw; float* pooled; int* amax; int* amin; float* z; float* vraw;
     float* q; float* out_v; int* status;
+    unsigned* xmax;   // [L] bit patterns of max |[agg|x]| per layer (math 1 + need_backward: feeds the f16 dW scales)
 };
 
 struct QBwdArgs {
     int n, b, H, L, mode, body_layers;
     const int* gptr; const int* rowptr_t; const int* col_t; const float* invdeg;
-    const char* wpack; size_t bwd_off[kMaxL];
+    const char* wpack; size_t bwd_off[kMaxL]; size_t bias_off[kMaxL];
     const float* acts;
     const float* lin_w; const float* v0_w; const float* v1_w;
     const float* adv_raw; const int* amax; const int* amin; const float* z; const float* vraw;
@@ -43,6 +44,7 @@ struct QBwdArgs {
     float* G; float* d_embeds;
     float* dadv; float* dz; float* dvr; float* lin_part;
     int* status;
+    unsigned* gmax;   // [L] bit patterns of max |G_l| per layer (math 1)
 };
 
 template <int NT> struct QLds {
@@ -53,14 +55,15 @@ template <int NT> struct QLds {
     static constexpr int off_x = 2 * kHalf * 16;
     static constexpr int off_rp = off_x + kRows * XS * 4;
     static constexpr int off_col = off_rp + 272;            // (kRows+2) u16, padded
-    static constexpr int col_cap = (kLdsBytes - off_col) < 8192 ? (kLdsBytes - off_col) : 8192;
+    static constexpr int col_cap = (kLdsBytes - 64 - off_col) < 8192 ? (kLdsBytes - 64 - off_col) : 8192;
+    static constexpr int off_max = off_col + col_cap;       // 8 per-wave maxima (math 1), 64 B
     // 16 KB of scratch (first-layer operands, head-tail reductions): aliases the weight halves when they are
     // large enough (NT >= 4), otherwise a region of its own (small widths leave plenty of LDS)
     static constexpr bool scr_alias = NT >= 4;
     static constexpr int scr_bytes = 16384;
-    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_col + col_cap;   // half B
-    static constexpr int off_scr_tail = scr_alias ? off_w : off_col + col_cap;
-    static constexpr int total = off_col + col_cap + (scr_alias ? 0 : scr_bytes);
+    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_max + 64;   // half B
+    static constexpr int off_scr_tail = scr_alias ? off_w : off_max + 64;
+    static constexpr int total = off_max + 64 + (scr_alias ? 0 : scr_bytes);
     static_assert(col_cap >= 1024 && total <= kLdsBytes, "LDS budget");
     static_assert(!scr_alias || kHalf * 16 >= scr_bytes, "scratch must fit one weight half");
 };
@@ -126,28 +129,48 @@ __device__ __forceinline__ void mfma_chunk(const f32x4* __restrict__ wfrag /* &w
 }
 
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// x = hi + lo (+ O(2^-16 |x|)) with hi, lo in bf16
-__device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, bf16x8& hi, bf16x8& lo) {
+// x*s = hi + lo (+ O(2^-22 |x s|)) with hi, lo in fp16; s is the row's power-of-two scale (exact)
+__device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, const float s, f16x8& hi, f16x8& lo) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)a[j]; hi[4 + j] = (__bf16)b[j]; }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { lo[j] = (__bf16)(a[j] - (float)hi[j]); lo[4 + j] = (__bf16)(b[j] - (float)hi[4 + j]); }
+    for (int j = 0; j < 4; ++j) {
+        const float va = a[j] * s, vb = b[j] * s;
+        hi[j] = (_Float16)va; hi[4 + j] = (_Float16)vb;
+        lo[j] = (_Float16)(va - (float)hi[j]); lo[4 + j] = (_Float16)(vb - (float)hi[4 + j]);
+    }
 }
-__device__ __forceinline__ void split_one(const f32x4 a, bf16x4& hi, bf16x4& lo) {
+__device__ __forceinline__ void split_one(const f32x4 a, const float s, f16x4& hi, f16x4& lo) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) { hi[j] = (__bf16)a[j]; lo[j] = (__bf16)(a[j] - (float)hi[j]); }
+    for (int j = 0; j < 4; ++j) { const float v = a[j] * s; hi[j] = (_Float16)v; lo[j] = (_Float16)(v - (float)hi[j]); }
+}
+
+__device__ __forceinline__ void row_scale(const float m, float& s, float& inv) { pow2_scale(m, s, inv); }
+template <int NT>
+__device__ __forceinline__ float frag_absmax(const f32x4 (&x)[NT], float m) {
+#pragma unroll
+    for (int c = 0; c < NT; ++c) m = fmaxf(fmaxf(m, fmaxf(fabsf(x[c][0]), fabsf(x[c][1]))), fmaxf(fabsf(x[c][2]), fabsf(x[c][3])));
+    return m;
+}
+__device__ __forceinline__ float row_max4(float m) {   // max over the 4 lanes (l, l^16, l^32, l^48) that share a row
+    m = fmaxf(m, __shfl_xor(m, 16));
+    return fmaxf(m, __shfl_xor(m, 32));
+}
+__device__ __forceinline__ float rows_max16(float m) {  // ... then over the wave's 16 rows
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
+    return m;
 }
 
 // One K-half of a layer: acc[t] += sum_c W(c,t)^T * x[c] over the NT feature chunks of this lane's row.
-//   MATH 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), weights packed as float4 fragments.
-//   MATH 1: split precision ("bf16x3"): W ~ Whi + Wlo, x ~ xhi + xlo in bf16, acc += Wlo*xhi + Whi*xlo + Whi*xhi on
-//           v_mfma_f32_16x16x32_bf16 (chunk pairs) / v_mfma_f32_16x16x16_bf16 (odd last chunk), fp32 accumulate.
+//   MATH 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), weights packed as float4 fragments; `scale` unused.
+//   MATH 1: split precision ("f16x3"): W s_W = Whi + Wlo, x s = xhi + xlo in fp16 (s = this row's power-of-two scale),
+//           acc += Wlo*xhi + Whi*xlo + Whi*xhi on v_mfma_f32_16x16x32_f16 (chunk pairs) / v_mfma_f32_16x16x16_f16
+//           (odd last chunk), fp32 accumulate; the caller multiplies by 1/(s s_W).
 template <int NT, int MATH>
 __device__ __forceinline__ void contract_half(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
-                                              f32x4 (&acc)[NT]) {
+                                              f32x4 (&acc)[NT], const float scale = 1.f) {
     if constexpr (MATH == 0) {
 #pragma unroll
         for (int c = 0; c < NT; ++c) mfma_chunk<NT>(whalf + (c * NT) * 64 + lane, x[c], acc);
@@ -155,29 +178,29 @@ __device__ __forceinline__ void contract_half(const f32x4* __restrict__ whalf, i
         const char* wb = reinterpret_cast<const char*>(whalf);
 #pragma unroll
         for (int p = 0; p < NT / 2; ++p) {
-            bf16x8 xh, xl;
-            split_pair(x[2 * p], x[2 * p + 1], xh, xl);
+            f16x8 xh, xl;
+            split_pair(x[2 * p], x[2 * p + 1], scale, xh, xl);
             const char* ub = wb + (2 * p) * NT * 1024 + lane * 16;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const bf16x8 wh = *reinterpret_cast<const bf16x8*>(ub + t * 2048);
-                const bf16x8 wl = *reinterpret_cast<const bf16x8*>(ub + t * 2048 + 1024);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, xh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, xh, acc[t], 0, 0, 0);
+                const f16x8 wh = *reinterpret_cast<const f16x8*>(ub + t * 2048);
+                const f16x8 wl = *reinterpret_cast<const f16x8*>(ub + t * 2048 + 1024);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[t], 0, 0, 0);
             }
         }
         if constexpr (NT & 1) {
-            bf16x4 xh, xl;
-            split_one(x[NT - 1], xh, xl);
+            f16x4 xh, xl;
+            split_one(x[NT - 1], scale, xh, xl);
             const char* ub = wb + (NT - 1) * NT * 1024 + lane * 8;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const bf16x4 wh = *reinterpret_cast<const bf16x4*>(ub + t * 1024);
-                const bf16x4 wl = *reinterpret_cast<const bf16x4*>(ub + t * 1024 + 512);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wl, xh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(wh, xh, acc[t], 0, 0, 0);
+                const f16x4 wh = *reinterpret_cast<const f16x4*>(ub + t * 1024);
+                const f16x4 wl = *reinterpret_cast<const f16x4*>(ub + t * 1024 + 512);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xh, acc[t], 0, 0, 0);
             }
         }
     }
@@ -241,6 +264,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const int grow = r0 + lrow;
     const int e0 = a.rowptr[r0], ne = a.rowptr[r1] - e0;
     const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
+    float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
+    if (tid < 16) s_max[tid] = 0.f;
 
     // ---- stage W_l of layer 1 into half A; first-layer scratch lives in half B ----
     if (a.L > 1)
@@ -343,6 +368,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) acc[t] = br[4 * t];
         }
+        float rs = 1.f, rinv = 1.f;
         if (wactive) {
             // phase 1: mean-gather from LDS, then K-half over W_l (half A)
             f32x4 ag[NT];
@@ -367,11 +393,29 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                     for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
                 }
             }
-            contract_half<NT, MATH>(wbuf, lane, ag, acc);
+            if constexpr (MATH == 1) {   // one power-of-two scale per row over [agg | x]; the bias joins the scaled sum
+                const float m = row_max4(frag_absmax<NT>(xs, frag_absmax<NT>(ag, 0.f)));
+                row_scale(m, rs, rinv);
+                if (a.xmax) { const float wm = rows_max16(m); if (lane == 0) s_max[wave] = wm; }
+                const float* wsc = reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP;
+                const float up = rs * wsc[0];
+                rinv *= wsc[1];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] *= up;
+            }
+            contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
         }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
         lds_barrier();     // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
+        if constexpr (MATH == 1) {
+            if (a.xmax && tid == 0) {   // layer maximum of [agg | x] over this graph -> global (order-independent)
+                float mm = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) mm = fmaxf(mm, s_max[w8]);
+                atomicMax(a.xmax + l, __builtin_bit_cast(unsigned, mm));
+            }
+        }
         if (l + 1 < a.L) {   // stream W_l(l+1) towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
 #pragma unroll
@@ -379,11 +423,12 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         }
         if (wactive) {
             // phase 2: K-half over W_r (half B) with the self rows kept in registers
-            contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc);
+            contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs);
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 v = acc[t];
+                if constexpr (MATH == 1) v *= rinv;
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) v[q4] = (rvalid && v[q4] > 0.f) ? v[q4] : 0.f;
                 xs[t] = v;
@@ -554,6 +599,8 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int grow = r0 + lrow;
     const int e0 = a.rowptr_t[r0], ne = a.rowptr_t[r1] - e0;
     const bool csr_lds = load_csr<NT>(lds, a.rowptr_t, a.col_t, r0, cnt, e0, ne, a.status);
+    float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
+    if (tid < 16) s_max[tid] = 0.f;
     const size_t slab = (size_t)a.n * HP;
     const int H2 = H / 2, H4 = 4 * H;
     constexpr int kStage = (kHalf + 511) / 512;
@@ -607,8 +654,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         for (int w = 0; w < 8; ++w) sdq += s_red[w];
         mean_dq = sdq * inv_cnt;
         const float dV = a.mode == 0 ? sdq : a.d_out_v[gi];
-        const float V = tanhf(a.vraw[gi]);
-        const float dv = dV * (1.f - V * V);
+        const float dv = dV * sech2f(a.vraw[gi]);
         if (tid == 0) a.dvr[gi] = dv;
         if (tid < H2) {
             const float zz = a.z[(size_t)gi * H2 + tid];
@@ -627,8 +673,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     if (tid < kRows) {
         float dar = 0.f;
         if (tid < cnt) {
-            const float t = tanhf(a.adv_raw[r0 + tid]);
-            dar = (a.dq[r0 + tid] - mean_dq) * 2.f * (1.f - t * t);
+            dar = (a.dq[r0 + tid] - mean_dq) * 2.f * sech2f(a.adv_raw[r0 + tid]);
             a.dadv[r0 + tid] = dar;
         }
         s_dar[tid] = dar;
@@ -718,6 +763,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         f32x4 acc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float rs = 1.f, rinv = 1.f;
         if (wactive) {
             // mask by this layer's ReLU, publish G_l
             if (rvalid) {
@@ -733,9 +779,23 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 }
             }
             // phase 1: dAggS = (G W_l) / deg     (half A)
-            contract_half<NT, MATH>(wbuf, lane, gx, acc);
+            if constexpr (MATH == 1) {
+                const float m = row_max4(frag_absmax<NT>(gx, 0.f));
+                row_scale(m, rs, rinv);
+                if (a.gmax) { const float wm = rows_max16(m); if (lane == 0) s_max[wave] = wm; }
+                rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
+            }
+            contract_half<NT, MATH>(wbuf, lane, gx, acc, rs);
         }
         lds_barrier();     // barrier A: gathers of the previous layer are done (dbuf free); half A free
+        if constexpr (MATH == 1) {
+            if (a.gmax && tid == 0) {
+                float mm = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) mm = fmaxf(mm, s_max[w8]);
+                atomicMax(a.gmax + l, __builtin_bit_cast(unsigned, mm));
+            }
+        }
         if (more) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
@@ -753,14 +813,14 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) dxs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         {
-            const float scl = rvalid ? a.invdeg[grow] : 0.f;
+            const float scl = rvalid ? a.invdeg[grow] * rinv : 0.f;
             f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) dr[4 * t] = acc[t] * scl;
         }
         if (wactive) {
             // phase 2: dXs = G W_r     (half B)
-            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, dxs);
+            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, dxs, rs);
         }
         lds_barrier();     // barrier B: dAggS rows + half A visible; half B free
         if (more) {
@@ -769,7 +829,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         }
         // gradient w.r.t. this layer's input = dXs + transposed gather of dAggS
 #pragma unroll
-        for (int t = 0; t < NT; ++t) gx[t] = dxs[t];
+        for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? dxs[t] * rinv : dxs[t];
         if (rvalid) {
             if (csr_lds) {
                 gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, gx);

@@ -1,4 +1,4 @@
-// Split-precision ("bf16x3") instantiations of the fused per-graph kernels (kernels: qnet_fused_kernels.h).
+// Split-precision ("f16x3") instantiations of the fused per-graph kernels (kernels: qnet_fused_kernels.h).
 #include "qnet_fused_kernels.h"
 
 namespace hexgnn {

@@ -39,7 +39,7 @@ int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
             p->bwd_off[l] = off; off += pack;
             p->agg_off[l] = soff; soff += align_up(sizeof(float) * (size_t)n * hp, 256);
         }
-        p->bias_off[l] = off; off += align_up(sizeof(float) * hp, 256);
+        p->bias_off[l] = off; off += align_up(sizeof(float) * (hp + 2), 256);   // bias[hp], then {w scale, 1/scale} (math 1)
     }
     p->pack_bytes = off;
     p->saved_bytes = soff;
@@ -97,25 +97,51 @@ __global__ void sage_pack_kernel(PackArgs a, char* __restrict__ wpack) {
 }
 
 
-// ---- split-precision packing for the fused kernels (math mode 1, "bf16x3"): every fp32 weight w is stored as two
-//      bf16 planes hi = bf16(w), lo = bf16(w - hi); the contraction W*X ~= Whi*Xhi + Whi*Xlo + Wlo*Xhi runs on the bf16
-//      MFMA pipe with fp32 accumulation (product error ~3*2^-16 relative; measured parity in tests/test_gpu_model.py).
+// ---- split-precision packing for the fused kernels (math mode 1, "f16x3"): every fp32 weight w of a layer is scaled
+//      by the layer's power of two s_W (max |w| * s_W in [2^14, 2^15)) and stored as two fp16 planes hi = f16(w s_W),
+//      lo = f16(w s_W - hi): 22 significand bits.  The contraction W*X ~= Whi*Xhi + Whi*Xlo + Wlo*Xhi runs on the f16
+//      MFMA pipe with fp32 accumulation (rows get their own power-of-two scale in the kernel; both are undone exactly in
+//      the epilogue).  Product error ~3*2^-22 relative to max|w| max|x|; measured parity in tests/test_gpu_model.py.
 //      Layout per K-half (NT*NT KiB, identical size to the fp32 pack): units u = chunk pairs (2p, 2p+1) [+ one odd
 //      chunk]; unit of s chunks at byte (first_chunk*NT) KiB; tile t at + t*s KiB; plane hi at +0, lo at + s*512 B;
 //      lane l at + l*8*s B holding the k-slots (kq = l>>4): j < 4 -> feature 16*c0 + 4*kq + j, j >= 4 -> 16*(c0+1) + 4*kq + j-4.
 struct Pack16Args {
     LayerPtrs p;
-    size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers];
-    int nt, L, hidden, first_hidden;
+    size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers], bias_off[kMaxLayers];
+    int nt, L, hidden, first_hidden, hp;
 };
-__device__ __forceinline__ unsigned short bf16_bits(float v) { __bf16 b = (__bf16)v; return __builtin_bit_cast(unsigned short, b); }
-__device__ __forceinline__ float bf16_to_f32(unsigned short u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+__device__ __forceinline__ unsigned short f16_bits(float v) { _Float16 b = (_Float16)v; return __builtin_bit_cast(unsigned short, b); }
+__device__ __forceinline__ float f16_to_f32(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
+
+// per hidden layer: s_W = 2^(14 - floor(log2 max|w|)) over W_l and W_r, stored with its inverse after the padded bias
+__global__ __launch_bounds__(256) void sage_wscale_kernel(Pack16Args a, char* __restrict__ wpack) {
+    const int l = a.first_hidden + blockIdx.x;
+    const int H = a.hidden;
+    const float* wl = a.p.wl[l];
+    const float* wr = a.p.wr[l];
+    float m = 0.f;
+    for (int i = threadIdx.x; i < H * H; i += 256) m = fmaxf(m, fmaxf(fabsf(wl[i]), fabsf(wr[i])));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    __shared__ float sm[4];
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        const unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
+        const bool ok = e >= 64u && e <= 190u;
+        float* out = reinterpret_cast<float*>(wpack + a.bias_off[l]) + a.hp;
+        out[0] = ok ? __builtin_bit_cast(float, (268u - e) << 23) : 1.f;
+        out[1] = ok ? __builtin_bit_cast(float, (e - 14u) << 23) : 1.f;
+    }
+}
 
 __global__ void sage_pack16_kernel(Pack16Args a, char* __restrict__ wpack) {
     const int l = a.first_hidden + blockIdx.y;
     const int nt = a.nt, H = a.hidden;
     const float* wl = a.p.wl[l];
     const float* wr = a.p.wr[l];
+    const float wscale = reinterpret_cast<const float*>(wpack + a.bias_off[l])[a.hp];
     // one thread per (direction, half, chunk c, tile t, lane, j<4): 2*2*nt*nt*64*4 elements
     const int per_dir = 2 * nt * nt * 256;
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -136,8 +162,9 @@ __global__ void sage_pack16_kernel(Pack16Args a, char* __restrict__ wpack) {
         const int o = 16 * c + 4 * kq + j, i = 16 * t + m;
         v = (o < H && i < H) ? w[o * H + i] : 0.f;
     }
-    const unsigned short hi = bf16_bits(v);
-    const unsigned short lo = bf16_bits(v - bf16_to_f32(hi));
+    v *= wscale;
+    const unsigned short hi = f16_bits(v);
+    const unsigned short lo = f16_bits(v - f16_to_f32(hi));
     const bool paired = (c | 1) < nt;           // chunk belongs to a full pair
     const int c0 = c & ~1;
     const int s = paired ? 2 : 1;
@@ -478,6 +505,160 @@ __global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __res
     if (kq == 0) slab[(size_t)HP * 2 * HP + 16 * w + m] = bsum;
 }
 
+
+// ---- the same batched weight gradient in split precision ("f16x3", math 1) ---------------------------------
+// The contraction runs over ROWS, so both MFMA operands need 8 consecutive rows of one column per lane.  Every thread
+// stages TWO adjacent rows (2i, 2i+1) of one float4 column group: the chunk (R = 32 rows = one K step) is scaled by the
+// layer's power of two (max |G_l|, max |[agg|x]| -> 2^14..2^15, maxima produced by the fused forward / backward
+// kernels), split into fp16 hi / lo and stored as ROW-PAIR words (row 2i in the low half, row 2i+1 in the high half)
+// in two planes T[plane][rowpair][col].  A fragment is then four conflict-free ds_read_b32 per plane (row-pair stride
+// == 4 mod 8 dwords) with no unpacking at all.  Wave w owns the input-feature tiles {2w, 2w+1} of [agg | x] and all
+// NT output tiles: 9 fragments feed 42 v_mfma_f32_16x16x32_f16 per chunk.  db is summed exactly in fp32 on the staging
+// path.  Same slab layout as sage_dw_kernel (deterministic slice reduce afterwards).
+struct Dw16Args {
+    const float* xin[kMaxLayers];
+    const float* agg[kMaxLayers];
+    const float* g[kMaxLayers];
+    const unsigned* xmax;     // [absolute layer] bit pattern of max |[agg | x]|
+    const unsigned* gmax;     // [absolute layer] bit pattern of max |G|
+    int first_hidden, n, rows_per_slice, S;
+};
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// rows (a, b) of one column, scaled: hi word = (f16(a s), f16(b s)), lo word = the fp16 remainders
+__device__ __forceinline__ void split_rowpair(float va, float vb, float sa, float sb, unsigned& hi, unsigned& lo) {
+    const float a = va * sa, b = vb * sb;
+    const h16x2 h = {(_Float16)a, (_Float16)b};
+    const h16x2 l = {(_Float16)(a - (float)h[0]), (_Float16)(b - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ h16x8 dw16_frag(const unsigned* __restrict__ base /* &T[4kq][col] */, int stride) {
+    return __builtin_bit_cast(h16x8, (u32x4){base[0], base[stride], base[2 * stride], base[3 * stride]});
+}
+
+template <int NT>
+__global__ __launch_bounds__(64 * NT) void sage_dw16_kernel(Dw16Args a, float* __restrict__ part) {
+    constexpr int HP = 16 * NT, R = 32, Q = 4 * NT, NTHR = 64 * NT;
+    constexpr int XS2 = 2 * HP + 4;     // dwords per row pair; 4*XS2 == 16 (mod 32): conflict-free fragment reads
+    constexpr int GS2 = HP + 4;
+    constexpr int RP = R / 2;           // row pairs per chunk
+    static_assert(RP * Q == NTHR, "one (row pair, column group) per thread");
+    __shared__ __attribute__((aligned(16))) unsigned Xh[RP * XS2], Xl[RP * XS2];
+    __shared__ __attribute__((aligned(16))) unsigned Gh[RP * GS2], Gl[RP * GS2];
+    const int li = blockIdx.y, s = blockIdx.x;
+    const int labs = a.first_hidden + li;
+    const float* __restrict__ xin = a.xin[li];
+    const float* __restrict__ agg = a.agg[li];
+    const float* __restrict__ gg = a.g[li];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int r_beg = s * a.rows_per_slice;
+    const int r_end = min(a.n, r_beg + a.rows_per_slice);
+    float sx, ix, sg, ig;
+    pow2_scale(__builtin_bit_cast(float, a.xmax[labs]), sx, ix);
+    pow2_scale(__builtin_bit_cast(float, a.gmax[labs]), sg, ig);
+
+    f32x4 acc[NT][2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) { acc[t][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = acc[t][0]; }
+    f32x4 gsum = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (r_beg >= r_end) return;         // block-uniform (cannot happen with the host's slicing)
+
+    const int q = tid % Q, rp = tid / Q;            // this thread's column group and row pair
+    // two register sets of prefetched rows: the loads of chunk i+2 are issued while chunk i is multiplied (86 KB in flight
+    // per CU; one workgroup per CU, <= 256 VGPRs)
+    struct Pre { f32x4 ra[2], rx[2], rg[2]; float f0, f1; };   // f = 1 when the staged row exists (rows past the slice: zeros)
+    Pre pA, pB;
+    auto issue = [&](Pre& p, int rc) {
+        const int row0 = rc + 2 * rp, row1 = row0 + 1;
+        p.f0 = row0 < r_end ? 1.f : 0.f; p.f1 = row1 < r_end ? 1.f : 0.f;
+        const size_t o0 = (size_t)min(row0, r_end - 1) * HP, o1 = (size_t)min(row1, r_end - 1) * HP;
+        p.ra[0] = reinterpret_cast<const f32x4*>(agg + o0)[q]; p.ra[1] = reinterpret_cast<const f32x4*>(agg + o1)[q];
+        p.rx[0] = reinterpret_cast<const f32x4*>(xin + o0)[q]; p.rx[1] = reinterpret_cast<const f32x4*>(xin + o1)[q];
+        p.rg[0] = reinterpret_cast<const f32x4*>(gg + o0)[q];  p.rg[1] = reinterpret_cast<const f32x4*>(gg + o1)[q];
+    };
+    auto stage = [&](const Pre& p) {
+        // conditional adds, NOT `gsum += rg[0] * f0 + rg[1] * f1`: hipcc 7.2 turned that form into a
+        // v_mul/v_pk_fma_f32 sequence whose third component came out ~6 % low on gfx950 (caught by the parity tests)
+        if (p.f0 != 0.f) gsum += p.rg[0];
+        if (p.f1 != 0.f) gsum += p.rg[1];
+        const float sx0 = sx * p.f0, sx1 = sx * p.f1, sg0 = sg * p.f0, sg1 = sg * p.f1;
+        u32x4 ah, al, xh, xl, gh, gl;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            unsigned h, l;
+            split_rowpair(p.ra[0][c], p.ra[1][c], sx0, sx1, h, l); ah[c] = h; al[c] = l;
+            split_rowpair(p.rx[0][c], p.rx[1][c], sx0, sx1, h, l); xh[c] = h; xl[c] = l;
+            split_rowpair(p.rg[0][c], p.rg[1][c], sg0, sg1, h, l); gh[c] = h; gl[c] = l;
+        }
+        *reinterpret_cast<u32x4*>(&Xh[rp * XS2 + 4 * q]) = ah;
+        *reinterpret_cast<u32x4*>(&Xl[rp * XS2 + 4 * q]) = al;
+        *reinterpret_cast<u32x4*>(&Xh[rp * XS2 + HP + 4 * q]) = xh;
+        *reinterpret_cast<u32x4*>(&Xl[rp * XS2 + HP + 4 * q]) = xl;
+        *reinterpret_cast<u32x4*>(&Gh[rp * GS2 + 4 * q]) = gh;
+        *reinterpret_cast<u32x4*>(&Gl[rp * GS2 + 4 * q]) = gl;
+    };
+    auto compute = [&]() {
+        h16x8 bh[2], bl[2];
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb) {
+            const int o = (4 * kq) * XS2 + 16 * (2 * w + tb) + m;
+            bh[tb] = dw16_frag(&Xh[o], XS2);
+            bl[tb] = dw16_frag(&Xl[o], XS2);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            const int o = (4 * kq) * GS2 + 16 * t + m;
+            const h16x8 ah = dw16_frag(&Gh[o], GS2);
+            const h16x8 al = dw16_frag(&Gl[o], GS2);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[0], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(al, bh[1], acc[t][1], 0, 0, 0);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[0], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bl[1], acc[t][1], 0, 0, 0);
+            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[0], acc[t][0], 0, 0, 0);
+            acc[t][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ah, bh[1], acc[t][1], 0, 0, 0);
+        }
+    };
+    issue(pA, r_beg);
+    issue(pB, r_beg + R);          // rows past the slice are clamped + flagged, so an over-issue is harmless
+    for (int rc = r_beg; rc < r_end; rc += 2 * R) {
+        stage(pA);
+        __syncthreads();
+        issue(pA, rc + 2 * R);
+        compute();
+        __syncthreads();
+        if (rc + R < r_end) {       // block-uniform
+            stage(pB);
+            __syncthreads();
+            issue(pB, rc + 3 * R);
+            compute();
+            __syncthreads();
+        }
+    }
+    // slab [HP][2HP] then bias [HP]
+    float* slab = part + ((size_t)li * a.S + s) * ((size_t)HP * (2 * HP + 1));
+    const float inv = ix * ig;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                slab[(size_t)(16 * t + 4 * kq + r) * (2 * HP) + 16 * (2 * w + tb) + m] = acc[t][tb][r] * inv;
+    float* red = reinterpret_cast<float*>(Xh);      // [16][HP] partial column sums of G (exact fp32)
+    *reinterpret_cast<f32x4*>(&red[rp * HP + 4 * q]) = gsum;
+    __syncthreads();
+    if (tid < HP) {
+        float b = 0.f;
+#pragma unroll
+        for (int k = 0; k < RP; ++k) b += red[k * HP + tid];
+        slab[(size_t)HP * 2 * HP + tid] = b;
+    }
+}
+
 struct DwReduceArgs {
     float* dwl[kMaxLayers];
     float* dbl[kMaxLayers];
@@ -604,6 +785,12 @@ static void launch_dw(const DwArgs& a, int layers, float* part, hipStream_t st) 
     sage_dw_kernel<NT><<<dim3(a.S, layers), 64 * NT, 0, st>>>(a, part);
 }
 
+template <int NT>
+static void launch_dw16(const Dw16Args& a, int layers, float* part, hipStream_t st) {
+    KernelTimer kt(HEXGNN_K_SAGE_DW, st);
+    sage_dw16_kernel<NT><<<dim3(a.S, layers), 64 * NT, 0, st>>>(a, part);
+}
+
 #define HEXGNN_NT_SWITCH(nt, CALL)                 \
     switch (nt) {                                  \
         case 1: { constexpr int NT_ = 1; CALL; } break; \
@@ -653,21 +840,25 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
     pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
     const int pack_elems = 2 * p.nt * p.nt * 256;
     sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
-    if (math == 1) {   // overwrite the hidden layers' weight packs with the split-bf16 layout (biases / raw layer stay fp32)
+    if (math == 1) {   // overwrite the hidden layers' weight packs with the split-f16 layout (biases / raw layer stay fp32)
         Pack16Args pb;
         pb.p = pa.p;
-        for (int l = 0; l < p.L; ++l) { pb.fwd_off[l] = p.fwd_off[l]; pb.bwd_off[l] = p.bwd_off[l]; }
-        pb.nt = p.nt; pb.L = p.L; pb.hidden = hidden; pb.first_hidden = p.small_first ? 1 : 0;
+        for (int l = 0; l < p.L; ++l) { pb.fwd_off[l] = p.fwd_off[l]; pb.bwd_off[l] = p.bwd_off[l]; pb.bias_off[l] = p.bias_off[l]; }
+        pb.nt = p.nt; pb.L = p.L; pb.hidden = hidden; pb.first_hidden = p.small_first ? 1 : 0; pb.hp = p.hp;
         const int nh = p.L - pb.first_hidden;
         const int elems = 2 * 2 * p.nt * p.nt * 256;
-        if (nh > 0) sage_pack16_kernel<<<dim3((elems + 255) / 256, nh), 256, 0, st>>>(pb, (char*)wpack);
+        if (nh > 0) {
+            sage_wscale_kernel<<<nh, 256, 0, st>>>(pb, (char*)wpack);
+            sage_pack16_kernel<<<dim3((elems + 255) / 256, nh), 256, 0, st>>>(pb, (char*)wpack);
+        }
     }
     return HEXGNN_OK;
 }
 
 int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
                         int x_stride, const float* acts, const char* sv, const float* G, float* const* d_wl,
-                        float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st) {
+                        float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st,
+                        int math, const unsigned* xmax, const unsigned* gmax) {
     const size_t slab = (size_t)n * p.hp;
     const int first_hidden = p.small_first ? 1 : 0;
     const int nh = p.L - first_hidden;
@@ -683,7 +874,15 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
         }
         da.n = n; da.rows_per_slice = b.rps; da.S = b.S;
         ra.S = b.S; ra.hp = p.hp; ra.hidden = hidden;
-        HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
+        if (math == 1 && xmax && gmax) {
+            Dw16Args d16;
+            for (int i = 0; i < nh; ++i) { d16.xin[i] = da.xin[i]; d16.agg[i] = da.agg[i]; d16.g[i] = da.g[i]; }
+            d16.xmax = xmax; d16.gmax = gmax; d16.first_hidden = first_hidden;
+            d16.n = n; d16.rows_per_slice = b.rps; d16.S = b.S;
+            HEXGNN_NT_SWITCH(p.nt, (launch_dw16<NT_>(d16, nh, part, st)));
+        } else {
+            HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
+        }
         const int tot = hidden * (2 * hidden + 1);
         sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
     }

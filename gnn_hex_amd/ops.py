@@ -286,18 +286,19 @@ class HeadTailFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------
 
 _FUSED_ENABLED = True
-_MATH = 0     # 0 = exact fp32 MFMA, 1 = split precision "bf16x3" (fused kernels only)
+_MATH = 0     # 0 = exact fp32 MFMA, 1 = split precision "f16x3" (fused kernels only)
 
 
 def set_math(mode) -> None:
-    """Arithmetic of the fused kernels' contractions: "fp32" (exact, default) or "bf16x3" (fp32 operands split into
-    bf16 hi+lo pairs, three bf16 MFMAs per product block, fp32 accumulation; ~1e-5 relative)."""
+    """Arithmetic of the fused kernels' contractions: "fp32" (exact fp32 MFMA, default) or "f16x3" (fp32 operands
+    scaled by exact powers of two and split into fp16 hi+lo pairs = 22 significand bits, three f16 MFMAs per product
+    block, fp32 accumulation; ~1e-6 relative)."""
     global _MATH
-    _MATH = {"fp32": 0, 0: 0, "bf16x3": 1, 1: 1}[mode]
+    _MATH = {"fp32": 0, 0: 0, "f16x3": 1, 1: 1}[mode]
 
 
 def get_math() -> str:
-    return "bf16x3" if _MATH == 1 else "fp32"
+    return "f16x3" if _MATH == 1 else "fp32"
 
 
 def set_fused(enabled: bool) -> None:

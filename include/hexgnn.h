@@ -127,9 +127,11 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
  *      by the forward call and consumed by the backward call of the same step.  Same results as the
  *      sage_stack + head calls above.
  *      math: 0 = exact fp32 MFMA (v_mfma_f32_16x16x4_f32; same fmaf chains as the layered kernels);
- *            1 = split precision "bf16x3": every fp32 operand a = hi + lo (bf16 pair), W*x ~= Whi*xhi + Whi*xlo + Wlo*xhi on
- *                the bf16 MFMA pipe with fp32 accumulation (relative product error ~3*2^-16; Q / gradients stay within the
- *                1e-4 parity bar, see tests/test_gpu_model.py).  The backward call must use the math of its forward. ---- */
+ *            1 = split precision "f16x3": weights (per layer) and rows (per row) are scaled by exact powers of two, every
+ *                scaled fp32 operand a = hi + lo (fp16 pair, 22 significand bits), W*x ~= Whi*xhi + Whi*xlo + Wlo*xhi on
+ *                the f16 MFMA pipe with fp32 accumulation, scales undone exactly in the epilogue (product error
+ *                ~3*2^-22 of max|w| max|x|; same parity bar as math 0, see tests/test_gpu_model.py).  The backward
+ *                call must use the math of its forward. ---- */
 int hexgnn_qnet_supported(int c_in, int hidden, int max_nodes_per_graph);
 size_t hexgnn_qnet_saved_bytes(int n, int b, int c_in, int hidden, int total_layers);
 int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,

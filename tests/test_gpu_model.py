@@ -13,10 +13,10 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-@pytest.fixture(params=[(True, "fp32"), (True, "bf16x3"), (False, "fp32")], ids=["fused", "fused-bf16x3", "layered"],
+@pytest.fixture(params=[(True, "fp32"), (True, "f16x3"), (False, "fp32")], ids=["fused", "fused-f16x3", "layered"],
                 autouse=True)
 def _all_paths(request):
-    """Every parity test runs through the fused per-graph kernels (exact fp32 MFMA and the split-precision bf16x3
+    """Every parity test runs through the fused per-graph kernels (exact fp32 MFMA and the split-precision f16x3
     math) and through the general layer-major kernels (graphs > 128 nodes or hidden > 112 always take the latter).
     The SAME 1e-4 bar applies to all three."""
     from gnn_hex_amd import ops
@@ -264,9 +264,37 @@ def test_dense_graph_exceeds_lds_csr_capacity():
     x, ei, batch, ptr = _random_batch([100, 100], seed=7, directed=True, p_edge=0.6)
     assert ei.shape[1] > 2 * 3800
     # degree-60 random graphs with features up to 8 are far outside the board-graph domain (degree <= ~12) and make the
-    # gradient sums cancel heavily.  The exact fp32 paths still meet 1e-4 elementwise; the split-precision math, whose
-    # error is ~1e-5 of the SUMMED magnitudes, is held to 1e-4 on Q and to a 5e-3 norm-wise bound on the gradients (measured up to ~1e-3 of the tensor norm).
-    if ops.get_math() == "bf16x3":
-        _compare(hip, ref, x, ei, batch, ptr, tol=TOL, grad_norm_rel=5e-3)
-    else:
-        _compare(hip, ref, x, ei, batch, ptr)
+    # gradient sums cancel heavily: the hardest case for the split-precision math, held to the same bar as exact fp32.
+    _compare(hip, ref, x, ei, batch, ptr)
+
+
+def test_split_math_is_fp32_class_against_float64():
+    """Accuracy of both arithmetic modes of the fused kernels measured against the SAME oracle evaluated in float64
+    (GNN-L, Hex-11 mid-game boards, loss gradients): the f16x3 split (22-bit products, fp32 accumulate) must sit within
+    a small factor of the exact-fp32 MFMA path's own rounding error, i.e. both are fp32-class results."""
+    import copy
+    from gnn_hex_amd import ops
+    hip, ref = make_pair(15, 110, seed=5)
+    ref64 = copy.deepcopy(ref).double()
+    x, ei, batch, ptr = batch_tensors("D1", [11] * 24, maker=True)
+    sel, tgt = sel_and_targets(ptr)
+    q64, g64 = _step(ref64, x.double(), ei, batch, ptr, sel, tgt.double())
+    errs = {}
+    if ops.get_math() != "fp32" or not ops._FUSED_ENABLED:
+        pytest.skip("mode-independent: runs once (it sets both math modes itself)")
+    for math in ("fp32", "f16x3"):      # the autouse fixture restores the defaults afterwards
+        ops.set_math(math)
+        q, g = _step(hip, x.cuda(), ei.cuda(), batch.cuda(), ptr.cuda(), sel.cuda(), tgt.cuda())
+        torch.cuda.synchronize()
+        eq = (q.cpu().double() - q64).abs().max().item()
+        # tensors whose true gradient vanishes (the advantage bias: the dueling mean removes it) are pure rounding noise
+        eg = max(((g[k].cpu().double() - g64[k]).norm() / g64[k].norm()).item()
+                 for k in g64 if g64[k] is not None and g64[k].norm() > 1e-6)
+        errs[math] = (eq, eg)
+    print("max |Q - Q64| and worst relative gradient-tensor error:", errs)
+    # measured on MI355X: Q 1.7e-7 (fp32) / 2.7e-7 (f16x3); gradients 7.7e-4 / 6.3e-4 (the random-init network
+    # saturates tanh, so its gradients are ill-conditioned in ANY fp32 arithmetic; the CPU fp32 oracle itself: 3.0e-4)
+    assert errs["fp32"][0] < 2e-6 and errs["f16x3"][0] < 2e-6
+    assert errs["fp32"][1] < 5e-3 and errs["f16x3"][1] < 5e-3
+    assert errs["f16x3"][0] <= 4 * errs["fp32"][0] + 1e-7
+    assert errs["f16x3"][1] <= 2 * errs["fp32"][1] + 1e-5
