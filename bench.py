@@ -22,6 +22,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")   # ROCm 7.2 hipGraph bug, see gnn_hex_amd/graphs.py (--graph)
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
@@ -61,6 +62,9 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path "
                          "on a box with fewer GPUs than ranks)")
+    ap.add_argument("--graph", action="store_true",
+                    help="capture each step (maker batch / breaker batch) into a HIP graph and replay it; the gradient "
+                         "all-reduce stays outside the graph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -125,10 +129,32 @@ def main():
         for p in plist:              # optimizer.zero_grad(set_to_none=True) over a cached parameter list
             p.grad = None
         q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
-        loss = torch.nn.functional.mse_loss(q[bt["sel"]], bt["tgt"])
+        loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"])
         loss.backward()
         if world > 1:
             sync.all_reduce()
+
+    if args.graph:
+        from gnn_hex_amd.graphs import GraphedStep
+
+        def local_step(bt):
+            def fn():
+                for p in plist:
+                    p.grad = None
+                q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
+                loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"])
+                loss.backward()
+                return loss
+            return fn
+
+        g0 = GraphedStep(local_step(batches[0]), plist)
+        g1 = GraphedStep(local_step(batches[1]), plist, pool=g0.pool())
+        graphs = (g0, g1)
+
+        def step(i):
+            graphs[i & 1].replay()
+            if world > 1:
+                sync.all_reduce()
 
     def barrier():
         torch.cuda.synchronize()
@@ -210,7 +236,7 @@ def main():
             "config": {"workload": "%s, %s board graphs, %d graphs per GPU (N=%d nodes, E=%d directed edges)"
                                    % (label, "start-position" if args.data == "D0" else "random-playout",
                                       B, batches[0]["n"], batches[0]["e"]),
-                       "parallelism": "dp%d" % world, "global_batch": B * world},
+                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * world},
             "roofline": roof, "cpu_baseline": cpu,
         }
         print(json.dumps(out))
@@ -257,11 +283,12 @@ def selfplay(args, num_layers, hidden, label, dev):
 
 
 def step_local(hip, batches, i):
+    from gnn_hex_amd import ops as hexops
     bt = batches[i & 1]
     for p in hip.parameters():
         p.grad = None
     q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
-    torch.nn.functional.mse_loss(q[bt["sel"]], bt["tgt"]).backward()
+    hexops.td_loss(q, bt["sel"], bt["tgt"])[0].backward()
 
 
 def cpu_baseline(ref, batches, B):

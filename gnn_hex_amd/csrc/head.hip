@@ -305,6 +305,47 @@ int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const 
 }
 
 
+// ---- TD loss on the selected nodes: loss = mean_j w_j * l(q[sel_j] - tgt_j), l = d^2 ("mse") or Huber(delta 1) -----------
+// The reference's training loop gathers Q(s, a) with torch indexing and calls the loss in torch (Rainbow agent,
+// --loss_fn=mse, importance weights of the prioritized replay): ~15 tiny kernels forward + backward (gather, sub, pow,
+// mean, sort-based index_put ...).  Here: one single-workgroup kernel forward (fixed-shape tree => deterministic) and
+// one memset + one scatter kernel backward.  td[j] = q[sel_j] - tgt_j is returned for the priority update.
+__global__ __launch_bounds__(256) void td_loss_fwd_kernel(int n, int k, const float* __restrict__ q,
+                                                         const int64_t* __restrict__ sel, const float* __restrict__ tgt,
+                                                         const float* __restrict__ w, int loss_fn,
+                                                         float* __restrict__ loss, float* __restrict__ td) {
+    __shared__ float red[256];
+    float acc = 0.f;
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const int64_t i = sel[j];
+        const float d = (i >= 0 && i < n) ? q[i] - tgt[j] : 0.f;
+        td[j] = d;
+        const float a = fabsf(d);
+        const float l = loss_fn == 0 ? d * d : (a <= 1.f ? 0.5f * d * d : a - 0.5f);
+        acc += (w ? w[j] : 1.f) * l;
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) loss[0] = red[0] / (float)(k > 0 ? k : 1);
+}
+
+__global__ void td_loss_bwd_kernel(int n, int k, const int64_t* __restrict__ sel, const float* __restrict__ td,
+                                   const float* __restrict__ w, int loss_fn, const float* __restrict__ gloss,
+                                   float* __restrict__ dq) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= k) return;
+    const int64_t i = sel[j];
+    if (i < 0 || i >= n) return;
+    const float d = td[j];
+    const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
+    atomicAdd(dq + i, gloss[0] * (w ? w[j] : 1.f) * dl / (float)k);   // one add per selected node (duplicates: two adds commute)
+}
+
+
 // ---- acting: per-graph epsilon-greedy / argmax over the non-terminal nodes, mapped to vertex ids ----------------------
 // One wave per graph.  Greedy = first node attaining the maximum of q[gptr[g]+2 : gptr[g+1]] (torch.argmax tie rule;
 // GN0/RainbowDQN/evaluate_elo.py:253-266); with u given, env g explores when u[2g] < eps and then plays node
@@ -356,6 +397,22 @@ int hexgnn_select_actions(int b, const int* gptr, const float* q, const int64_t*
     if (b == 0) return HEXGNN_OK;
     select_actions_kernel<<<b, 64, 0, (hipStream_t)stream_>>>(b, gptr, q, backmap, eps, u, action_vertex, action_rank,
                                                               exploratory);
+    return check_launch();
+}
+
+int hexgnn_td_loss_forward(int n, int k, const float* q, const int64_t* sel, const float* target, const float* weights,
+                           int loss_fn, float* loss, float* td, hexgnn_stream_t stream_) {
+    if (n < 0 || k < 0 || loss_fn < 0 || loss_fn > 1 || !loss || (k > 0 && (!q || !sel || !target || !td))) return HEXGNN_EINVAL;
+    td_loss_fwd_kernel<<<1, 256, 0, (hipStream_t)stream_>>>(n, k, q, sel, target, weights, loss_fn, loss, td);
+    return check_launch();
+}
+
+int hexgnn_td_loss_backward(int n, int k, const int64_t* sel, const float* td, const float* weights, int loss_fn,
+                            const float* grad_loss, float* dq, hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    if (n < 0 || k < 0 || loss_fn < 0 || loss_fn > 1 || !grad_loss || (n > 0 && !dq) || (k > 0 && (!sel || !td))) return HEXGNN_EINVAL;
+    if (n > 0) (void)hipMemsetAsync(dq, 0, sizeof(float) * (size_t)n, st);
+    if (k > 0 && n > 0) td_loss_bwd_kernel<<<(k + 255) / 256, 256, 0, st>>>(n, k, sel, td, weights, loss_fn, grad_loss, dq);
     return check_launch();
 }
 

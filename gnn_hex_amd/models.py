@@ -345,7 +345,9 @@ class DuellingTwoHeaded(torch.nn.Module):
 
         # general layer-major path (any graph size, hidden <= 128)
         embeds = self.gnn(x2, edge_index, set_cache=set_cache, _graph=gs)
-        self.final_conv_acts = embeds
+        # values only (as the fused path): keeping the differentiable tensor on the module would keep the whole autograd
+        # graph -- and its per-parameter AccumulateGrad nodes -- alive across steps (see gnn_hex_amd/graphs.py)
+        self.final_conv_acts = embeds.detach()
         if embeds.requires_grad:
             embeds.register_hook(self.activations_hook)
         hx = head.gnn(embeds, edge_index, set_cache=set_cache, _graph=gs)

@@ -408,3 +408,55 @@ class QNetFusedFn(torch.autograd.Function):
         if mode == 2:
             tg[2] = tg[3] = tg[4] = tg[5] = None
         return (None,) * 10 + tuple(cg) + tuple(tg)
+
+
+class TdLossFn(torch.autograd.Function):
+    """``loss_fn(Q[sel], target)`` of the DQN update as one kernel forward and memset + scatter backward (C ABI
+    ``hexgnn_td_loss_*``): mean of importance-weighted squared ("mse") or Huber errors over the selected nodes."""
+
+    @staticmethod
+    def forward(ctx, q, sel, target, weights, loss_fn: int):
+        L = _lib.lib()
+        dev = q.device
+        qf = q.reshape(-1)
+        if qf.dtype != torch.float32 or not qf.is_contiguous():
+            qf = qf.float().contiguous()
+        sel = sel.to(device=dev, dtype=torch.long).contiguous()
+        tgt = target.to(device=dev, dtype=torch.float32).contiguous()
+        w = None if weights is None else weights.to(device=dev, dtype=torch.float32).contiguous()
+        k, n = int(sel.numel()), int(qf.numel())
+        if tgt.numel() != k or (w is not None and w.numel() != k):
+            raise ValueError("sel / target / weights must have the same length")
+        loss = torch.empty((), dtype=torch.float32, device=dev)
+        td = torch.empty(k, dtype=torch.float32, device=dev)
+        _lib.check(L.hexgnn_td_loss_forward(n, k, qf.data_ptr(), sel.data_ptr(), tgt.data_ptr(),
+                                            w.data_ptr() if w is not None else None, loss_fn, loss.data_ptr(),
+                                            td.data_ptr(), _stream()), "hexgnn_td_loss_forward")
+        ctx.save_for_backward(sel, td, w if w is not None else td)
+        ctx.has_w, ctx.loss_fn, ctx.shape = w is not None, loss_fn, q.shape
+        ctx.mark_non_differentiable(td)
+        return loss, td
+
+    @staticmethod
+    def backward(ctx, gloss, _gtd):
+        sel, td, w = ctx.saved_tensors
+        n = 1
+        for d in ctx.shape:
+            n *= int(d)
+        dq = torch.empty(n, dtype=torch.float32, device=td.device)
+        g = gloss.reshape(1).float().contiguous()
+        _lib.check(_lib.lib().hexgnn_td_loss_backward(n, int(sel.numel()), sel.data_ptr(), td.data_ptr(),
+                                                      w.data_ptr() if ctx.has_w else None, ctx.loss_fn, g.data_ptr(),
+                                                      dq.data_ptr(), _stream()), "hexgnn_td_loss_backward")
+        return dq.view(ctx.shape), None, None, None, None
+
+
+def td_loss(q: torch.Tensor, sel: torch.Tensor, target: torch.Tensor, weights: Optional[torch.Tensor] = None,
+            loss_fn: str = "mse"):
+    """``(loss, td_errors)`` with ``loss = mean(weights * l(q[sel] - target))``, ``l`` = squared error ("mse", the
+    reference's ``--loss_fn=mse``) or Huber with delta 1 ("huber"); ``td_errors = q[sel] - target`` (detached) feed
+    ``GraphReplayBuffer.update_priorities``.  Equal to ``F.mse_loss(q[sel], target)`` / ``F.huber_loss`` when
+    ``weights`` is None."""
+    if q.device.type != "cuda":
+        raise _lib.HexGnnError("td_loss runs only on the MI355X HIP path (no CPU fallback)")
+    return TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])

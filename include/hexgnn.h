@@ -234,6 +234,16 @@ int hexgnn_profile_enable(int kernel_class); /* -1: off.  Clears earlier samples
 /* Waits for the recorded events; returns the number of launches and their summed duration. */
 int hexgnn_profile_read(int* launches, float* total_ms);
 
+/* ---- TD loss on selected nodes (the training loop's `loss_fn(Q[sel], target)` with the prioritized replay's importance
+ *      weights; Rainbow agent of the un-vendored submodule, flags README.md:5,7 --loss_fn=mse --prioritized_er=True):
+ *      loss = mean_j w_j * l(q[sel_j] - target_j), l = d^2 (loss_fn 0) or Huber with delta 1 (loss_fn 1); weights may be
+ *      NULL.  td[j] = q[sel_j] - target_j (priority update).  backward: dq[n] = d loss / d q scaled by *grad_loss
+ *      (device scalar).  sel entries outside [0, n) contribute nothing. ---- */
+int hexgnn_td_loss_forward(int n, int k, const float* q, const int64_t* sel, const float* target, const float* weights,
+                           int loss_fn, float* loss, float* td, hexgnn_stream_t stream);
+int hexgnn_td_loss_backward(int n, int k, const int64_t* sel, const float* td, const float* weights, int loss_fn,
+                            const float* grad_loss, float* dq, hexgnn_stream_t stream);
+
 /* ---- acting: epsilon-greedy action per graph straight from the Q / advantage vector (replaces the per-graph python
  *      argmax over action_values[ptr[g]+2 : ptr[g+1]] of GN0/RainbowDQN/evaluate_elo.py:253-266 and the backmap lookup
  *      of Env_manager.validate_actions, graph_game/multi_env_manager.py:62-64).  u: [b][2] uniforms in [0,1) or NULL for

@@ -298,3 +298,78 @@ def test_split_math_is_fp32_class_against_float64():
     assert errs["fp32"][1] < 5e-3 and errs["f16x3"][1] < 5e-3
     assert errs["f16x3"][0] <= 4 * errs["fp32"][0] + 1e-7
     assert errs["f16x3"][1] <= 2 * errs["fp32"][1] + 1e-5
+
+
+def test_graphed_step_replays_bit_identical_gradients():
+    """A whole step (CSR build + forward + loss + backward) captured into a HIP graph and replayed must reproduce the
+    eager step's Q loss and gradients bit for bit, for two captured batches (maker / breaker) sharing one model."""
+    from gnn_hex_amd.graphs import GraphedStep
+    hip, _ = make_pair(4, 35, seed=3)
+    params = list(hip.parameters())
+    batches = []
+    for maker in (True, False):
+        x, ei, batch, ptr = batch_tensors("D1", [7, 5, 7, 6], maker=maker)
+        sel, tgt = sel_and_targets(ptr)
+        xd = x.cuda()
+        xd._hex_is_maker = maker
+        xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())
+        batches.append((xd, ei.cuda(), batch.cuda(), ptr.cuda(), sel.cuda(), tgt.cuda()))
+
+    def make_fn(bt):
+        def fn():
+            for p in params:
+                p.grad = None
+            q = hip(bt[0], bt[1], bt[2], bt[3])
+            loss = torch.nn.functional.mse_loss(q[bt[4]], bt[5])
+            loss.backward()
+            return loss
+        return fn
+
+    eager = []
+    for bt in batches:
+        loss = make_fn(bt)()
+        torch.cuda.synchronize()
+        eager.append((loss.detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in params]))
+        del loss    # see GraphedStep: no autograd graph built on the default stream may be alive at capture time
+    g0 = GraphedStep(make_fn(batches[0]), params)
+    g1 = GraphedStep(make_fn(batches[1]), params, pool=g0.pool())
+    for rep in range(2):
+        for g, (loss_e, grads_e) in zip((g0, g1), eager):
+            loss = g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(loss, loss_e)
+            for p, ge in zip(params, grads_e):
+                if ge is None:
+                    assert p.grad is None
+                else:
+                    assert torch.equal(p.grad, ge)
+
+
+@pytest.mark.parametrize("loss_fn", ["mse", "huber"])
+@pytest.mark.parametrize("weighted", [False, True])
+def test_td_loss_matches_torch(loss_fn, weighted):
+    """Fused TD loss (gather + loss + mean; memset + scatter backward) vs the torch expression it replaces, including
+    duplicate selections, importance weights and an upstream gradient scale."""
+    from gnn_hex_amd import ops
+    if ops.get_math() != "fp32" or not ops._FUSED_ENABLED:
+        pytest.skip("mode-independent")
+    gen = torch.Generator().manual_seed(11)
+    n, k = 5000, 257
+    q0 = (torch.randn(n, generator=gen) * 1.5)
+    sel = torch.randint(0, n, (k,), generator=gen)
+    sel[5] = sel[17]                       # a duplicate
+    tgt = torch.randn(k, generator=gen)
+    w = torch.rand(k, generator=gen) + 0.1 if weighted else None
+    qr = q0.clone().requires_grad_(True)
+    d = qr[sel] - tgt
+    el = d * d if loss_fn == "mse" else torch.nn.functional.huber_loss(qr[sel], tgt, reduction="none", delta=1.0)
+    ref = (el * w).mean() if weighted else el.mean()
+    (ref * 0.7).backward()
+    qh = q0.clone().cuda().requires_grad_(True)
+    loss, td = ops.td_loss(qh, sel.cuda(), tgt.cuda(), None if w is None else w.cuda(), loss_fn)
+    (loss * 0.7).backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - ref.item()) < 1e-5 * max(1.0, abs(ref.item()))
+    assert torch.allclose(td.cpu(), d.detach(), atol=1e-6)
+    assert torch.allclose(qh.grad.cpu(), qr.grad, atol=1e-7)
+    assert not td.requires_grad
