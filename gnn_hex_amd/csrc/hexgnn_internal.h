@@ -33,7 +33,10 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
 int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
                         int x_stride, const float* acts, const char* saved, const float* G, float* const* d_wl,
                         float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st,
-                        int math = 0, const unsigned* xmax = nullptr, const unsigned* gmax = nullptr);
+                        int math = 0, const unsigned* xmax = nullptr, const unsigned* gmax = nullptr,
+                        bool hidden_only_no_reduce = false);
+// hidden_only_no_reduce: leave the slice slabs in `part` and skip the raw first layer (the fused path reduces everything in
+// one launch and gets the first layer's per-graph partials from its backward kernel).
 // math 1: f16x3 split with per-layer power-of-two scales from xmax[l] = max |[agg_l | x_l]|, gmax[l] = max |G_l| (bit patterns)
 
 struct HeadSaved { size_t adv_off, pooled_off, amax_off, amin_off, z_off, v_off, total; };

@@ -26,6 +26,110 @@ int launch_qbwd_math(int nt, int math, const QBwdArgs& a, hipStream_t st) {
     return HEXGNN_OK;
 }
 
+
+// ---- ONE launch for every reduction that turns the backward's partial results into parameter gradients --------------
+// roles by block range (256 threads each):
+//   R0  hidden-layer dW / db: sum of the S row-slice slabs written by sage_dw(16)_kernel            (fixed order over s)
+//   R1  raw first layer dW / db: sum over graphs of the per-graph partials of qnet_bwd_kernel        (wave per output)
+//   R2  advantage Linear: sum over graphs of lin_part                                               (wave per output)
+//   R3  value MLP: d_v0_w = dz^T pooled, d_v0_b, d_v1_w, d_v1_b                                     (as head_value_wgrad_kernel)
+// Every sum has a fixed shape => bit-reproducible.  Replaces five launches of the layered path.
+struct GradReduceArgs {
+    float* dwl[kMaxLayers]; float* dbl[kMaxLayers]; float* dwr[kMaxLayers];   // hidden layers (index = hidden layer)
+    const float* part; int S, hp, H, nh, blk_per_layer;
+    const float* first_part; int b, c_in; float* dwl0; float* dbl0; float* dwr0;
+    const float* lin_part; float* d_lin_w; float* d_lin_b;
+    const float* dz; const float* dvr; const float* pooled; const float* z;
+    float* d_v0_w; float* d_v0_b; float* d_v1_w; float* d_v1_b;
+    int n0, n1, n2, n3, nbx3;
+};
+
+__device__ __forceinline__ float wsum_all(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(GradReduceArgs a) {
+    __shared__ float red[3][64];
+    int blk = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, hp = a.hp;
+    if (blk < a.n0) {                     // ---- R0
+        const int li = blk / a.blk_per_layer, idx = (blk % a.blk_per_layer) * 256 + tid;
+        const int per = 2 * H + 1;
+        if (idx >= H * per) return;
+        const int o = idx / per, c = idx % per;
+        const size_t slab_sz = (size_t)hp * (2 * hp + 1);
+        size_t off;
+        if (c < H) off = (size_t)o * 2 * hp + c;
+        else if (c < 2 * H) off = (size_t)o * 2 * hp + hp + (c - H);
+        else off = (size_t)hp * 2 * hp + o;
+        const float* p = a.part + (size_t)li * a.S * slab_sz + off;
+        float sum = 0.f;
+        for (int s = 0; s < a.S; ++s) sum += p[(size_t)s * slab_sz];
+        if (c < H) a.dwl[li][o * H + c] = sum;
+        else if (c < 2 * H) a.dwr[li][o * H + (c - H)] = sum;
+        else a.dbl[li][o] = sum;
+        return;
+    }
+    blk -= a.n0;
+    if (blk < a.n1) {                     // ---- R1
+        const int per = 2 * a.c_in + 1;
+        const int idx = blk * 4 + wave;
+        if (idx >= H * per) return;
+        const int o = idx / per, c = idx % per;
+        const int q = c < a.c_in ? c : (c < 2 * a.c_in ? kSmallCin + (c - a.c_in) : 2 * kSmallCin);
+        float sum = 0.f;
+        for (int g = lane; g < a.b; g += 64) sum += a.first_part[((size_t)g * 17 + q) * hp + o];
+        sum = wsum_all(sum);
+        if (lane == 0) {
+            if (c < a.c_in) a.dwl0[o * a.c_in + c] = sum;
+            else if (c < 2 * a.c_in) a.dwr0[o * a.c_in + (c - a.c_in)] = sum;
+            else a.dbl0[o] = sum;
+        }
+        return;
+    }
+    blk -= a.n1;
+    if (blk < a.n2) {                     // ---- R2
+        const int c = blk * 4 + wave;     // c in [0, H]  (H == bias)
+        if (c > H) return;
+        const int src = c < H ? c : hp;
+        float s = 0.f;
+        for (int g = lane; g < a.b; g += 64) s += a.lin_part[(size_t)g * (hp + 1) + src];
+        s = wsum_all(s);
+        if (lane == 0) { if (c < H) a.d_lin_w[c] = s; else a.d_lin_b[0] = s; }
+        return;
+    }
+    blk -= a.n2;
+    {                                     // ---- R3
+        const int H2 = H / 2, H4 = 4 * H;
+        const int bx = blk % a.nbx3, k = blk / a.nbx3;
+        const int cl = tid & 63, ph = tid >> 6;
+        const int c = bx * 64 + cl;
+        float s = 0.f;
+        if (c < H4) {
+#pragma unroll 8
+            for (int g = ph; g < a.b; g += 4) s += a.dz[(size_t)g * H2 + k] * a.pooled[(size_t)g * H4 + c];
+        }
+        if (ph > 0) red[ph - 1][cl] = s;
+        __syncthreads();
+        if (ph == 0 && c < H4) a.d_v0_w[(size_t)k * H4 + c] = s + red[0][cl] + red[1][cl] + red[2][cl];
+        if (bx == 0) {
+            float p = 0.f;
+            if (wave == 0) { for (int g = lane; g < a.b; g += 64) p += a.dz[(size_t)g * H2 + k]; }
+            else if (wave == 1) { for (int g = lane; g < a.b; g += 64) p += a.dvr[g] * a.z[(size_t)g * H2 + k]; }
+            else if (wave == 2 && k == 0) { for (int g = lane; g < a.b; g += 64) p += a.dvr[g]; }
+            p = wsum_all(p);
+            if (lane == 0) {
+                if (wave == 0) a.d_v0_b[k] = p;
+                else if (wave == 1) a.d_v1_w[k] = p;
+                else if (wave == 2 && k == 0) a.d_v1_b[0] = p;
+            }
+        }
+    }
+}
+
 }  // namespace hexgnn
 
 using namespace hexgnn;
@@ -37,7 +141,7 @@ struct QPlan {
     size_t head_saved_off, xmax_off, saved_total;
     BwdPlan bp;
     HeadWs hw;
-    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_gmax_off, ws_total;
+    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_gmax_off, ws_first_off, ws_total;
 };
 int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     int rc = make_plan(n, c_in, hidden, L, &q->sp);
@@ -56,6 +160,7 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     q->ws_part0_off = off; off += align_up(sizeof(float) * (size_t)q->bp.S0 * q->sp.hp * 17, 256);
     q->ws_head_off = off; off += q->hw.total;
     q->ws_gmax_off = align_up(off, 256); off = q->ws_gmax_off + sizeof(unsigned) * kMaxLayers;
+    q->ws_first_off = align_up(off, 256); off = q->ws_first_off + sizeof(float) * (size_t)(b > 0 ? b : 1) * 17 * q->sp.hp;
     q->ws_total = off;
     return HEXGNN_OK;
 }
@@ -169,6 +274,9 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.dadv = (float*)(hws + qp.hw.dadv_off); a.dz = (float*)(hws + qp.hw.dz_off);
     a.dvr = (float*)(hws + qp.hw.dvr_off); a.lin_part = (float*)(hws + qp.hw.part_off);
     a.status = status;
+    a.x = x; a.x_stride = x_stride; a.c_in = c_in;
+    a.agg0 = (const float*)(sv + qp.sp.agg_off[0]);
+    a.first_part = (float*)(ws + qp.ws_first_off);
     a.gmax = nullptr;
     if (math == 1) {
         a.gmax = (unsigned*)(ws + qp.ws_gmax_off);
@@ -189,14 +297,30 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
         (void)hipMemsetAsync(a.dz, 0, sizeof(float) * (size_t)(b > 0 ? b : 1) * (hidden / 2), st);
         (void)hipMemsetAsync(a.dvr, 0, sizeof(float) * (size_t)(b > 0 ? b : 1), st);
     }
-    if (n > 0) {
+    if (n > 0 && b > 0) {
         rc = launch_weight_grads(n, c_in, hidden, qp.sp, qp.bp, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part,
-                                 part0, st, math, (const unsigned*)(sv + qp.xmax_off), a.gmax);
+                                 part0, st, math, (const unsigned*)(sv + qp.xmax_off), a.gmax, /*hidden_only_no_reduce=*/true);
         if (rc != HEXGNN_OK) return rc;
+        GradReduceArgs r;
+        const int nh = total_layers - 1;
+        for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[i + 1]; r.dbl[i] = d_bl[i + 1]; r.dwr[i] = d_wr[i + 1]; }
+        r.part = part; r.S = qp.bp.S; r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
+        r.blk_per_layer = (hidden * (2 * hidden + 1) + 255) / 256;
+        r.first_part = a.first_part; r.b = b; r.c_in = c_in; r.dwl0 = d_wl[0]; r.dbl0 = d_bl[0]; r.dwr0 = d_wr[0];
+        r.lin_part = a.lin_part; r.d_lin_w = d_lin_w; r.d_lin_b = d_lin_b;
+        r.dz = a.dz; r.dvr = a.dvr; r.pooled = (const float*)(hsv + qp.hs.pooled_off); r.z = (const float*)(hsv + qp.hs.z_off);
+        r.d_v0_w = d_v0_w; r.d_v0_b = d_v0_b; r.d_v1_w = d_v1_w; r.d_v1_b = d_v1_b;
+        r.n0 = nh * r.blk_per_layer;
+        r.n1 = (hidden * (2 * c_in + 1) + 3) / 4;
+        r.n2 = (hidden + 1 + 3) / 4;
+        r.nbx3 = (4 * hidden + 63) / 64;
+        r.n3 = (mode != 2 && hidden / 2 > 0) ? r.nbx3 * (hidden / 2) : 0;
+        qnet_grad_reduce_kernel<<<r.n0 + r.n1 + r.n2 + r.n3, 256, 0, st>>>(r);
+    } else {
+        launch_head_param_grads(b, hidden, mode, a.dz, a.dvr, (const float*)(hsv + qp.hs.pooled_off),
+                                (const float*)(hsv + qp.hs.z_off), a.lin_part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w,
+                                d_v1_b, st);
     }
-    launch_head_param_grads(b, hidden, mode, a.dz, a.dvr, (const float*)(hsv + qp.hs.pooled_off),
-                            (const float*)(hsv + qp.hs.z_off), a.lin_part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w,
-                            d_v1_b, st);
     return check_launch();
 }
 

@@ -45,6 +45,8 @@ struct QBwdArgs {
     float* dadv; float* dz; float* dvr; float* lin_part;
     int* status;
     unsigned* gmax;   // [L] bit patterns of max |G_l| per layer (math 1)
+    // raw first layer: per-graph partial weight gradient [b][17][HP] = G_0^T [agg0(8) | x0(8) | 1] (null: not produced)
+    const float* x; int x_stride; int c_in; const float* agg0; float* first_part;
 };
 
 template <int NT> struct QLds {
@@ -61,11 +63,14 @@ template <int NT> struct QLds {
     // large enough (NT >= 4), otherwise a region of its own (small widths leave plenty of LDS)
     static constexpr bool scr_alias = NT >= 4;
     static constexpr int scr_bytes = 16384;
+    static constexpr int scr0_bytes = kRows * 48 * 4;   // backward: [rows][48] raw first-layer inputs (MFMA operand)
     static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_max + 64;   // half B
     static constexpr int off_scr_tail = scr_alias ? off_w : off_max + 64;
-    static constexpr int total = off_max + 64 + (scr_alias ? 0 : scr_bytes);
+    static constexpr int off_scr_bwd0 = scr_alias ? off_w : off_max + 64;
+    static constexpr int total = off_max + 64 + (scr_alias ? 0 : (scr0_bytes > scr_bytes ? scr0_bytes : scr_bytes));
     static_assert(col_cap >= 1024 && total <= kLdsBytes, "LDS budget");
     static_assert(!scr_alias || kHalf * 16 >= scr_bytes, "scratch must fit one weight half");
+    static_assert(!scr_alias || 2 * kHalf * 16 >= scr0_bytes, "first-layer scratch must fit the weight halves");
 };
 
 __device__ __forceinline__ float wsum64(float v) {
@@ -858,6 +863,48 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) v[q4] = yv[q4] > 0.f ? v[q4] : 0.f;
             go[4 * t] = v;
+            gx[t] = v;
+        }
+    }
+    // ---- raw first layer: this graph's share of dW_0 = G_0^T [agg0 | x0 | 1], reduced over the graphs afterwards ----
+    if (a.first_part) {
+        __syncthreads();             // every wave's last gather is done: dbuf and the weight halves are free
+        // F = [agg0(8) | x0(8) | 1 | 0...] per row, 48-float rows (stride == 16 mod 32: conflict-free fragment reads)
+        float* s_f = reinterpret_cast<float*>(lds + LD::off_scr_bwd0);
+        {
+            f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dr[4 * t] = rvalid ? gx[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        if (tid < kRows) {
+            f32x4* fr = reinterpret_cast<f32x4*>(s_f + tid * 48);
+            f32x4 a0 = f32x4{0.f, 0.f, 0.f, 0.f}, a1 = a0, x0 = a0, x1 = a0, one = a0;
+            if (tid < cnt) {
+                const f32x4* ar = reinterpret_cast<const f32x4*>(a.agg0 + (size_t)(r0 + tid) * kSmallCin);
+                a0 = ar[0]; a1 = ar[1];
+                const float* xr = a.x + (size_t)(r0 + tid) * a.x_stride;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { x0[q] = q < a.c_in ? xr[q] : 0.f; x1[q] = 4 + q < a.c_in ? xr[4 + q] : 0.f; }
+                one[0] = 1.f;
+            }
+            fr[0] = a0; fr[1] = a1; fr[2] = x0; fr[3] = x1; fr[4] = one;
+            fr[5] = f32x4{0.f, 0.f, 0.f, 0.f}; fr[6] = fr[5]; fr[7] = fr[5];
+        }
+        __syncthreads();
+        if (wave < NT) {
+            // dW_0^T tile [c (2 x 16)][o = 16 wave ..] = F^T G_0 over the 128 rows: exact fp32 MFMA, two interleaved chains
+            f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+#pragma unroll 8
+            for (int k = 0; k < kRows / 4; ++k) {
+                const int row = 4 * k + g;
+                const float bv = dbuf[row * XS + 16 * wave + r];
+                acc0 = mfma16x16x4(s_f[row * 48 + r], bv, acc0);
+                acc1 = mfma16x16x4(s_f[row * 48 + 16 + r], bv, acc1);
+            }
+            float* out = a.first_part + (size_t)gi * 17 * HP + 16 * wave + r;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) out[(size_t)(4 * g + j) * HP] = acc0[j];
+            if (g == 0) out[(size_t)16 * HP] = acc1[0];
         }
     }
 }

@@ -858,7 +858,7 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
 int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
                         int x_stride, const float* acts, const char* sv, const float* G, float* const* d_wl,
                         float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st,
-                        int math, const unsigned* xmax, const unsigned* gmax) {
+                        int math, const unsigned* xmax, const unsigned* gmax, bool hidden_only_no_reduce) {
     const size_t slab = (size_t)n * p.hp;
     const int first_hidden = p.small_first ? 1 : 0;
     const int nh = p.L - first_hidden;
@@ -884,9 +884,9 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
             HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
         }
         const int tot = hidden * (2 * hidden + 1);
-        sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
+        if (!hidden_only_no_reduce) sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
     }
-    if (p.small_first) {
+    if (p.small_first && !hidden_only_no_reduce) {
         sage_first_dw_kernel<<<b.S0, 256, 0, st>>>(n, c_in, p.hp, b.rps0, G, (const float*)(sv + p.agg_off[0]), x,
                                                    x_stride, part0);
         const int tot = hidden * (2 * c_in + 1);
