@@ -25,10 +25,11 @@ struct BwdPlan {
     int S0, rps0;   // raw first layer: many small slices (VALU kernel, one pass over G)
 };
 void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b);
+int dw_slices_for(int n, int hidden_layers, int math);   // slices the weight-gradient launch actually uses (<= BwdPlan::S)
 
 // pack all layers of a stack (forward + backward fragment order, padded bias) -- one launch
 int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
-                const float* const* wr, void* wpack, hipStream_t st, int math = 0);
+                const float* const* wr, void* wpack, hipStream_t st, int math = 0, unsigned* zero_maxima = nullptr);
 // batched weight-gradient GEMM + reductions for all layers of a stack, given G (per-layer masked output gradients)
 int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
                         int x_stride, const float* acts, const char* saved, const float* G, float* const* d_wl,

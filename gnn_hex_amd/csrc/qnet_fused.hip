@@ -141,7 +141,7 @@ struct QPlan {
     size_t head_saved_off, xmax_off, saved_total;
     BwdPlan bp;
     HeadWs hw;
-    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_gmax_off, ws_first_off, ws_total;
+    size_t ws_g_off, ws_part_off, ws_part0_off, ws_head_off, ws_first_off, ws_total;
 };
 int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     int rc = make_plan(n, c_in, hidden, L, &q->sp);
@@ -150,7 +150,7 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     q->hs = head_saved_plan(n, b, hidden);
     q->head_saved_off = align_up(q->sp.saved_bytes, 256);
     q->xmax_off = align_up(q->head_saved_off + q->hs.total, 256);     // per-layer maxima (math 1), kMaxLayers words
-    q->saved_total = q->xmax_off + sizeof(unsigned) * kMaxLayers;
+    q->saved_total = q->xmax_off + 2 * sizeof(unsigned) * kMaxLayers;   // xmax[kMaxLayers] then gmax[kMaxLayers]
     make_bwd_plan(n, q->sp, &q->bp);
     q->hw = head_ws_plan(n, b, hidden);
     const size_t slab = align_up(sizeof(float) * (size_t)n * q->sp.hp, 256);
@@ -159,7 +159,6 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     q->ws_part_off = off; off += align_up(sizeof(float) * (size_t)L * q->bp.S * q->sp.hp * (2 * q->sp.hp + 1), 256);
     q->ws_part0_off = off; off += align_up(sizeof(float) * (size_t)q->bp.S0 * q->sp.hp * 17, 256);
     q->ws_head_off = off; off += q->hw.total;
-    q->ws_gmax_off = align_up(off, 256); off = q->ws_gmax_off + sizeof(unsigned) * kMaxLayers;
     q->ws_first_off = align_up(off, 256); off = q->ws_first_off + sizeof(float) * (size_t)(b > 0 ? b : 1) * 17 * q->sp.hp;
     q->ws_total = off;
     return HEXGNN_OK;
@@ -196,7 +195,9 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     if (mode == 1 && !out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts || !q)) return HEXGNN_EINVAL;
     if (x_stride < c_in) return HEXGNN_EINVAL;
-    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st, math);
+    // math 1 + backward: the pack's scale kernel also zeroes the per-layer maxima (xmax | gmax) kept behind the saved tensors
+    unsigned* maxima = (math == 1 && need_backward) ? (unsigned*)((char*)saved + qp.xmax_off) : nullptr;
+    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st, math, maxima);
     if (rc != HEXGNN_OK) return rc;
     if (b == 0) return check_launch();
     QFwdArgs a;
@@ -214,11 +215,7 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     a.amax = (int*)(hsv + qp.hs.amax_off); a.amin = (int*)(hsv + qp.hs.amin_off);
     a.z = (float*)(hsv + qp.hs.z_off); a.vraw = (float*)(hsv + qp.hs.v_off);
     a.q = q; a.out_v = out_v; a.status = status;
-    a.xmax = nullptr;
-    if (math == 1 && need_backward) {
-        a.xmax = (unsigned*)((char*)saved + qp.xmax_off);
-        (void)hipMemsetAsync(a.xmax, 0, sizeof(unsigned) * kMaxLayers, st);
-    }
+    a.xmax = maxima;
     {
         KernelTimer kt(HEXGNN_K_QNET_FWD, st);
         rc = launch_qfwd_math(qp.sp.nt, math, a, st);
@@ -277,11 +274,9 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     a.x = x; a.x_stride = x_stride; a.c_in = c_in;
     a.agg0 = (const float*)(sv + qp.sp.agg_off[0]);
     a.first_part = (float*)(ws + qp.ws_first_off);
-    a.gmax = nullptr;
-    if (math == 1) {
-        a.gmax = (unsigned*)(ws + qp.ws_gmax_off);
-        (void)hipMemsetAsync(a.gmax, 0, sizeof(unsigned) * kMaxLayers, st);
-    }
+    // max |G_l| per layer (math 1): lives behind the forward's saved tensors, zeroed by the forward; a backward pass
+    // repeated on the same saved state only re-maxes identical values
+    a.gmax = math == 1 ? (unsigned*)(const_cast<char*>(sv) + qp.xmax_off) + kMaxLayers : nullptr;
     if (b > 0 && n > 0) {
         KernelTimer kt(HEXGNN_K_QNET_BWD, st);
         rc = launch_qbwd_math(qp.sp.nt, math, a, st);
@@ -304,7 +299,7 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
         GradReduceArgs r;
         const int nh = total_layers - 1;
         for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[i + 1]; r.dbl[i] = d_bl[i + 1]; r.dwr[i] = d_wr[i + 1]; }
-        r.part = part; r.S = qp.bp.S; r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
+        r.part = part; r.S = dw_slices_for(n, nh, math); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
         r.blk_per_layer = (hidden * (2 * hidden + 1) + 255) / 256;
         r.first_part = a.first_part; r.b = b; r.c_in = c_in; r.dwl0 = d_wl[0]; r.dbl0 = d_bl[0]; r.dwr0 = d_wr[0];
         r.lin_part = a.lin_part; r.d_lin_w = d_lin_w; r.d_lin_b = d_lin_b;

@@ -109,25 +109,28 @@ struct Pack16Args {
     LayerPtrs p;
     size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers], bias_off[kMaxLayers];
     int nt, L, hidden, first_hidden, hp;
+    unsigned* zero_maxima;    // 2*kMaxLayers words cleared by the scale kernel (per-layer activation / gradient maxima), or null
 };
 __device__ __forceinline__ unsigned short f16_bits(float v) { _Float16 b = (_Float16)v; return __builtin_bit_cast(unsigned short, b); }
 __device__ __forceinline__ float f16_to_f32(unsigned short u) { return (float)__builtin_bit_cast(_Float16, u); }
 
 // per hidden layer: s_W = 2^(14 - floor(log2 max|w|)) over W_l and W_r, stored with its inverse after the padded bias
-__global__ __launch_bounds__(256) void sage_wscale_kernel(Pack16Args a, char* __restrict__ wpack) {
+__global__ __launch_bounds__(1024) void sage_wscale_kernel(Pack16Args a, char* __restrict__ wpack) {
     const int l = a.first_hidden + blockIdx.x;
     const int H = a.hidden;
     const float* wl = a.p.wl[l];
     const float* wr = a.p.wr[l];
+    if (blockIdx.x == 0 && a.zero_maxima && threadIdx.x < 2 * kMaxLayers) a.zero_maxima[threadIdx.x] = 0u;
     float m = 0.f;
-    for (int i = threadIdx.x; i < H * H; i += 256) m = fmaxf(m, fmaxf(fabsf(wl[i]), fabsf(wr[i])));
+    for (int i = threadIdx.x; i < H * H; i += 1024) m = fmaxf(m, fmaxf(fabsf(wl[i]), fabsf(wr[i])));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    __shared__ float sm[4];
+    __shared__ float sm[16];
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
     __syncthreads();
     if (threadIdx.x == 0) {
-        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+#pragma unroll
+        for (int w = 1; w < 16; ++w) m = fmaxf(m, sm[w]);
         const unsigned e = __builtin_bit_cast(unsigned, m) >> 23;
         const bool ok = e >= 64u && e <= 190u;
         float* out = reinterpret_cast<float*>(wpack + a.bias_off[l]) + a.hp;
@@ -804,10 +807,22 @@ static void launch_dw16(const Dw16Args& a, int layers, float* part, hipStream_t 
         default: return HEXGNN_EUNSUPPORTED;       \
     }
 
-static int dw_slices(int n) {
+// Row slices per layer of the batched weight-gradient GEMM.  Exact fp32 (MFMA-bound, one workgroup per CU): ~1024-row
+// slices, two rounds of workgroups overlap each other's staging.  Split f16 (HBM-bound): (slices x hidden layers) fills the
+// 256 CUs in ONE round and halves the slab traffic of the reduce.  The plan sizes its workspace for the larger count.
+static int dw_slices_fp32(int n) {
     int s = (n + 1023) / 1024;
     if (s < 1) s = 1;
     if (s > 64) s = 64;
+    return s;
+}
+int dw_slices_for(int n, int hidden_layers, int math) {
+    const int s0 = dw_slices_fp32(n);
+    if (math != 1) return s0;
+    int s = 256 / (hidden_layers > 0 ? hidden_layers : 1);
+    if (s > n / 256) s = n / 256;
+    if (s > s0) s = s0;
+    if (s < 1) s = 1;
     return s;
 }
 static int dw_rows_per_slice(int n, int S) {
@@ -820,7 +835,7 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     size_t off = 0;
     b->g_off = off; off += slab * p.L;
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { b->pair_off[i][j] = off; off += slab; }
-    b->S = dw_slices(n);
+    b->S = dw_slices_fp32(n);
     b->rps = dw_rows_per_slice(n, b->S);
     b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * b->S * p.hp * (2 * p.hp + 1), 256);
     b->rps0 = 128;
@@ -830,7 +845,7 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
 }
 
 int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
-                const float* const* wr, void* wpack, hipStream_t st, int math) {
+                const float* const* wr, void* wpack, hipStream_t st, int math, unsigned* zero_maxima) {
     PackArgs pa;
     for (int l = 0; l < p.L; ++l) {
         if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
@@ -845,10 +860,11 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
         pb.p = pa.p;
         for (int l = 0; l < p.L; ++l) { pb.fwd_off[l] = p.fwd_off[l]; pb.bwd_off[l] = p.bwd_off[l]; pb.bias_off[l] = p.bias_off[l]; }
         pb.nt = p.nt; pb.L = p.L; pb.hidden = hidden; pb.first_hidden = p.small_first ? 1 : 0; pb.hp = p.hp;
+        pb.zero_maxima = zero_maxima;
         const int nh = p.L - pb.first_hidden;
         const int elems = 2 * 2 * p.nt * p.nt * 256;
         if (nh > 0) {
-            sage_wscale_kernel<<<nh, 256, 0, st>>>(pb, (char*)wpack);
+            sage_wscale_kernel<<<nh, 1024, 0, st>>>(pb, (char*)wpack);
             sage_pack16_kernel<<<dim3((elems + 255) / 256, nh), 256, 0, st>>>(pb, (char*)wpack);
         }
     }
@@ -872,13 +888,15 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
             da.g[i] = G + slab * l;
             ra.dwl[i] = d_wl[l]; ra.dbl[i] = d_bl[l]; ra.dwr[i] = d_wr[l];
         }
-        da.n = n; da.rows_per_slice = b.rps; da.S = b.S;
-        ra.S = b.S; ra.hp = p.hp; ra.hidden = hidden;
+        const int S = dw_slices_for(n, nh, (math == 1 && xmax && gmax) ? 1 : 0);
+        const int rps = dw_rows_per_slice(n, S);
+        da.n = n; da.rows_per_slice = rps; da.S = S;
+        ra.S = S; ra.hp = p.hp; ra.hidden = hidden;
         if (math == 1 && xmax && gmax) {
             Dw16Args d16;
             for (int i = 0; i < nh; ++i) { d16.xin[i] = da.xin[i]; d16.agg[i] = da.agg[i]; d16.g[i] = da.g[i]; }
             d16.xmax = xmax; d16.gmax = gmax; d16.first_hidden = first_hidden;
-            d16.n = n; d16.rows_per_slice = b.rps; d16.S = b.S;
+            d16.n = n; d16.rows_per_slice = rps; d16.S = S;
             HEXGNN_NT_SWITCH(p.nt, (launch_dw16<NT_>(d16, nh, part, st)));
         } else {
             HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));

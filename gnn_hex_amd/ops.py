@@ -321,6 +321,7 @@ class QNetFusedFn(torch.autograd.Function):
     def forward(ctx, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
                 head_layers: int, mode: int, grad_sink, *params):
         L = _lib.lib()
+        ctx.set_materialize_grads(False)      # unused outputs (embeds, V) arrive as None instead of freshly zeroed tensors
         dev = x.device
         n = int(x.shape[0])
         hp = padded_width(hidden)
@@ -417,6 +418,7 @@ class TdLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, sel, target, weights, loss_fn: int):
         L = _lib.lib()
+        ctx.set_materialize_grads(False)
         dev = q.device
         qf = q.reshape(-1)
         if qf.dtype != torch.float32 or not qf.is_contiguous():
@@ -439,6 +441,8 @@ class TdLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gloss, _gtd):
+        if gloss is None:
+            return None, None, None, None, None
         sel, td, w = ctx.saved_tensors
         n = 1
         for d in ctx.shape:
