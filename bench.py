@@ -264,20 +264,36 @@ def selfplay(args, num_layers, hidden, label, dev):
         vert, _, _ = mgr.select_actions(adv, obs, eps=0.05)
         return mgr.step(vert)[0]
 
-    for _ in range(args.warmup):
-        obs = one(obs)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        obs = one(obs)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    if args.graph:
+        # device-resident rollout: 16 moves of every env per HIP-graph launch, one read-back per launch
+        from gnn_hex_amd.multi_env_manager import DeviceRollout
+        chunk = 16
+        ro = DeviceRollout(mgr, hip, steps=chunk, eps=0.05, graph=True)
+        launches_w, launches = max(1, args.warmup // chunk), max(1, args.steps // chunk)
+        for _ in range(launches_w):
+            ro.run()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(launches):
+            ro.run()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        args.steps = launches * chunk
+    else:
+        for _ in range(args.warmup):
+            obs = one(obs)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            obs = one(obs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
     out = {"metric": "self-play frames/sec (env step + observation + Q forward + action selection)",
            "value": args.envs * args.steps / dt, "unit": "frames/s", "n_gpus": 1, "steps": args.steps,
            "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
            "vs_baseline": None, "dtype": "f32", "data": "synthetic (self-generated games)",
            "config": {"workload": "%s acting, Hex-%d, %d parallel envs" % (label.split(" batch")[0], size, args.envs),
-                      "parallelism": "dp1"}}
+                      "parallelism": "dp1", "hip_graph": bool(args.graph), "math": args.math}}
     print(json.dumps(out))
     return out
 

@@ -55,6 +55,8 @@ _SIGS = {
     "hexgnn_env_step": (ci, [vp, vp, ci, ci, ci, vp, vp]),
     "hexgnn_env_observe": (ci, [vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_env_export": (ci, [vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_env_offsets": (ci, [ci, vp, vp, vp, vp]),
+    "hexgnn_env_import": (ci, [vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_states_observe": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_per_init": (ci, [ci, vp, vp, vp]),
     "hexgnn_per_update": (ci, [ci, ci, vp, vp, vp, vp, vp]),

@@ -521,6 +521,23 @@ __global__ void env_export_kernel(EnvDev d, uint64_t* __restrict__ adj, uint8_t*
     }
 }
 
+// inverse of env_export_kernel: overwrite the whole env state (checkpoint restore, rollback after a captured warm-up)
+__global__ void env_import_kernel(EnvDev d, const uint64_t* __restrict__ adj, const uint8_t* __restrict__ alive,
+                                  const int* __restrict__ maker_turn, const int* __restrict__ total_moves,
+                                  const short* __restrict__ resp_maker, const short* __restrict__ resp_breaker) {
+    const size_t tot = (size_t)d.num_envs * d.nv;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot * d.W; i += (size_t)gridDim.x * blockDim.x) d.adj[i] = adj[i];
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < tot; i += (size_t)gridDim.x * blockDim.x) {
+        d.alive[i] = alive[i];
+        d.resp_maker[i] = resp_maker[i];
+        d.resp_breaker[i] = resp_breaker[i];
+    }
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < d.num_envs; i += gridDim.x * blockDim.x) {
+        d.maker_turn[i] = maker_turn[i];
+        d.total_moves[i] = total_moves[i];
+    }
+}
+
 __global__ void env_set_turn_kernel(EnvDev d, int maker_turn) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < d.num_envs) d.maker_turn[i] = maker_turn;
@@ -537,6 +554,27 @@ static size_t env_lds_bytes(const EnvDev& d) {
 }  // namespace hexgnn
 
 using namespace hexgnn;
+
+// exclusive prefix sums of the per-env graph sizes a step reported (result[env] = {winner, moves, nodes, edges, illegal}):
+// the batched observation's node / edge offsets stay on the device, so a rollout never reads sizes back
+__global__ __launch_bounds__(64) void env_offsets_kernel(int k, const int* __restrict__ result, int* __restrict__ node_off,
+                                                         int* __restrict__ edge_off) {
+    const int lane = threadIdx.x;
+    int run_n = 0, run_e = 0;
+    for (int base = 0; base < k; base += 64) {
+        const int i = base + lane;
+        const int vn = i < k ? result[i * 5 + 2] : 0, ve = i < k ? result[i * 5 + 3] : 0;
+        int pn = vn, pe = ve;
+        for (int off = 1; off < 64; off <<= 1) {
+            const int a = __shfl_up(pn, off), b = __shfl_up(pe, off);
+            if (lane >= off) { pn += a; pe += b; }
+        }
+        if (i < k) { node_off[i] = run_n + pn - vn; edge_off[i] = run_e + pe - ve; }
+        run_n += __shfl(pn, 63);
+        run_e += __shfl(pe, 63);
+    }
+    if (lane == 0) { node_off[k] = run_n; edge_off[k] = run_e; }
+}
 
 extern "C" {
 
@@ -673,6 +711,21 @@ int hexgnn_states_observe(int hex_size, int k, const uint64_t* adj, const uint8_
     src.adj = adj; src.alive = alive; src.maker_turn = nullptr; src.side_u8 = side; src.index = index;
     env_observe_kernel<<<k, 64, env_lds_bytes(tmp), (hipStream_t)stream_>>>(
         src, node_off, edge_off, x, backmap, edge_local, edge_global, e_total, rowptr, col, invdeg, batch_vec, 1);
+    return check_launch();
+}
+
+int hexgnn_env_import(hexgnn_env* h, const uint64_t* adj, const uint8_t* alive, const int* maker_turn,
+                      const int* total_moves, const int16_t* resp_maker, const int16_t* resp_breaker, hexgnn_stream_t stream_) {
+    if (!h || !adj || !alive || !maker_turn || !total_moves || !resp_maker || !resp_breaker) return HEXGNN_EINVAL;
+    Env* e = reinterpret_cast<Env*>(h);
+    env_import_kernel<<<64, 256, 0, (hipStream_t)stream_>>>(e->d, adj, alive, maker_turn, total_moves,
+                                                          (const short*)resp_maker, (const short*)resp_breaker);
+    return check_launch();
+}
+
+int hexgnn_env_offsets(int k, const int* result, int* node_off, int* edge_off, hexgnn_stream_t stream_) {
+    if (k < 0 || !node_off || !edge_off || (k > 0 && !result)) return HEXGNN_EINVAL;
+    env_offsets_kernel<<<1, 64, 0, (hipStream_t)stream_>>>(k, result, node_off, edge_off);
     return check_launch();
 }
 

@@ -88,6 +88,179 @@ class TransitionBlock:
         return int(self.env.shape[0])
 
 
+class SnapObs(ObsList):
+    """An observation known only as board snapshots + graph sizes (what a device rollout records per step).  It carries
+    everything the replay path needs (``snapshot()``, ``node_off`` / ``edge_off``, ``is_maker``); the ``Data`` views of
+    an ``ObsList`` are not materialised."""
+
+    def __init__(self, snap, sizes: np.ndarray, is_maker: bool):
+        node_off = np.zeros(sizes.shape[0] + 1, dtype=np.int64)
+        edge_off = np.zeros(sizes.shape[0] + 1, dtype=np.int64)
+        np.cumsum(sizes[:, 0], out=node_off[1:])
+        np.cumsum(sizes[:, 1], out=edge_off[1:])
+        super().__init__(None, None, None, None, None, node_off.tolist(), edge_off.tolist(), None, is_maker,
+                         int(sizes[:, 0].max()) if sizes.shape[0] else 0, snap)
+
+    def __getitem__(self, i):
+        raise TypeError("a rollout observation holds board snapshots only; re-observe it through GraphReplayBuffer")
+
+    def to_batch(self):
+        raise TypeError("a rollout observation holds board snapshots only; re-observe it through GraphReplayBuffer")
+
+
+class RolloutResult:
+    """Histories of one ``DeviceRollout.run()``: ``states[0]`` is the observation the first move was chosen from,
+    ``states[t+1]`` the one after move ``t``; ``actions`` are node ranks inside ``states[t]`` (the model's output index,
+    what the reference stores), ``vertices`` the vertex ids played.  Host arrays; the snapshots stay on the device."""
+
+    def __init__(self, states, actions, vertices, rewards, dones, exploratories, infos):
+        self.states, self.actions, self.vertices = states, actions, vertices
+        self.rewards, self.dones, self.exploratories, self.infos = rewards, dones, exploratories, infos
+
+
+class DeviceRollout:
+    """``steps`` lock-step moves of every env of an ``Env_manager`` as a closed device loop: observation (HIP builder) ->
+    Q-network forward (advantages only) -> epsilon-greedy -> env step with dead/captured removal and auto reset -> graph
+    sizes prefix-summed on the device -> board snapshot.  Nothing is read back between the moves; with ``graph=True`` the
+    whole sequence is ONE HIP graph (``gnn_hex_amd.graphs``), so a rollout costs one launch + one read-back.  The
+    reference does this with a Python loop over envs per move (graph_game/multi_env_manager.py:76-103 +
+    GN0/RainbowDQN/evaluate_elo.py:253-275).  ``steps`` must be even so the side to move is the same before and after;
+    the model's weights are read at run time (training between runs is fine, ``grow_*`` needs a new rollout)."""
+
+    def __init__(self, mgr: "Env_manager", model, steps: int = 16, eps: float = 0.05, graph: bool = True):
+        if steps < 2 or steps % 2:
+            raise ValueError("steps must be a positive even number")
+        self.mgr, self.model, self.T, self.eps = mgr, model, steps, float(eps)
+        self.start_side = mgr.global_onturn
+        dev = mgr.device
+        k, nv, W = mgr.num_envs, mgr._nv, mgr._words
+        e_max = int(mgr._base_sizes[0, 1])
+        N, E = k * nv, k * e_max
+        self.x = torch.zeros((N, 3), dtype=torch.float32, device=dev)
+        self.backmap = torch.zeros(N, dtype=torch.long, device=dev)
+        self.batch_vec = torch.zeros(N, dtype=torch.long, device=dev)
+        self.edge_local = torch.zeros((2, E), dtype=torch.long, device=dev)
+        self.edge_global = torch.zeros((2, E), dtype=torch.long, device=dev)
+        rowptr = torch.zeros(N + 1, dtype=torch.int32, device=dev)
+        col = torch.zeros(E, dtype=torch.int32, device=dev)
+        invdeg = torch.ones(N, dtype=torch.float32, device=dev)
+        self.gs = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
+        self.node_off = torch.zeros(k + 1, dtype=torch.int32, device=dev)
+        self.edge_off = torch.zeros(k + 1, dtype=torch.int32, device=dev)
+        T = steps
+        self.vert = torch.zeros((T, k), dtype=torch.int32, device=dev)
+        self.rank = torch.zeros((T, k), dtype=torch.int32, device=dev)
+        self.expl = torch.zeros((T, k), dtype=torch.uint8, device=dev)
+        self.result = torch.zeros((T, k, 5), dtype=torch.int32, device=dev)
+        self.uni = torch.zeros((T, k, 2), dtype=torch.float32, device=dev)
+        self.adj = torch.zeros((T + 1, k, nv, W), dtype=torch.int64, device=dev)
+        self.alive = torch.zeros((T + 1, k, nv), dtype=torch.uint8, device=dev)
+        self._mt = torch.zeros(k, dtype=torch.int32, device=dev)
+        self._tm = torch.zeros(k, dtype=torch.int32, device=dev)
+        self._graph = None
+        if graph:
+            from .graphs import GraphedStep
+            self._upload_offsets()
+            state = self.mgr._state_tensors()
+            self._graph = GraphedStep(self._body, warmup=1)
+            self.mgr._restore_state_tensors(state)      # warm-up + capture played moves: put the boards back
+
+    # -- pieces ----------------------------------------------------------------------------------------
+    def _upload_offsets(self):
+        sizes = self.mgr._sizes
+        k = self.mgr.num_envs
+        off = np.zeros(2 * (k + 1), dtype=np.int32)
+        np.cumsum(sizes[:, 0], out=off[1:k + 1])
+        np.cumsum(sizes[:, 1], out=off[k + 2:])
+        t = torch.from_numpy(off).to(self.mgr.device)
+        self.node_off.copy_(t[:k + 1])
+        self.edge_off.copy_(t[k + 1:])
+
+    def _export(self, slot: int):
+        _lib.check(_lib.lib().hexgnn_env_export(self.mgr._h, self.adj[slot].data_ptr(), self.alive[slot].data_ptr(),
+                                               self._mt.data_ptr(), self._tm.data_ptr(), None, None, ops._stream()),
+                   "hexgnn_env_export")
+
+    def _body(self):
+        L = _lib.lib()
+        mgr, k = self.mgr, self.mgr.num_envs
+        E = int(self.edge_global.shape[1])
+        self._export(0)
+        maker = self.start_side == "m"
+        for t in range(self.T):
+            _lib.check(L.hexgnn_env_observe(mgr._h, self.node_off.data_ptr(), self.edge_off.data_ptr(), E,
+                                            self.x.data_ptr(), self.backmap.data_ptr(), self.edge_local.data_ptr(),
+                                            self.edge_global.data_ptr(), self.gs.rowptr.data_ptr(), self.gs.col.data_ptr(),
+                                            self.gs.invdeg.data_ptr(), self.batch_vec.data_ptr(), ops._stream()),
+                       "hexgnn_env_observe")
+            x = self.x.view(self.x.shape)       # fresh tensor object per step: the hints below differ per side
+            x._hex_is_maker = maker
+            x._hex_max_nodes = mgr._nv
+            ei = self.edge_global.view(self.edge_global.shape)
+            ei._hex_csr = self.gs
+            with torch.no_grad():
+                adv = self.model(x, ei, self.batch_vec, self.node_off, advantages_only=True)
+            u = None
+            if self.eps > 0:
+                u = self.uni[t]
+                u.uniform_()
+            _lib.check(L.hexgnn_select_actions(k, self.node_off.data_ptr(), adv.reshape(-1).data_ptr(),
+                                               self.backmap.data_ptr(), self.eps, u.data_ptr() if u is not None else None,
+                                               self.vert[t].data_ptr(), self.rank[t].data_ptr(), self.expl[t].data_ptr(),
+                                               ops._stream()), "hexgnn_select_actions")
+            # finished envs restart on the side everyone moves to next (multi_env_manager.py:98-101)
+            _lib.check(L.hexgnn_env_step(mgr._h, self.vert[t].data_ptr(), 1, 1, int(not maker), self.result[t].data_ptr(),
+                                         ops._stream()), "hexgnn_env_step")
+            _lib.check(L.hexgnn_env_offsets(k, self.result[t].data_ptr(), self.node_off.data_ptr(),
+                                            self.edge_off.data_ptr(), ops._stream()), "hexgnn_env_offsets")
+            self._export(t + 1)
+            maker = not maker
+
+    # -- public ----------------------------------------------------------------------------------------
+    def run(self) -> RolloutResult:
+        mgr = self.mgr
+        if mgr.global_onturn != self.start_side:
+            raise RuntimeError("this rollout was built with %r to move" % self.start_side)
+        sizes0 = mgr._sizes.copy()
+        self._upload_offsets()
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._body()
+        res = self.result.cpu().numpy()                      # the only read-back (also the synchronisation point)
+        if res[:, :, 4].any():
+            t, i = np.argwhere(res[:, :, 4])[0]
+            raise ValueError("illegal action at step %d for env %d" % (t, i))
+        ranks = self.rank.cpu().numpy().astype(np.int64)
+        verts = self.vert.cpu().numpy().astype(np.int64)
+        expl = self.expl.cpu().numpy().astype(bool)
+        T, k = self.T, mgr.num_envs
+        dones = res[:, :, 0] >= 0
+        rewards = np.zeros((T, k), dtype=float)
+        infos = [[{} for _ in range(k)] for _ in range(T)]
+        now = time.perf_counter()
+        maker = self.start_side == "m"
+        states = [SnapObs((self.adj[0], self.alive[0]), sizes0, maker)]
+        for t in range(T):
+            mover_is_maker = maker
+            for i in np.nonzero(dones[t])[0]:
+                winner_is_maker = res[t, i, 0] == 0
+                n = int(res[t, i, 1])
+                infos[t][i]["episode_metrics"] = {
+                    "return": 1 if winner_is_maker else -1,
+                    "discounted_return": float(mgr.gamma ** n if winner_is_maker else -(mgr.gamma ** n)),
+                    "length": n,
+                    "time": now - mgr._creation_time[i],
+                }
+                rewards[t, i] = 1 if winner_is_maker == mover_is_maker else -1
+                mgr._creation_time[i] = now
+            maker = not maker
+            states.append(SnapObs((self.adj[t + 1], self.alive[t + 1]), res[t, :, 2:4].astype(np.int64), maker))
+        mgr._sizes = res[-1, :, 2:4].astype(np.int64)
+        mgr.last_obs = None
+        return RolloutResult(states, ranks, verts, rewards, dones, expl, infos)
+
+
 class _EnvView:
     """Read-only stand-in for the per-env ``Hex_game`` objects of the reference's ``Env_manager.envs``."""
 
@@ -314,6 +487,28 @@ class Env_manager:
         self._sizes = np.tile(self._base_sizes, (self.num_envs, 1))
         self._creation_time = [time.perf_counter()] * self.num_envs
         return self.observe()
+
+    def _state_tensors(self):
+        """Device copy of the full env state (boards, side, move counters, response sets)."""
+        L = _lib.lib()
+        dev = self.device
+        k, nv = self.num_envs, self._nv
+        t = dict(adj=torch.empty((k, nv, self._words), dtype=torch.int64, device=dev),
+                 alive=torch.empty((k, nv), dtype=torch.uint8, device=dev),
+                 mt=torch.empty(k, dtype=torch.int32, device=dev), tm=torch.empty(k, dtype=torch.int32, device=dev),
+                 rm=torch.empty((k, nv), dtype=torch.int16, device=dev), rb=torch.empty((k, nv), dtype=torch.int16, device=dev))
+        _lib.check(L.hexgnn_env_export(self._h, t["adj"].data_ptr(), t["alive"].data_ptr(), t["mt"].data_ptr(),
+                                       t["tm"].data_ptr(), t["rm"].data_ptr(), t["rb"].data_ptr(), ops._stream()),
+                   "hexgnn_env_export")
+        t["sizes"], t["onturn"] = self._sizes.copy(), self.global_onturn
+        return t
+
+    def _restore_state_tensors(self, t):
+        _lib.check(_lib.lib().hexgnn_env_import(self._h, t["adj"].data_ptr(), t["alive"].data_ptr(), t["mt"].data_ptr(),
+                                               t["tm"].data_ptr(), t["rm"].data_ptr(), t["rb"].data_ptr(), ops._stream()),
+                   "hexgnn_env_import")
+        self._sizes, self.global_onturn = t["sizes"].copy(), t["onturn"]
+        self.last_obs = None
 
     # ---- raw state (tests, debugging) ------------------------------------------------------------------
     def _state(self):

@@ -191,6 +191,12 @@ int hexgnn_env_observe(hexgnn_env* env, const int* node_off, const int* edge_off
                        float* invdeg, int64_t* batch_vec, hexgnn_stream_t stream);
 /* Raw state dump (tests): adj [num_envs][nv][words] u64, alive [num_envs][nv] u8, maker_turn / total_moves [num_envs],
  * response sets [num_envs][nv] i16 (-1 = none; may be NULL). */
+/* Overwrite the whole state of every env with arrays in hexgnn_env_export's layout (all six required). */
+int hexgnn_env_import(hexgnn_env* env, const uint64_t* adj, const uint8_t* alive, const int* maker_turn,
+                      const int* total_moves, const int16_t* resp_maker, const int16_t* resp_breaker, hexgnn_stream_t stream);
+/* node_off / edge_off [k+1] (device) = exclusive prefix sums of result[env][2] / result[env][3] of the last
+ * hexgnn_env_step: feeds hexgnn_env_observe without reading the sizes back (device-resident rollouts). */
+int hexgnn_env_offsets(int k, const int* result, int* node_off, int* edge_off, hexgnn_stream_t stream);
 int hexgnn_env_export(hexgnn_env* env, uint64_t* adj, uint8_t* alive, int* maker_turn, int* total_moves,
                       int16_t* resp_maker, int16_t* resp_breaker, hexgnn_stream_t stream);
 

@@ -176,3 +176,60 @@ def test_select_actions_greedy_and_exploratory():
         assert 2 <= int(rank[g]) < obs.node_off[g + 1] - obs.node_off[g]
     obs2, rew, done, infos = mgr.step(vert)                              # device actions go straight into the step
     assert len(obs2) == 20
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_device_rollout_equals_step_by_step_loop(graph):
+    """DeviceRollout (observation -> Q forward -> greedy action -> step, sizes kept on the device, optionally one HIP
+    graph) must play exactly the games the public step-by-step API plays, and leave the envs in the same state."""
+    import torch
+    from gnn_hex_amd.data import Batch
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
+    from helpers import make_pair
+    hip, _ = make_pair(3, 35, seed=4)
+    k, size, T = 8, 5, 12
+    a, b = Env_manager(k, size, gamma=0.9), Env_manager(k, size, gamma=0.9)
+    a.reset(); b.reset()
+    ro = DeviceRollout(a, hip, steps=T, eps=0.0, graph=graph)
+    for _round in range(2):          # the second run starts from mid-game boards and replays the captured graph
+        res = ro.run()
+        obs = b.observe()
+        for t in range(T):
+            bt = Batch.from_data_list(obs)
+            with torch.no_grad():
+                adv = hip(bt.x, bt.edge_index, bt.batch, bt.ptr, advantages_only=True)
+            vert, rank, _ = b.select_actions(adv, obs, eps=0.0)
+            assert vert.cpu().tolist() == res.vertices[t].tolist(), "step %d" % t
+            assert rank.cpu().tolist() == res.actions[t].tolist()
+            assert obs.node_off == res.states[t].node_off and obs.edge_off == res.states[t].edge_off
+            assert torch.equal(obs.snapshot()[0], res.states[t].snapshot()[0])
+            obs, rew, dones, infos = b.step(vert)
+            assert rew.tolist() == res.rewards[t].tolist() and dones.tolist() == res.dones[t].tolist()
+            for i in range(k):
+                assert ("episode_metrics" in infos[i]) == ("episode_metrics" in res.infos[t][i])
+        assert res.dones.any(), "the rollout should finish at least one Hex-5 game"
+        sa, sb = a._state(), b._state()
+        for key in ("adj", "alive", "maker_turn", "total_moves"):
+            assert (sa[key] == sb[key]).all(), key
+        assert a.global_onturn == b.global_onturn and (a._sizes == b._sizes).all()
+
+
+def test_device_rollout_feeds_replay():
+    """Rollout histories -> vectorised n-step assembly -> device replay ring -> sampled batches the model accepts."""
+    import torch
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
+    from gnn_hex_amd.replay import GraphReplayBuffer
+    from helpers import make_pair
+    hip, _ = make_pair(3, 35, seed=4)
+    mgr = Env_manager(16, 5, gamma=0.97, n_steps=[2])
+    mgr.reset()
+    res = DeviceRollout(mgr, hip, steps=16, eps=0.3, graph=False).run()
+    mb, bb = mgr.assemble_transitions(res.states[0], res.states[1:], list(res.actions), list(res.rewards),
+                                      list(res.dones), list(res.exploratories))
+    assert len(mb) > 0 and len(bb) > 0
+    buf = GraphReplayBuffer(1024, 5, prioritized=True, alpha=0.5)
+    buf.put_block(mb)
+    idx, w, s, s2, act, r, d = buf.sample(32, beta=0.6)
+    q = hip(s.x, s.edge_index, s.batch, s.ptr)
+    assert q.shape[0] == s.x.shape[0] and torch.isfinite(q).all()
+    assert int(act.max()) < int((s.ptr[1:] - s.ptr[:-1]).max())
