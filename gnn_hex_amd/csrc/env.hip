@@ -34,43 +34,68 @@ struct Env {   // host handle
     void* blob;
 };
 
-struct Sets { uint64_t w[kMaxW]; };
+// WT = compile-time number of 64-bit words per vertex set.  WT < WT instantiations assume Wr() == WT (register-resident
+// sets, fully unrolled); WT == WT is the generic fallback with a runtime Wr().
+template <int WT> struct SetsT { uint64_t w[WT]; };
 
 // ------------------------------------------------------------------------------------------------------------
 // wave-level primitives on the LDS-resident game (blockDim.x == 64)
 // ------------------------------------------------------------------------------------------------------------
-struct Game {
+template <int WT>
+struct GameT {
+    using Sets = SetsT<WT>;
     uint64_t* adj;     // LDS [nv][W]
     uint8_t* alive;    // LDS [nv]
     uint64_t* scr;     // LDS scratch [4][kMaxW]
     int nv, W, K, lane;
+    __device__ __forceinline__ int Wr() const { if constexpr (WT == WT) return W; else return WT; }
     bool maker_won;
 
-    __device__ __forceinline__ uint64_t* row(int v) const { return adj + v * W; }
+    __device__ __forceinline__ uint64_t* row(int v) const { return adj + v * Wr(); }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 
     __device__ __forceinline__ Sets get_row(int v) const {
         Sets s;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) s.w[w] = w < W ? adj[v * W + w] : 0ull;
+        for (int w = 0; w < WT; ++w) s.w[w] = w < Wr() ? adj[v * Wr() + w] : 0ull;
         return s;
     }
-    __device__ __forceinline__ static bool has(const Sets& s, int v) { return (s.w[v >> 6] >> (v & 63)) & 1ull; }
-    __device__ __forceinline__ static void clr(Sets& s, int v) { s.w[v >> 6] &= ~(1ull << (v & 63)); }
+    // word selection by compare chains: a dynamically indexed register array would be demoted to scratch memory
+    __device__ __forceinline__ static uint64_t word(const Sets& s, int i) {
+        uint64_t r = s.w[0];
+#pragma unroll
+        for (int w = 1; w < WT; ++w) r = (i == w) ? s.w[w] : r;
+        return r;
+    }
+    __device__ __forceinline__ static bool has(const Sets& s, int v) { return (word(s, v >> 6) >> (v & 63)) & 1ull; }
+    __device__ __forceinline__ static void clr(Sets& s, int v) {
+        const uint64_t m = ~(1ull << (v & 63));
+#pragma unroll
+        for (int w = 0; w < WT; ++w) if ((v >> 6) == w) s.w[w] &= m;
+    }
+    __device__ __forceinline__ static void set(Sets& s, int v) {
+        const uint64_t m = 1ull << (v & 63);
+#pragma unroll
+        for (int w = 0; w < WT; ++w) if ((v >> 6) == w) s.w[w] |= m;
+    }
     __device__ __forceinline__ bool empty(const Sets& s) const {
         uint64_t o = 0;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) o |= s.w[w];
+        for (int w = 0; w < WT; ++w) o |= s.w[w];
         return o == 0;
     }
     // smallest element >= from, or -1 (uniform)
     __device__ __forceinline__ int next_bit(const Sets& s, int from) const {
-        for (int w = from >> 6; w < W; ++w) {
-            uint64_t m = s.w[w];
-            if (w == (from >> 6)) m &= ~0ull << (from & 63);
-            if (m) return w * 64 + __builtin_ctzll(m);
+        int found = -1;
+#pragma unroll
+        for (int w = WT - 1; w >= 0; --w) {       // descending, so the smallest matching word wins
+            if (w < Wr() && w >= (from >> 6)) {
+                uint64_t m = s.w[w];
+                if (w == (from >> 6)) m &= ~0ull << (from & 63);
+                if (m) found = w * 64 + __builtin_ctzll(m);
+            }
         }
-        return -1;
+        return found;
     }
     // every vertex of s is adjacent to every other vertex of s (graph_game/utils.py:104-116)
     __device__ __forceinline__ bool is_clique(const Sets& s) const {
@@ -79,7 +104,7 @@ struct Game {
             const int x = lane + 64 * k;
             if (x < nv && has(s, x)) {
                 const uint64_t* rx = row(x);
-                for (int w = 0; w < W; ++w) {
+                for (int w = 0; w < Wr(); ++w) {
                     uint64_t need = s.w[w];
                     if (w == (x >> 6)) need &= ~(1ull << (x & 63));
                     if ((rx[w] & need) != need) ok = false;
@@ -94,10 +119,10 @@ struct Game {
         const uint64_t m = ~(1ull << (v & 63));
         for (int k = 0; k < K; ++k) {
             const int x = lane + 64 * k;
-            if (x < nv) adj[x * W + (v >> 6)] &= m;
+            if (x < nv) adj[x * Wr() + (v >> 6)] &= m;
         }
         sync();
-        if (lane < W) adj[v * W + lane] = 0ull;
+        if (lane < Wr()) adj[v * Wr() + lane] = 0ull;
         if (lane == 0) alive[v] = 0;
         sync();
     }
@@ -105,14 +130,14 @@ struct Game {
     __device__ __forceinline__ Sets wave_or(const Sets& mine, int slot) {
         uint64_t* s = scr + slot * kMaxW;
         sync();
-        if (lane < W) s[lane] = 0ull;
+        if (lane < Wr()) s[lane] = 0ull;
         sync();
-        for (int w = 0; w < W; ++w)
+        for (int w = 0; w < Wr(); ++w)
             if (mine.w[w]) atomicOr(reinterpret_cast<unsigned long long*>(&s[w]), (unsigned long long)mine.w[w]);
         sync();
         Sets out;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) out.w[w] = w < W ? s[w] : 0ull;
+        for (int w = 0; w < WT; ++w) out.w[w] = w < Wr() ? s[w] : 0ull;
         return out;
     }
 
@@ -123,12 +148,12 @@ struct Game {
     __device__ __forceinline__ Sets maker_connect(int v) {
         Sets change;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) change.w[w] = 0ull;
+        for (int w = 0; w < WT; ++w) change.w[w] = 0ull;
         const Sets nb = get_row(v);
         const bool t0 = has(nb, 0), t1 = has(nb, 1);
         if (t0 && t1) {
             sync();
-            if (lane == 0) { adj[0 * W] |= 2ull; adj[1 * W] |= 1ull; }
+            if (lane == 0) { adj[0 * Wr()] |= 2ull; adj[1 * Wr()] |= 1ull; }
             maker_won = true;
             sync();
             return change;
@@ -140,12 +165,12 @@ struct Game {
                 const int x = lane + 64 * k;
                 if (x < nv && has(nb, x)) {
                     const bool a0 = has(n0, x), a1 = has(n1, x);
-                    for (int w = 0; w < W; ++w) {
+                    for (int w = 0; w < Wr(); ++w) {
                         uint64_t m = nb.w[w];
                         if (w == (x >> 6)) m &= ~(1ull << (x & 63));
                         if (a0) m &= ~n0.w[w];
                         if (a1) m &= ~n1.w[w];
-                        adj[x * W + w] |= m;
+                        adj[x * Wr() + w] |= m;
                     }
                 }
             }
@@ -156,29 +181,29 @@ struct Game {
         sync();
         for (int k = 0; k < K; ++k) {
             const int x = lane + 64 * k;
-            if (x < nv && x != t && has(nb, x)) adj[x * W] |= 1ull << t;
+            if (x < nv && x != t && has(nb, x)) adj[x * Wr()] |= 1ull << t;
         }
-        if (lane < W) {
-            uint64_t m = nb.w[lane];
+        if (lane < Wr()) {
+            uint64_t m = word(nb, lane);
             if (lane == 0) m &= ~(1ull << t);
-            adj[t * W + lane] |= m;
+            adj[t * Wr() + lane] |= m;
         }
         sync();
         // _fix_teminal_connections(t): drop every edge between two neighbours of t
         const Sets nt = get_row(t);
         Sets mine;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) mine.w[w] = 0ull;
+        for (int w = 0; w < WT; ++w) mine.w[w] = 0ull;
         for (int k = 0; k < K; ++k) {
             const int x = lane + 64 * k;
             if (x < nv && has(nt, x)) {
                 uint64_t any = 0;
-                for (int w = 0; w < W; ++w) {
-                    const uint64_t rem = adj[x * W + w] & nt.w[w];
+                for (int w = 0; w < Wr(); ++w) {
+                    const uint64_t rem = adj[x * Wr() + w] & nt.w[w];
                     any |= rem;
-                    adj[x * W + w] &= ~nt.w[w];
+                    adj[x * Wr() + w] &= ~nt.w[w];
                 }
-                if (any) mine.w[x >> 6] |= 1ull << (x & 63);
+                if (any) set(mine, x);
             }
         }
         return wave_or(mine, 0);
@@ -189,14 +214,14 @@ struct Game {
         while (!empty(consider)) {
             Sets big;
 #pragma unroll
-            for (int w = 0; w < kMaxW; ++w) big.w[w] = 0ull;
+            for (int w = 0; w < WT; ++w) big.w[w] = 0ull;
             for (int node = next_bit(consider, 2); node >= 0; node = next_bit(consider, node + 1)) {
                 sync();
                 if (!alive[node]) continue;
                 const Sets ns = get_row(node);
                 if (is_clique(ns)) {                       // dead
 #pragma unroll
-                    for (int w = 0; w < kMaxW; ++w) big.w[w] |= ns.w[w];
+                    for (int w = 0; w < WT; ++w) big.w[w] |= ns.w[w];
                     remove_vertex(node);
                     continue;
                 }
@@ -213,7 +238,7 @@ struct Game {
                         if (c < nv && c >= 2 && c != node && alive[c] && (c == one || has(cand, c))) {
                             hit = true;
                             const uint64_t* rc = row(c);
-                            for (int w = 0; w < W; ++w) {
+                            for (int w = 0; w < Wr(); ++w) {
                                 uint64_t a = rc[w], b = ns.w[w];
                                 if (w == (node >> 6)) a &= ~(1ull << (node & 63));
                                 if (w == (c >> 6)) b &= ~(1ull << (c & 63));
@@ -234,7 +259,7 @@ struct Game {
                     const Sets ch = maker_connect(node);
                     remove_vertex(node);
 #pragma unroll
-                    for (int w = 0; w < kMaxW; ++w) big.w[w] |= wm.w[w] | ch.w[w];
+                    for (int w = 0; w < WT; ++w) big.w[w] |= wm.w[w] | ch.w[w];
                     continue;
                 }
                 // breaker capture: some neighbour whose and whose partner's residual neighbourhoods are cliques
@@ -244,7 +269,7 @@ struct Game {
                     clr(wh, nbr);
                     if (is_clique(wm) && is_clique(wh)) {
 #pragma unroll
-                        for (int w = 0; w < kMaxW; ++w) big.w[w] |= wm.w[w] | wh.w[w];
+                        for (int w = 0; w < WT; ++w) big.w[w] |= wm.w[w] | wh.w[w];
                         if (lane == 0) { resp_b[node] = (short)nbr; resp_b[nbr] = (short)node; }
                         remove_vertex(node);
                         remove_vertex(nbr);
@@ -262,27 +287,28 @@ struct Game {
         if (maker_won || (adj[0] & 2ull)) return 0;
         Sets reach;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) reach.w[w] = 0ull;
+        for (int w = 0; w < WT; ++w) reach.w[w] = 0ull;
         reach.w[0] = 1ull;
         for (int it = 0; it < nv; ++it) {
             Sets mine;
 #pragma unroll
-            for (int w = 0; w < kMaxW; ++w) mine.w[w] = 0ull;
+            for (int w = 0; w < WT; ++w) mine.w[w] = 0ull;
             for (int k = 0; k < K; ++k) {
                 const int x = lane + 64 * k;
                 if (x < nv && has(reach, x))
-                    for (int w = 0; w < W; ++w) mine.w[w] |= adj[x * W + w];
+                    for (int w = 0; w < Wr(); ++w) mine.w[w] |= adj[x * Wr() + w];
             }
             Sets nr = wave_or(mine, 1);
             bool grew = false;
 #pragma unroll
-            for (int w = 0; w < kMaxW; ++w) { const uint64_t n = reach.w[w] | nr.w[w]; grew |= n != reach.w[w]; reach.w[w] = n; }
+            for (int w = 0; w < WT; ++w) { const uint64_t n = reach.w[w] | nr.w[w]; grew |= n != reach.w[w]; reach.w[w] = n; }
             if (has(reach, 1)) return -1;
             if (!grew) break;
         }
         return 1;
     }
 };
+using Game = GameT<kMaxW>;
 
 // observation source: an array of board states (the live envs, or a replay ring) + which of them to emit
 struct StateSrc {
@@ -294,7 +320,8 @@ struct StateSrc {
     const int* index;         // [k] state picked for output graph i, or null (identity)
 };
 
-__device__ __forceinline__ void load_game(Game& g, const EnvDev& d, int env, char* lds) {
+template <class G>
+__device__ __forceinline__ void load_game(G& g, const EnvDev& d, int env, char* lds) {
     g.nv = d.nv; g.W = d.W; g.K = d.K; g.lane = threadIdx.x; g.maker_won = false;
     g.adj = reinterpret_cast<uint64_t*>(lds);
     g.scr = g.adj + (size_t)d.nv * d.W;
@@ -304,13 +331,15 @@ __device__ __forceinline__ void load_game(Game& g, const EnvDev& d, int env, cha
     for (int i = threadIdx.x; i < d.nv; i += 64) g.alive[i] = d.alive[(size_t)env * d.nv + i];
     __syncthreads();
 }
-__device__ __forceinline__ void store_game(const Game& g, const EnvDev& d, int env) {
+template <class G>
+__device__ __forceinline__ void store_game(const G& g, const EnvDev& d, int env) {
     __syncthreads();
     uint64_t* dst = d.adj + (size_t)env * d.nv * d.W;
     for (int i = threadIdx.x; i < d.nv * d.W; i += 64) dst[i] = g.adj[i];
     for (int i = threadIdx.x; i < d.nv; i += 64) d.alive[(size_t)env * d.nv + i] = g.alive[i];
 }
-__device__ __forceinline__ void reset_game_lds(Game& g, const EnvDev& d) {
+template <class G>
+__device__ __forceinline__ void reset_game_lds(G& g, const EnvDev& d) {
     __syncthreads();
     for (int i = threadIdx.x; i < d.nv * d.W; i += 64) g.adj[i] = d.start_adj[i];
     for (int i = threadIdx.x; i < d.nv; i += 64) g.alive[i] = 1;
@@ -318,7 +347,8 @@ __device__ __forceinline__ void reset_game_lds(Game& g, const EnvDev& d) {
     __syncthreads();
 }
 // alive count and directed edge count (uniform)
-__device__ __forceinline__ void count_game(const Game& g, int* n_alive, int* n_dir_edges) {
+template <class G>
+__device__ __forceinline__ void count_game(const G& g, int* n_alive, int* n_dir_edges) {
     int a = 0, e = 0;
     for (int k = 0; k < g.K; ++k) {
         const int x = g.lane + 64 * k;
@@ -356,11 +386,13 @@ __global__ __launch_bounds__(64) void env_reset_kernel(EnvDev d, const uint8_t* 
 }
 
 // result record per env: [winner(-1/0/1), length, n_alive, n_directed_edges, error]
+template <int WT>
 __global__ __launch_bounds__(64) void env_step_kernel(EnvDev d, const int* __restrict__ actions, int remove_dc,
                                                     int auto_reset, int reset_maker_turn, int* __restrict__ result) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int env = blockIdx.x;
-    Game g;
+    GameT<WT> g;
+    using Sets = typename GameT<WT>::Sets;
     load_game(g, d, env, lds);
     short* rm = d.resp_maker + (size_t)env * d.nv;
     short* rb = d.resp_breaker + (size_t)env * d.nv;
@@ -374,11 +406,11 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev d, const int* __res
         ++moves;
         Sets consider;
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) consider.w[w] = 0ull;
+        for (int w = 0; w < WT; ++w) consider.w[w] = 0ull;
         if (mt) consider = g.maker_connect(v);
         const Sets nbv = g.get_row(v);
 #pragma unroll
-        for (int w = 0; w < kMaxW; ++w) consider.w[w] |= nbv.w[w];
+        for (int w = 0; w < WT; ++w) consider.w[w] |= nbv.w[w];
         g.remove_vertex(v);
         mt = !mt;
         if (remove_dc && !g.maker_won) g.dead_and_captured(consider, rm, rb);
@@ -551,6 +583,19 @@ static size_t env_lds_bytes(const EnvDev& d) {
     return align_up(b, 16);
 }
 
+template <int WT>
+static void launch_env_step(const EnvDev& d, const int* actions, int remove_dc, int auto_reset, int reset_maker_turn,
+                            int* result, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel<WT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        return true;
+    }();
+    (void)once;
+    env_step_kernel<WT><<<d.num_envs, 64, env_lds_bytes(d), st>>>(d, actions, remove_dc, auto_reset, reset_maker_turn, result);
+}
+
+
 }  // namespace hexgnn
 
 using namespace hexgnn;
@@ -654,16 +699,17 @@ int hexgnn_env_step(hexgnn_env* h, const int* actions, int remove_dead_and_captu
                     int reset_maker_turn, int* result, hexgnn_stream_t stream_) {
     if (!h || !actions || !result) return HEXGNN_EINVAL;
     Env* e = reinterpret_cast<Env*>(h);
-    static bool once = [] {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&env_step_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&env_observe_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-        return true;
-    }();
-    (void)once;
-    env_step_kernel<<<e->d.num_envs, 64, env_lds_bytes(e->d), (hipStream_t)stream_>>>(
-        e->d, actions, remove_dead_and_captured, auto_reset, reset_maker_turn ? 1 : 0, result);
+    hipStream_t st = (hipStream_t)stream_;
+    const int rm = reset_maker_turn ? 1 : 0;
+    // vertex sets as compile-time register arrays for the common board sizes (W = ceil((n*n+2)/64): Hex <= 7: 1,
+    // Hex 8-11: 2, Hex 12-13: 3, Hex 14-15: 4); larger boards take the generic runtime-W instantiation
+    switch (e->d.W) {
+        case 1: launch_env_step<1>(e->d, actions, remove_dead_and_captured, auto_reset, rm, result, st); break;
+        case 2: launch_env_step<2>(e->d, actions, remove_dead_and_captured, auto_reset, rm, result, st); break;
+        case 3: launch_env_step<3>(e->d, actions, remove_dead_and_captured, auto_reset, rm, result, st); break;
+        case 4: launch_env_step<4>(e->d, actions, remove_dead_and_captured, auto_reset, rm, result, st); break;
+        default: launch_env_step<kMaxW>(e->d, actions, remove_dead_and_captured, auto_reset, rm, result, st); break;
+    }
     return check_launch();
 }
 
