@@ -244,7 +244,7 @@ def main():
             split = {"math": "f16x3", "value": B * args.steps / dt2, "unit": "graphs/s", "ms_per_step": dt2 / args.steps * 1e3}
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline:      # rank 0 at N=1 only (bench contract)
             cpu = cpu_baseline(ref, batches, B)
 
         out = {
