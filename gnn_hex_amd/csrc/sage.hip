@@ -511,9 +511,10 @@ __global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __res
 
 // ---- the same batched weight gradient in split precision ("f16x3", math 1) ---------------------------------
 // The contraction runs over ROWS, so both MFMA operands need 8 consecutive rows of one column per lane.  Every thread
-// stages TWO adjacent rows (2i, 2i+1) of one float4 column group: the chunk (R = 32 rows = one K step) is scaled by the
+// stages TWO rows (i, i+16) of one float4 column group (any fixed pairing works: the contraction index is permuted the
+// same way for both operands, and this one keeps every wave-wide global load contiguous): the chunk (R = 32 rows = one K step) is scaled by the
 // layer's power of two (max |G_l|, max |[agg|x]| -> 2^14..2^15, maxima produced by the fused forward / backward
-// kernels), split into fp16 hi / lo and stored as ROW-PAIR words (row 2i in the low half, row 2i+1 in the high half)
+// kernels), split into fp16 hi / lo and stored as ROW-PAIR words (row i in the low half, row i+16 in the high half)
 // in two planes T[plane][rowpair][col].  A fragment is then four conflict-free ds_read_b32 per plane (row-pair stride
 // == 4 mod 8 dwords) with no unpacking at all.  Wave w owns the input-feature tiles {2w, 2w+1} of [agg | x] and all
 // NT output tiles: 9 fragments feed 42 v_mfma_f32_16x16x32_f16 per chunk.  db is summed exactly in fp32 on the staging
@@ -576,7 +577,7 @@ __global__ __launch_bounds__(64 * NT) void sage_dw16_kernel(Dw16Args a, float* _
     struct Pre { f32x4 ra[2], rx[2], rg[2]; float f0, f1; };   // f = 1 when the staged row exists (rows past the slice: zeros)
     Pre pA, pB;
     auto issue = [&](Pre& p, int rc) {
-        const int row0 = rc + 2 * rp, row1 = row0 + 1;
+        const int row0 = rc + rp, row1 = row0 + RP;   // rows (i, i+16): both loads of a wave are contiguous 1 KB pieces
         p.f0 = row0 < r_end ? 1.f : 0.f; p.f1 = row1 < r_end ? 1.f : 0.f;
         const size_t o0 = (size_t)min(row0, r_end - 1) * HP, o1 = (size_t)min(row1, r_end - 1) * HP;
         p.ra[0] = reinterpret_cast<const f32x4*>(agg + o0)[q]; p.ra[1] = reinterpret_cast<const f32x4*>(agg + o1)[q];
