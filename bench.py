@@ -120,7 +120,9 @@ def main():
         xd = x.to(dev)
         xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
         xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
-        batches.append(dict(x=xd, ei=ei.to(dev), bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
+        eid = ei.to(dev)
+        eid._hex_grouped = True           # collated graph by graph (what Batch.from_data_list produces and marks)
+        batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
 
     plist = list(hip.parameters())

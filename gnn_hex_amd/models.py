@@ -318,15 +318,17 @@ class DuellingTwoHeaded(torch.nn.Module):
         n = x.shape[0]
         x2 = x[:, :2]
 
+        gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
+        max_nodes = getattr(x, "_hex_max_nodes", None)
         gs = getattr(edge_index, "_hex_csr", None)          # CSR emitted by the env builder, if any
         if gs is None or gs.n != n:
-            gs = ops.GraphStructure(edge_index, n)       # edge_index CSR-sorted once per batch
-        gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
+            # edge_index CSR-sorted once per batch; collated batches (edges grouped by graph) take the one-launch build
+            grouped = getattr(edge_index, "_hex_grouped", False) and max_nodes is not None and max_nodes <= 2048
+            gs = ops.GraphStructure(edge_index, n, gptr, b) if grouped else ops.GraphStructure(edge_index, n)
         head = self.maker_head if is_maker else self.breaker_head
         mode = 2 if advantages_only else (1 if seperate else 0)
 
         # fused per-graph path (one launch per direction) when every graph fits a workgroup's LDS
-        max_nodes = getattr(x, "_hex_max_nodes", None)
         if max_nodes is None and ops._FUSED_ENABLED:
             max_nodes = int((gptr[1:] - gptr[:-1]).max()) if b > 0 else 0     # host sync (no size hint given)
         h = self.gnn.hidden_channels

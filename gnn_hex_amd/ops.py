@@ -48,7 +48,9 @@ class GraphStructure:
 
     __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status")
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, gptr: Optional[torch.Tensor] = None, b: int = 0):
+        """``gptr`` (int32 [b+1] node ranges) selects the single-launch build for batches whose edges are grouped by
+        graph in graph order (``Batch.from_data_list``, the env builder); without it the general build runs."""
         _require_cuda(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
@@ -59,6 +61,18 @@ class GraphStructure:
         n, e = int(num_nodes), int(edge_index.shape[1])
         L = _lib.lib()
         self.n, self.e = n, e
+        if gptr is not None and b > 0:
+            ibuf = torch.empty(2 * (n + 1) + 1, dtype=torch.int32, device=dev)
+            self.rowptr, self.rowptr_t = ibuf[:n + 1], ibuf[n + 1:2 * (n + 1)]
+            self.status = ibuf[2 * (n + 1):]
+            self.col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+            self.col_t = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
+            self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+            _lib.check(L.hexgnn_csr_build_grouped(n, e, int(b), edge_index[0].data_ptr(), edge_index[1].data_ptr(),
+                                                  gptr.data_ptr(), self.rowptr.data_ptr(), self.col.data_ptr(),
+                                                  self.rowptr_t.data_ptr(), self.col_t.data_ptr(), self.invdeg.data_ptr(),
+                                                  self.status.data_ptr(), _stream()), "hexgnn_csr_build_grouped")
+            return
         ws_bytes = L.hexgnn_csr_workspace_bytes(n, e)
         # one int32 buffer [rowptr | rowptr_t | status | workspace]: the build zeroes it with a single memset
         ibuf = torch.empty(2 * (n + 1) + 1 + (ws_bytes + 3) // 4, dtype=torch.int32, device=dev)
@@ -92,7 +106,8 @@ class GraphStructure:
         """Host-synchronising validity check (debug aid; not called on the hot path)."""
         if int(self.status.item()) != 0:
             raise IndexError("invalid batch structure (status=%d): 1 = node id outside [0,%d), 2 = graph larger than "
-                             "128 nodes reached the fused kernel, 4 = an edge connects two graphs" % (int(self.status.item()), self.n))
+                             "128 nodes reached the fused kernel, 4 = an edge connects two graphs (or a batch passed as grouped is "
+                             "not), 8 = graph above 2048 nodes in the grouped build" % (int(self.status.item()), self.n))
 
 
 def graph_ptr(graph_indices: Optional[torch.Tensor], ptr: Optional[torch.Tensor], n: int, device):

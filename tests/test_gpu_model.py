@@ -85,6 +85,36 @@ def test_csr_build_bit_exact():
     gs.check()
     gptr, b = ops.graph_ptr(batch.cuda(), None, n, "cuda")
     assert b == 6 and np.array_equal(gptr.cpu().numpy(), ptr.numpy())
+    # the one-launch build for grouped (collated) batches must give exactly the same structure
+    gg = ops.GraphStructure(ei.cuda(), n, gptr, b)
+    torch.cuda.synchronize()
+    for name in ("rowptr", "rowptr_t", "invdeg"):
+        assert torch.equal(getattr(gg, name), getattr(gs, name)), name
+    assert torch.equal(gg.col[: ei.shape[1]], gs.col[: ei.shape[1]]) and torch.equal(gg.col_t[: ei.shape[1]], gs.col_t[: ei.shape[1]])
+    gg.check()
+
+
+def test_grouped_csr_build_edge_cases():
+    """Grouped build: empty graphs, a graph without edges, directed (asymmetric) edges, isolated nodes, and the status
+    bit when the batch is not actually grouped."""
+    from gnn_hex_amd import ops
+    # graphs of 3, 0, 2, 4 nodes; graph 2 has no edges; graph 3 is directed
+    ptr = torch.tensor([0, 3, 3, 5, 9])
+    ei = torch.tensor([[0, 1, 2, 0, 5, 6, 8, 8, 5],
+                       [1, 0, 0, 2, 6, 5, 5, 7, 7]])
+    n = 9
+    gptr = ptr.to(torch.int32).cuda()
+    gs = ops.GraphStructure(ei.cuda(), n)
+    gg = ops.GraphStructure(ei.cuda(), n, gptr, 4)
+    torch.cuda.synchronize()
+    for name in ("rowptr", "rowptr_t", "invdeg"):
+        assert torch.equal(getattr(gg, name), getattr(gs, name)), name
+    assert torch.equal(gg.col[:9], gs.col[:9]) and torch.equal(gg.col_t[:9], gs.col_t[:9])
+    gg.check()
+    bad = ops.GraphStructure(ei.flip(1).contiguous().cuda(), n, gptr, 4)      # graphs in reverse order: not grouped
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        bad.check()
 
 
 @pytest.mark.parametrize("maker", [True, False])
