@@ -430,13 +430,23 @@ struct DwArgs {
     int n, rows_per_slice, S;
 };
 
+// Waves per workgroup: for NT >= 4 one EXTRA wave owns the last two input-feature tiles for all NT output tiles, the NT
+// regular waves the other 2NT-2: 8 waves of 12|14 MFMAs per k-step load the four SIMDs 24/24/24/26 instead of 7 waves
+// of 14 loading them 28/28/28/14 (the fp32 MFMA pipe is the bound of this kernel).
+template <int NT> struct DwShape {
+    static constexpr bool kBal = NT >= 4;
+    static constexpr int kWaves = kBal ? NT + 1 : NT;
+    static constexpr int kRegB = kBal ? 2 * NT - 2 : 2 * NT;     // input-feature tiles of a regular wave
+};
+
 template <int NT>
-__global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
+__global__ __launch_bounds__(64 * DwShape<NT>::kWaves) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
     constexpr int HP = 16 * NT;
     constexpr int R = 32;
     constexpr int AS = 2 * HP + 16;                     // == 16 (mod 32): conflict-free fragment reads
     constexpr int GS = (NT % 2 == 1) ? HP : HP + 16;
-    constexpr int NTHR = 64 * NT;
+    constexpr int NTHR = 64 * DwShape<NT>::kWaves;
+    constexpr int NB = DwShape<NT>::kRegB;
     __shared__ __attribute__((aligned(16))) float As[R * AS];
     __shared__ __attribute__((aligned(16))) float Gs[R * GS];
     const int li = blockIdx.y, s = blockIdx.x;
@@ -445,10 +455,11 @@ __global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __res
     const float* __restrict__ gg = a.g[li];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
+    const bool extra = DwShape<NT>::kBal && w == NT;     // wave-uniform
     const int r_beg = s * a.rows_per_slice;
     const int r_end = min(a.n, r_beg + a.rows_per_slice);
 
-    f32x4 acc[2 * NT];
+    f32x4 acc[2 * NT];       // regular wave: tile t < NB; extra wave: [2 * t + tb]
 #pragma unroll
     for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
@@ -485,29 +496,52 @@ __global__ __launch_bounds__(64 * NT) void sage_dw_kernel(DwArgs a, float* __res
         }
         __syncthreads();
         if (rc + R < r_end) issue(rc + R);
+        if (!extra) {
 #pragma unroll
-        for (int ks = 0; ks < R / 4; ++ks) {
-            const float av = Gs[(4 * ks + kq) * GS + 16 * w + m];
-            bsum += av;
+            for (int ks = 0; ks < R / 4; ++ks) {
+                const float av = Gs[(4 * ks + kq) * GS + 16 * w + m];
+                bsum += av;
 #pragma unroll
-            for (int t = 0; t < 2 * NT; ++t) {
-                const float bv = As[(4 * ks + kq) * AS + 16 * t + m];
-                acc[t] = mfma16x16x4(av, bv, acc[t]);
+                for (int t = 0; t < NB; ++t) {
+                    const float bv = As[(4 * ks + kq) * AS + 16 * t + m];
+                    acc[t] = mfma16x16x4(av, bv, acc[t]);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int ks = 0; ks < R / 4; ++ks) {
+                const float bv0 = As[(4 * ks + kq) * AS + 16 * NB + m];
+                const float bv1 = As[(4 * ks + kq) * AS + 16 * (NB + 1) + m];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float av = Gs[(4 * ks + kq) * GS + 16 * t + m];
+                    acc[2 * t] = mfma16x16x4(av, bv0, acc[2 * t]);
+                    acc[2 * t + 1] = mfma16x16x4(av, bv1, acc[2 * t + 1]);
+                }
             }
         }
         __syncthreads();
     }
     // slab [HP][2HP] then bias [HP]
     float* slab = part + ((size_t)li * a.S + s) * ((size_t)HP * (2 * HP + 1));
+    if (!extra) {
 #pragma unroll
-    for (int t = 0; t < 2 * NT; ++t)
+        for (int t = 0; t < NB; ++t)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) slab[(size_t)(16 * w + 4 * kq + q) * (2 * HP) + 16 * t + m] = acc[t][q];
-    bsum += __shfl_xor(bsum, 16);
-    bsum += __shfl_xor(bsum, 32);
-    if (kq == 0) slab[(size_t)HP * 2 * HP + 16 * w + m] = bsum;
+            for (int q = 0; q < 4; ++q) slab[(size_t)(16 * w + 4 * kq + q) * (2 * HP) + 16 * t + m] = acc[t][q];
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (kq == 0) slab[(size_t)HP * 2 * HP + 16 * w + m] = bsum;
+    } else {
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int tb = 0; tb < 2; ++tb)
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    slab[(size_t)(16 * t + 4 * kq + q) * (2 * HP) + 16 * (NB + tb) + m] = acc[2 * t + tb][q];
+    }
 }
-
 
 // ---- the same batched weight gradient in split precision ("f16x3", math 1) ---------------------------------
 // The contraction runs over ROWS, so both MFMA operands need 8 consecutive rows of one column per lane.  Every thread
@@ -786,7 +820,7 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
 template <int NT>
 static void launch_dw(const DwArgs& a, int layers, float* part, hipStream_t st) {
     KernelTimer kt(HEXGNN_K_SAGE_DW, st);
-    sage_dw_kernel<NT><<<dim3(a.S, layers), 64 * NT, 0, st>>>(a, part);
+    sage_dw_kernel<NT><<<dim3(a.S, layers), 64 * DwShape<NT>::kWaves, 0, st>>>(a, part);
 }
 
 template <int NT>
