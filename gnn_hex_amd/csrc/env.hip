@@ -126,18 +126,16 @@ struct GameT {
         if (lane == 0) alive[v] = 0;
         sync();
     }
-    // OR the per-lane contribution into scratch slot `slot` and return the combined set
-    __device__ __forceinline__ Sets wave_or(const Sets& mine, int slot) {
-        uint64_t* s = scr + slot * kMaxW;
-        sync();
-        if (lane < Wr()) s[lane] = 0ull;
-        sync();
-        for (int w = 0; w < Wr(); ++w)
-            if (mine.w[w]) atomicOr(reinterpret_cast<unsigned long long*>(&s[w]), (unsigned long long)mine.w[w]);
-        sync();
+    // OR of the per-lane contributions across the wave (butterfly over lanes: no LDS round trip, no barrier)
+    __device__ __forceinline__ Sets wave_or(const Sets& mine, int /*slot*/) {
         Sets out;
 #pragma unroll
-        for (int w = 0; w < WT; ++w) out.w[w] = w < Wr() ? s[w] : 0ull;
+        for (int w = 0; w < WT; ++w) {
+            uint64_t v = w < Wr() ? mine.w[w] : 0ull;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v |= __shfl_xor(v, off);
+            out.w[w] = v;
+        }
         return out;
     }
 
@@ -285,23 +283,28 @@ struct GameT {
     __device__ __forceinline__ int who_won() {
         sync();
         if (maker_won || (adj[0] & 2ull)) return 0;
-        Sets reach;
+        Sets reach, frontier;
 #pragma unroll
         for (int w = 0; w < WT; ++w) reach.w[w] = 0ull;
         reach.w[0] = 1ull;
+        frontier = reach;
         for (int it = 0; it < nv; ++it) {
             Sets mine;
 #pragma unroll
             for (int w = 0; w < WT; ++w) mine.w[w] = 0ull;
             for (int k = 0; k < K; ++k) {
                 const int x = lane + 64 * k;
-                if (x < nv && has(reach, x))
+                if (x < nv && has(frontier, x))
                     for (int w = 0; w < Wr(); ++w) mine.w[w] |= adj[x * Wr() + w];
             }
-            Sets nr = wave_or(mine, 1);
+            const Sets nr = wave_or(mine, 1);
             bool grew = false;
 #pragma unroll
-            for (int w = 0; w < WT; ++w) { const uint64_t n = reach.w[w] | nr.w[w]; grew |= n != reach.w[w]; reach.w[w] = n; }
+            for (int w = 0; w < WT; ++w) {
+                frontier.w[w] = nr.w[w] & ~reach.w[w];        // newly reached vertices only
+                grew |= frontier.w[w] != 0ull;
+                reach.w[w] |= nr.w[w];
+            }
             if (has(reach, 1)) return -1;
             if (!grew) break;
         }
