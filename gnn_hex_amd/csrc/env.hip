@@ -207,49 +207,110 @@ struct GameT {
         return wave_or(mine, 0);
     }
 
-    // shannon_node_switching_game.py:119-196 with iterate=True (canonical order: oracle/env_ref.c)
+    // ---- single-lane versions of the tests (every lane screens a different candidate vertex) ----------------------
+    __device__ __forceinline__ bool lane_is_clique(const Sets& s) const {
+        bool ok = true;
+#pragma unroll
+        for (int w = 0; w < WT; ++w) {
+            if (w < Wr()) {
+                uint64_t bits = s.w[w];
+                while (bits && ok) {
+                    const int bpos = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const uint64_t* ry = row(64 * w + bpos);
+#pragma unroll
+                    for (int u = 0; u < WT; ++u) {
+                        if (u < Wr()) {
+                            uint64_t need = s.w[u];
+                            if (u == w) need &= ~(1ull << bpos);
+                            if ((ry[u] & need) != need) ok = false;
+                        }
+                    }
+                }
+            }
+        }
+        return ok;
+    }
+    // What the sequential pass would do with vertex x in the CURRENT graph: 0 nothing, 1 dead, 2 maker capture (partner =
+    // twin), 3 breaker capture (partner = neighbour).  Same tests, same priorities, same ascending candidate order.
+    __device__ __forceinline__ int lane_screen(int x, int& partner) const {
+        const Sets ns = get_row(x);
+        if (lane_is_clique(ns)) return 1;
+        const int one = next_bit(ns, 0);
+        Sets cs = get_row(one);
+        set(cs, one);
+        int first = -1;
+        bool hit_one = false;
+#pragma unroll
+        for (int w = 0; w < WT; ++w) {
+            if (w < Wr()) {
+                uint64_t bits = cs.w[w];
+                while (bits) {
+                    const int bpos = __builtin_ctzll(bits);
+                    bits &= bits - 1;
+                    const int c = 64 * w + bpos;
+                    if (c < 2 || c == x || !alive[c]) continue;
+                    const uint64_t* rc = row(c);
+                    bool hit = true;
+#pragma unroll
+                    for (int u = 0; u < WT; ++u) {
+                        if (u < Wr()) {
+                            uint64_t ra = rc[u], rb = ns.w[u];
+                            if (u == (x >> 6)) ra &= ~(1ull << (x & 63));
+                            if (u == (c >> 6)) rb &= ~(1ull << (c & 63));
+                            if (ra != rb) hit = false;
+                        }
+                    }
+                    if (hit) { if (c == one) hit_one = true; if (first < 0) first = c; }
+                }
+            }
+        }
+        const int twin = hit_one ? one : first;
+        if (twin >= 0) { partner = twin; return 2; }
+        for (int nbr = next_bit(ns, 2); nbr >= 0; nbr = next_bit(ns, nbr + 1)) {
+            Sets wm = get_row(nbr), wh = ns;
+            clr(wm, x);
+            clr(wh, nbr);
+            if (lane_is_clique(wm) && lane_is_clique(wh)) { partner = nbr; return 3; }
+        }
+        return 0;
+    }
+
+    // shannon_node_switching_game.py:119-196 with iterate=True (canonical order: oracle/env_ref.c).  The reference visits
+    // the candidates one by one; most of them need no action.  Here every lane screens one candidate against the current
+    // graph, the smallest vertex that needs an action is handled by the whole wave, and the candidates above it are screened
+    // again on the changed graph -- exactly the sequence of actions of the ascending sequential pass, in (#actions + 1)
+    // screening rounds instead of one wave-wide evaluation per candidate.
     __device__ __forceinline__ void dead_and_captured(Sets consider, short* resp_m, short* resp_b) {
         while (!empty(consider)) {
             Sets big;
 #pragma unroll
             for (int w = 0; w < WT; ++w) big.w[w] = 0ull;
-            for (int node = next_bit(consider, 2); node >= 0; node = next_bit(consider, node + 1)) {
+            int from = 2;
+            while (true) {
                 sync();
-                if (!alive[node]) continue;
+                int code = 0, partner = -1, node = -1;
+                for (int k = 0; k < K && code == 0; ++k) {
+                    const int x = lane + 64 * k;
+                    int c = 0, p = -1;
+                    if (x < nv && x >= from && has(consider, x) && alive[x]) c = lane_screen(x, p);
+                    const uint64_t bal = __ballot(c != 0);
+                    if (bal) {
+                        const int srcl = __builtin_ctzll(bal);
+                        node = 64 * k + srcl;
+                        code = __shfl(c, srcl);
+                        partner = __shfl(p, srcl);
+                    }
+                }
+                if (code == 0) break;
+                from = node + 1;
                 const Sets ns = get_row(node);
-                if (is_clique(ns)) {                       // dead
+                if (code == 1) {                              // dead
 #pragma unroll
                     for (int w = 0; w < WT; ++w) big.w[w] |= ns.w[w];
                     remove_vertex(node);
-                    continue;
-                }
-                // maker capture: twin with the same neighbourhood; candidates chain([one], neighbours(one))
-                const int one = next_bit(ns, 0);
-                const Sets cand = get_row(one);
-                int twin = -1;
-                {
-                    bool hit_one = false;
-                    int first = -1;
-                    for (int k = 0; k < K; ++k) {
-                        const int c = lane + 64 * k;
-                        bool hit = false;
-                        if (c < nv && c >= 2 && c != node && alive[c] && (c == one || has(cand, c))) {
-                            hit = true;
-                            const uint64_t* rc = row(c);
-                            for (int w = 0; w < Wr(); ++w) {
-                                uint64_t a = rc[w], b = ns.w[w];
-                                if (w == (node >> 6)) a &= ~(1ull << (node & 63));
-                                if (w == (c >> 6)) b &= ~(1ull << (c & 63));
-                                if (a != b) hit = false;
-                            }
-                        }
-                        const uint64_t bal = __ballot(hit);
-                        if (k == (one >> 6) && one >= 2 && ((bal >> (one & 63)) & 1ull)) hit_one = true;
-                        if (first < 0 && bal) first = 64 * k + __builtin_ctzll(bal);
-                    }
-                    twin = hit_one ? one : first;
-                }
-                if (twin >= 0) {
+                } else if (code == 2) {                       // maker capture: twin with the same neighbourhood
+                    const int twin = partner;
                     Sets wm = get_row(twin);
                     clr(wm, node);
                     if (lane == 0) { resp_m[node] = (short)twin; resp_m[twin] = (short)node; }
@@ -258,21 +319,16 @@ struct GameT {
                     remove_vertex(node);
 #pragma unroll
                     for (int w = 0; w < WT; ++w) big.w[w] |= wm.w[w] | ch.w[w];
-                    continue;
-                }
-                // breaker capture: some neighbour whose and whose partner's residual neighbourhoods are cliques
-                for (int nbr = next_bit(ns, 2); nbr >= 0; nbr = next_bit(ns, nbr + 1)) {
+                } else {                                      // breaker capture
+                    const int nbr = partner;
                     Sets wm = get_row(nbr), wh = ns;
                     clr(wm, node);
                     clr(wh, nbr);
-                    if (is_clique(wm) && is_clique(wh)) {
 #pragma unroll
-                        for (int w = 0; w < WT; ++w) big.w[w] |= wm.w[w] | wh.w[w];
-                        if (lane == 0) { resp_b[node] = (short)nbr; resp_b[nbr] = (short)node; }
-                        remove_vertex(node);
-                        remove_vertex(nbr);
-                        break;
-                    }
+                    for (int w = 0; w < WT; ++w) big.w[w] |= wm.w[w] | wh.w[w];
+                    if (lane == 0) { resp_b[node] = (short)nbr; resp_b[nbr] = (short)node; }
+                    remove_vertex(node);
+                    remove_vertex(nbr);
                 }
             }
             consider = big;
