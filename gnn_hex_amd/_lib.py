@@ -27,7 +27,7 @@ _SIGS = {
     "hexgnn_padded_width": (ci, [ci]),
     "hexgnn_csr_workspace_bytes": (sz, [ci, ci]),
     "hexgnn_csr_build": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
-    "hexgnn_csr_build_grouped": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_csr_build_grouped": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_graph_ptr": (ci, [ci, ci, vp, vp, vp]),
     "hexgnn_sage_stack_pack_bytes": (sz, [ci, ci, ci]),
     "hexgnn_sage_stack_saved_bytes": (sz, [ci, ci, ci, ci]),

@@ -134,32 +134,44 @@ __global__ void unpad_rows_kernel(int n, int hidden, int hp, const float* __rest
 // the graph sets status bit 4 (as the fused kernels do), a node id outside [0, n) bit 1, a graph larger than
 // kCsrMaxGraph nodes bit 8; in each case the result is unspecified, exactly like the general build's status contract.
 constexpr int kCsrMaxGraph = 2048;
+constexpr int kCsrLdsEdges = 4096;      // graphs with at most this many edges are filled and sorted in LDS
+
+// first index i in [0, e) with dst[i] >= target (dst grouped by graph => monotone predicate): 256-ary search, one
+// dependent global load per round instead of log2(e)
+__device__ __forceinline__ int csr_lower_bound_256(const int64_t* __restrict__ dst, int e, int64_t target) {
+    int lo = 0, hi = e;     // every index < lo is below the target; index hi (if any) is not
+    while (lo < hi) {
+        const int step = (hi - lo + 255) / 256;
+        const int pos = lo + (int)threadIdx.x * step;
+        const bool below = pos < hi && dst[pos] < target;
+        const int c = __syncthreads_count(below);              // probes 0..c-1 are below (monotone predicate)
+        if (c == 0) { hi = lo; }
+        else { const int nlo = lo + (c - 1) * step + 1; hi = min(hi, lo + c * step); lo = nlo; }
+    }
+    return lo;
+}
 
 __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, const int64_t* __restrict__ src,
                                                          const int64_t* __restrict__ dst, const int* __restrict__ gptr,
+                                                         const int64_t* __restrict__ ptr64, int* __restrict__ gptr_out,
                                                          int* __restrict__ rowptr, int* __restrict__ col,
                                                          int* __restrict__ rowptr_t, int* __restrict__ col_t,
                                                          float* __restrict__ invdeg, int* __restrict__ status) {
     __shared__ int s_start[2][kCsrMaxGraph + 1];   // row starts (local, exclusive prefix), CSR and transpose
     __shared__ int s_cnt[2][kCsrMaxGraph];         // degree histogram, then fill cursors
     __shared__ int s_part[2][256];
-    __shared__ int s_range[2];
+    __shared__ int s_col[2][kCsrLdsEdges];         // this graph's col / col_t while they are filled and sorted
     const int g = blockIdx.x, tid = threadIdx.x;
-    const int r0 = gptr[g], r1 = gptr[g + 1];
+    const int r0 = ptr64 ? (int)ptr64[g] : gptr[g], r1 = ptr64 ? (int)ptr64[g + 1] : gptr[g + 1];
+    if (gptr_out && tid == 0) { gptr_out[g] = r0; if (g == b - 1) gptr_out[b] = r1; }
     const int cnt = r1 - r0;
     if (cnt > kCsrMaxGraph || cnt < 0) { if (tid == 0) atomicOr(status, 8); return; }
-    if (tid < 2) {
-        const int64_t target = tid == 0 ? r0 : r1;
-        int lo = 0, hi = e;
-        while (lo < hi) {
-            const int mid = (lo + hi) >> 1;
-            if (dst[mid] < target) lo = mid + 1; else hi = mid;
-        }
-        s_range[tid] = lo;
-    }
     for (int i = tid; i < cnt; i += 256) { s_cnt[0][i] = 0; s_cnt[1][i] = 0; }
+    const int eb = csr_lower_bound_256(dst, e, r0);
+    const int ee = csr_lower_bound_256(dst, e, r1);
+    const int ne = ee - eb;
+    const bool in_lds = ne <= kCsrLdsEdges;
     __syncthreads();
-    const int eb = s_range[0], ee = s_range[1];
     int flags = 0;
     for (int i = eb + tid; i < ee; i += 256) {
         const int64_t sv = src[i], dv = dst[i];
@@ -207,18 +219,20 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
     __syncthreads();
     for (int i = tid; i < cnt; i += 256) { s_cnt[0][i] = 0; s_cnt[1][i] = 0; }
     __syncthreads();
+    int* c0 = in_lds ? s_col[0] : col + eb;
+    int* c1 = in_lds ? s_col[1] : col_t + eb;
     for (int i = eb + tid; i < ee; i += 256) {
         const int64_t sv = src[i], dv = dst[i];
         if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) continue;
         const int d = (int)dv - r0, sl = (int)sv - r0;
-        col[eb + s_start[0][d] + atomicAdd(&s_cnt[0][d], 1)] = (int)sv;
-        col_t[eb + s_start[1][sl] + atomicAdd(&s_cnt[1][sl], 1)] = (int)dv;
+        c0[s_start[0][d] + atomicAdd(&s_cnt[0][d], 1)] = (int)sv;
+        c1[s_start[1][sl] + atomicAdd(&s_cnt[1][sl], 1)] = (int)dv;
     }
     __syncthreads();
-    // rows ascending (deterministic CSR); the row segments were written by this workgroup and are still in L2
+    // rows ascending (deterministic CSR)
     for (int i = tid; i < 2 * cnt; i += 256) {
         const int t = i >= cnt ? 1 : 0, r = t ? i - cnt : i;
-        int* c = (t ? col_t : col) + eb;
+        int* c = t ? c1 : c0;
         const int rb = s_start[t][r], re = s_start[t][r + 1];
         for (int k = rb + 1; k < re; ++k) {
             const int v = c[k];
@@ -226,6 +240,11 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
             while (j >= rb && c[j] > v) { c[j + 1] = c[j]; --j; }
             c[j + 1] = v;
         }
+    }
+    if (in_lds) {
+        __syncthreads();
+        const int valid = s_start[0][cnt];          // edges that passed validation (== ne when status stays clean)
+        for (int i = tid; i < valid; i += 256) { col[eb + i] = s_col[0][i]; col_t[eb + i] = s_col[1][i]; }
     }
 }
 
@@ -292,18 +311,23 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* 
     return check_launch();
 }
 
-int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr, int* rowptr,
-                             int* col, int* rowptr_t, int* col_t, float* invdeg, int* status, hexgnn_stream_t stream_) {
+int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                             const int64_t* ptr64, int* gptr_out, int* rowptr, int* col, int* rowptr_t, int* col_t,
+                             float* invdeg, int* status, hexgnn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (n < 0 || e < 0 || b < 0 || !rowptr || !rowptr_t || !status || !gptr || (n > 0 && !invdeg)) return HEXGNN_EINVAL;
+    if (n < 0 || e < 0 || b < 0 || !rowptr || !rowptr_t || !status || (!gptr && !ptr64) || (ptr64 && !gptr_out) ||
+        (n > 0 && !invdeg))
+        return HEXGNN_EINVAL;
     if (e > 0 && (!src || !dst || !col || !col_t)) return HEXGNN_EINVAL;
     (void)hipMemsetAsync(status, 0, sizeof(int), stream);
     KernelTimer kt(HEXGNN_K_CSR, stream);
     if (b > 0) {
-        csr_grouped_kernel<<<b, 256, 0, stream>>>(n, e, b, src, dst, gptr, rowptr, col, rowptr_t, col_t, invdeg, status);
+        csr_grouped_kernel<<<b, 256, 0, stream>>>(n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t,
+                                                  invdeg, status);
     } else {
         (void)hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(n + 1), stream);
         (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
+        if (gptr_out) (void)hipMemsetAsync(gptr_out, 0, sizeof(int), stream);
     }
     return check_launch();
 }

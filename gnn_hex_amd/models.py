@@ -318,13 +318,21 @@ class DuellingTwoHeaded(torch.nn.Module):
         n = x.shape[0]
         x2 = x[:, :2]
 
-        gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
         max_nodes = getattr(x, "_hex_max_nodes", None)
         gs = getattr(edge_index, "_hex_csr", None)          # CSR emitted by the env builder, if any
-        if gs is None or gs.n != n:
-            # edge_index CSR-sorted once per batch; collated batches (edges grouped by graph) take the one-launch build
-            grouped = getattr(edge_index, "_hex_grouped", False) and max_nodes is not None and max_nodes <= 2048
-            gs = ops.GraphStructure(edge_index, n, gptr, b) if grouped else ops.GraphStructure(edge_index, n)
+        # edge_index CSR-sorted once per batch; collated batches (edges grouped by graph) take the one-launch build
+        grouped = (gs is None or gs.n != n) and getattr(edge_index, "_hex_grouped", False) \
+            and max_nodes is not None and max_nodes <= 2048
+        if grouped and ptr is not None and ptr.dtype == torch.int64 and ptr.is_cuda and ptr.is_contiguous():
+            b = int(ptr.numel()) - 1            # the build reads the int64 ptr itself and emits the int32 copy
+            gptr = torch.empty(b + 1, dtype=torch.int32, device=x.device)
+            gs = ops.GraphStructure(edge_index, n, gptr, b, ptr64=ptr) if b > 0 else ops.GraphStructure(edge_index, n)
+            if b == 0:
+                gptr.zero_()
+        else:
+            gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
+            if gs is None or gs.n != n:
+                gs = ops.GraphStructure(edge_index, n, gptr, b) if grouped else ops.GraphStructure(edge_index, n)
         head = self.maker_head if is_maker else self.breaker_head
         mode = 2 if advantages_only else (1 if seperate else 0)
 

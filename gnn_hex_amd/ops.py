@@ -48,9 +48,12 @@ class GraphStructure:
 
     __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status")
 
-    def __init__(self, edge_index: torch.Tensor, num_nodes: int, gptr: Optional[torch.Tensor] = None, b: int = 0):
+    def __init__(self, edge_index: torch.Tensor, num_nodes: int, gptr: Optional[torch.Tensor] = None, b: int = 0,
+                 ptr64: Optional[torch.Tensor] = None):
         """``gptr`` (int32 [b+1] node ranges) selects the single-launch build for batches whose edges are grouped by
-        graph in graph order (``Batch.from_data_list``, the env builder); without it the general build runs."""
+        graph in graph order (``Batch.from_data_list``, the env builder); without it the general build runs.  With
+        ``ptr64`` (the batch's int64 ``ptr``) the node ranges are read from it and ``gptr`` (preallocated) receives the
+        int32 copy."""
         _require_cuda(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
@@ -69,7 +72,10 @@ class GraphStructure:
             self.col_t = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
             self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
             _lib.check(L.hexgnn_csr_build_grouped(n, e, int(b), edge_index[0].data_ptr(), edge_index[1].data_ptr(),
-                                                  gptr.data_ptr(), self.rowptr.data_ptr(), self.col.data_ptr(),
+                                                  gptr.data_ptr() if ptr64 is None else None,
+                                                  ptr64.data_ptr() if ptr64 is not None else None,
+                                                  gptr.data_ptr() if ptr64 is not None else None,
+                                                  self.rowptr.data_ptr(), self.col.data_ptr(),
                                                   self.rowptr_t.data_ptr(), self.col_t.data_ptr(), self.invdeg.data_ptr(),
                                                   self.status.data_ptr(), _stream()), "hexgnn_csr_build_grouped")
             return
