@@ -184,7 +184,8 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
                         const float* const* wl, const float* const* bl, const float* const* wr,
                         const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
                         const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
-                        int need_backward, int math, float* q, float* out_v, int* status, hexgnn_stream_t stream_) {
+                        int need_backward, int acts_layer, int math, float* q, float* out_v, int* status,
+                        hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 0 || b < 0 || mode < 0 || mode > 2 || math < 0 || math > 1) return HEXGNN_EINVAL;
     QPlan qp;
@@ -203,6 +204,7 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     QFwdArgs a;
     a.n = n; a.b = b; a.c_in = c_in; a.H = hidden; a.L = total_layers; a.mode = mode; a.x_stride = x_stride;
     a.need_backward = need_backward;
+    a.acts_layer = acts_layer;
     a.gptr = gptr; a.rowptr = rowptr; a.col = col; a.invdeg = invdeg; a.x = x;
     a.wpack = (const char*)wpack;
     for (int l = 0; l < total_layers; ++l) {

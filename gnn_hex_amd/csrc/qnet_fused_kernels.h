@@ -31,6 +31,7 @@ struct QFwdArgs {
     float* adv_raw; float* pooled; int* amax; int* amin; float* z; float* vraw;
     float* q; float* out_v; int* status;
     unsigned* xmax;   // [L] bit patterns of max |[agg|x]| per layer (math 1 + need_backward: feeds the f16 dW scales)
+    int acts_layer;   // inference (need_backward == 0): store only this layer's activations (-1: every layer's)
 };
 
 struct QBwdArgs {
@@ -348,7 +349,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) xr[4 * t] = xs[t];
-        if (rvalid) {
+        if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == 0)) {
             f32x4* yo = reinterpret_cast<f32x4*>(a.acts + (size_t)grow * HP) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
@@ -439,7 +440,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 xs[t] = v;
                 xr[4 * t] = v;
             }
-            if (rvalid) {
+            if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == l)) {
                 f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];

@@ -364,7 +364,8 @@ class QNetFusedFn(torch.autograd.Function):
             n, b, c_in, hidden, tot, mode, gptr.data_ptr(), gs.rowptr.data_ptr(), gs.col.data_ptr(),
             gs.invdeg.data_ptr(), x.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr),
             tail[0].data_ptr(), tail[1].data_ptr(), tail[2].data_ptr(), tail[3].data_ptr(), tail[4].data_ptr(),
-            tail[5].data_ptr(), wpack.data_ptr(), acts.data_ptr(), saved.data_ptr(), int(need_bwd), _MATH, q.data_ptr(),
+            tail[5].data_ptr(), wpack.data_ptr(), acts.data_ptr(), saved.data_ptr(), int(need_bwd), body_layers - 1, _MATH,
+            q.data_ptr(),
             out_v.data_ptr() if out_v is not None else None, status.data_ptr(), _stream()), "hexgnn_qnet_forward")
         embeds = acts[body_layers - 1][:, :hidden]
         ctx.mark_non_differentiable(embeds)

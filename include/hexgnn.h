@@ -149,7 +149,10 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
                         const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
                         const float* v1_w, const float* v1_b,
                         void* wpack /* hexgnn_sage_stack_pack_bytes(c_in, hidden, total_layers) */,
-                        float* acts /*[total_layers][n][HP]*/, void* saved, int need_backward, int math,
+                        float* acts /*[total_layers][n][HP]*/, void* saved, int need_backward,
+                        int acts_layer /* need_backward == 0: store only this layer's activations (the body output read as
+                                          final_conv_acts); -1: every layer's */,
+                        int math,
                         float* q /*[n]*/, float* out_v /*[b] (mode 1) or NULL*/, int* status /*[1], caller-zeroed*/,
                         hexgnn_stream_t stream);
 size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, int total_layers);
