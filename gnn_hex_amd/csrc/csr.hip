@@ -134,7 +134,7 @@ __global__ void unpad_rows_kernel(int n, int hidden, int hp, const float* __rest
 // the graph sets status bit 4 (as the fused kernels do), a node id outside [0, n) bit 1, a graph larger than
 // kCsrMaxGraph nodes bit 8; in each case the result is unspecified, exactly like the general build's status contract.
 constexpr int kCsrMaxGraph = 2048;
-constexpr int kCsrLdsEdges = 4096;      // graphs with at most this many edges are filled and sorted in LDS
+constexpr int kCsrLdsEdges = 3072;      // graphs with at most this many edges are filled and sorted in LDS (static LDS < 64 KB)
 
 // first index i in [0, e) with dst[i] >= target (dst grouped by graph => monotone predicate): 256-ary search, one
 // dependent global load per round instead of log2(e)
@@ -219,32 +219,36 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
     __syncthreads();
     for (int i = tid; i < cnt; i += 256) { s_cnt[0][i] = 0; s_cnt[1][i] = 0; }
     __syncthreads();
-    int* c0 = in_lds ? s_col[0] : col + eb;
-    int* c1 = in_lds ? s_col[1] : col_t + eb;
-    for (int i = eb + tid; i < ee; i += 256) {
-        const int64_t sv = src[i], dv = dst[i];
-        if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) continue;
-        const int d = (int)dv - r0, sl = (int)sv - r0;
-        c0[s_start[0][d] + atomicAdd(&s_cnt[0][d], 1)] = (int)sv;
-        c1[s_start[1][sl] + atomicAdd(&s_cnt[1][sl], 1)] = (int)dv;
-    }
-    __syncthreads();
-    // rows ascending (deterministic CSR)
-    for (int i = tid; i < 2 * cnt; i += 256) {
-        const int t = i >= cnt ? 1 : 0, r = t ? i - cnt : i;
-        int* c = t ? c1 : c0;
-        const int rb = s_start[t][r], re = s_start[t][r + 1];
-        for (int k = rb + 1; k < re; ++k) {
-            const int v = c[k];
-            int j = k - 1;
-            while (j >= rb && c[j] > v) { c[j + 1] = c[j]; --j; }
-            c[j + 1] = v;
+    // Two explicit code paths: a pointer that may be LDS or global becomes a FLAT pointer, and flat accesses into a large
+    // LDS allocation faulted on gfx950 (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, found with random-playout batches).
+    auto fill_and_sort = [&](auto* c0, auto* c1) {
+        for (int i = eb + tid; i < ee; i += 256) {
+            const int64_t sv = src[i], dv = dst[i];
+            if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) continue;
+            const int d = (int)dv - r0, sl = (int)sv - r0;
+            c0[s_start[0][d] + atomicAdd(&s_cnt[0][d], 1)] = (int)sv;
+            c1[s_start[1][sl] + atomicAdd(&s_cnt[1][sl], 1)] = (int)dv;
         }
-    }
+        __syncthreads();
+        // rows ascending (deterministic CSR)
+        for (int i = tid; i < 2 * cnt; i += 256) {
+            const int t = i >= cnt ? 1 : 0, r = t ? i - cnt : i;
+            const int rb = s_start[t][r], re = s_start[t][r + 1];
+            for (int k = rb + 1; k < re; ++k) {
+                const int v = t ? c1[k] : c0[k];
+                int j = k - 1;
+                while (j >= rb && (t ? c1[j] : c0[j]) > v) { if (t) c1[j + 1] = c1[j]; else c0[j + 1] = c0[j]; --j; }
+                if (t) c1[j + 1] = v; else c0[j + 1] = v;
+            }
+        }
+    };
     if (in_lds) {
+        fill_and_sort(&s_col[0][0], &s_col[1][0]);
         __syncthreads();
         const int valid = s_start[0][cnt];          // edges that passed validation (== ne when status stays clean)
         for (int i = tid; i < valid; i += 256) { col[eb + i] = s_col[0][i]; col_t[eb + i] = s_col[1][i]; }
+    } else {
+        fill_and_sort(col + eb, col_t + eb);
     }
 }
 

@@ -94,6 +94,24 @@ def test_csr_build_bit_exact():
     gg.check()
 
 
+def test_grouped_csr_build_random_playout_batch():
+    """256 mid-game Hex-11 boards of very different sizes (3..123 nodes): the one-launch build must equal the general one
+    (regression: a flat pointer into the workgroup's LDS faulted on exactly this kind of batch)."""
+    from gnn_hex_amd import ops
+    x, ei, batch, ptr = batch_tensors("D1", [11] * 256)
+    n = x.shape[0]
+    ref = ops.GraphStructure(ei.cuda(), n)
+    gptr = torch.empty(257, dtype=torch.int32, device="cuda")
+    gg = ops.GraphStructure(ei.cuda(), n, gptr, 256, ptr64=ptr.cuda())
+    torch.cuda.synchronize()
+    gg.check()
+    assert torch.equal(gptr.long().cpu(), ptr)
+    for name in ("rowptr", "rowptr_t", "invdeg"):
+        assert torch.equal(getattr(gg, name), getattr(ref, name)), name
+    e = ei.shape[1]
+    assert torch.equal(gg.col[:e], ref.col[:e]) and torch.equal(gg.col_t[:e], ref.col_t[:e])
+
+
 def test_grouped_csr_build_edge_cases():
     """Grouped build: empty graphs, a graph without edges, directed (asymmetric) edges, isolated nodes, and the status
     bit when the batch is not actually grouped."""
