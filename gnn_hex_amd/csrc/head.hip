@@ -380,7 +380,7 @@ __global__ __launch_bounds__(64) void select_actions_kernel(int b, const int* __
             ex = 1;
         }
         act_rank[g] = rank;
-        act_vertex[g] = rank >= 0 ? (int)backmap[r0 + rank] : -1;
+        if (act_vertex) act_vertex[g] = rank >= 0 ? (backmap ? (int)backmap[r0 + rank] : rank) : -1;
         if (expl) expl[g] = ex;
     }
 }
@@ -393,7 +393,7 @@ extern "C" {
 
 int hexgnn_select_actions(int b, const int* gptr, const float* q, const int64_t* backmap, float eps, const float* u,
                           int* action_vertex, int* action_rank, uint8_t* exploratory, hexgnn_stream_t stream_) {
-    if (b < 0 || (b > 0 && (!gptr || !q || !backmap || !action_vertex || !action_rank))) return HEXGNN_EINVAL;
+    if (b < 0 || (b > 0 && (!gptr || !q || !action_rank))) return HEXGNN_EINVAL;
     if (b == 0) return HEXGNN_OK;
     select_actions_kernel<<<b, 64, 0, (hipStream_t)stream_>>>(b, gptr, q, backmap, eps, u, action_vertex, action_rank,
                                                               exploratory);

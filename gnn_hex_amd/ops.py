@@ -486,3 +486,19 @@ def td_loss(q: torch.Tensor, sel: torch.Tensor, target: torch.Tensor, weights: O
     if q.device.type != "cuda":
         raise _lib.HexGnnError("td_loss runs only on the MI355X HIP path (no CPU fallback)")
     return TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])
+
+
+def greedy_nodes(q: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:
+    """For every graph of a batch the global index of its best non-terminal node: ``ptr[g] + 2 + argmax(q[ptr[g]+2 :
+    ptr[g+1]])`` (first maximum) -- the per-graph python argmax of GN0/RainbowDQN/evaluate_elo.py:253-266, and the
+    double-DQN action selection over a sampled batch, as one launch (``hexgnn_select_actions`` without a backmap)."""
+    _require_cuda(q, "q")
+    b = int(ptr.numel()) - 1
+    gptr = ptr.to(device=q.device, dtype=torch.int32)
+    qf = q.reshape(-1)
+    if qf.dtype != torch.float32 or not qf.is_contiguous():
+        qf = qf.float().contiguous()
+    rank = torch.empty(b, dtype=torch.int32, device=q.device)
+    _lib.check(_lib.lib().hexgnn_select_actions(b, gptr.data_ptr(), qf.data_ptr(), None, 0.0, None, None, rank.data_ptr(),
+                                                None, _stream()), "hexgnn_select_actions")
+    return gptr[:-1].long() + rank.long()

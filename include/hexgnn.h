@@ -265,7 +265,8 @@ int hexgnn_td_loss_backward(int n, int k, const int64_t* sel, const float* td, c
 /* ---- acting: epsilon-greedy action per graph straight from the Q / advantage vector (replaces the per-graph python
  *      argmax over action_values[ptr[g]+2 : ptr[g+1]] of GN0/RainbowDQN/evaluate_elo.py:253-266 and the backmap lookup
  *      of Env_manager.validate_actions, graph_game/multi_env_manager.py:62-64).  u: [b][2] uniforms in [0,1) or NULL for
- *      pure greedy.  action_vertex feeds hexgnn_env_step without leaving the device. ---------------------------------- */
+ *      pure greedy.  backmap / action_vertex may be NULL (ranks only: the double-DQN argmax over a sampled batch).
+ *      action_vertex feeds hexgnn_env_step without leaving the device. ---------------------------------- */
 int hexgnn_select_actions(int b, const int* gptr, const float* q, const int64_t* backmap, float eps, const float* u,
                           int* action_vertex /*[b]*/, int* action_rank /*[b]*/, uint8_t* exploratory /*[b] or NULL*/,
                           hexgnn_stream_t stream);

@@ -50,10 +50,10 @@ def test_rollout_replay_update_loop(math):
                     # the next state has the SAME side to move (2n plies later): double DQN over the non-terminal nodes
                     q_next_online = q_net(s2.x, s2.edge_index, s2.batch, s2.ptr)
                     q_next_target = target_net(s2.x, s2.edge_index, s2.batch, s2.ptr)
-                    best = torch.empty(64, dtype=torch.long, device="cuda")
+                    best = ops.greedy_nodes(q_next_online, s2.ptr)
                     p2 = s2.ptr.tolist()
-                    for g in range(64):
-                        best[g] = p2[g] + 2 + int(torch.argmax(q_next_online[p2[g] + 2:p2[g + 1]]))
+                    g0 = 5
+                    assert int(best[g0]) == p2[g0] + 2 + int(torch.argmax(q_next_online[p2[g0] + 2:p2[g0 + 1]]))
                     y = r + (gamma ** n_step) * q_next_target[best] * (~d).float()
                 q = q_net(s.x, s.edge_index, s.batch, s.ptr)
                 sel = s.ptr[:-1] + act.long()
