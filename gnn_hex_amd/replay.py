@@ -51,6 +51,7 @@ class GraphReplayBuffer:
         self.done = z(C, dtype=torch.bool)
         self.n_nodes = np.zeros(2 * C, dtype=np.int64)      # host copies of the graph sizes (known when stored)
         self.n_edges = np.zeros(2 * C, dtype=np.int64)
+        self.side_host = np.zeros(2 * C, dtype=np.uint8)    # host mirror of `side` (sampling needs it without a sync)
         self.pos, self.size = 0, 0
         self.cap2 = _pow2_at_least(C)
         self.sum_tree = torch.empty(2 * self.cap2, dtype=torch.float64, device=dev)
@@ -94,6 +95,7 @@ class GraphReplayBuffer:
             self.adj[st] = snap_adj[it]
             self.alive[st] = snap_alive[it]
             self.side[st] = torch.as_tensor(side, dtype=torch.uint8, device=dev)
+            self.side_host[np.asarray(slot, dtype=np.int64)] = np.asarray(side, dtype=np.uint8)
 
     def put(self, transitions: List[tuple]) -> None:
         """Append transitions ``(state, action, reward, next_state, done)`` as returned by
@@ -137,6 +139,7 @@ class GraphReplayBuffer:
             self.adj[sd] = snap_adj[it]
             self.alive[sd] = snap_alive[it]
         self.side[torch.from_numpy(slots).to(dev)] = 1 if side else 0
+        self.side_host[slots] = 1 if side else 0
 
     def put_block(self, block) -> None:
         """Append a ``TransitionBlock`` from ``Env_manager.assemble_transitions`` (array form of ``put``)."""
@@ -224,9 +227,8 @@ class GraphReplayBuffer:
         state = self._build_batch(idx, host)
         nxt = self._build_batch(idx + self.capacity, host + self.capacity)
         # all stored states of one buffer share the mover's side (maker / breaker buffers are separate)
-        side = bool(self.side[int(host[0])].item()) if batch_size else True
-        state.x._hex_is_maker = side
-        nxt.x._hex_is_maker = bool(self.side[int(host[0]) + self.capacity].item())
+        state.x._hex_is_maker = bool(self.side_host[int(host[0])]) if batch_size else True
+        nxt.x._hex_is_maker = bool(self.side_host[int(host[0]) + self.capacity]) if batch_size else True
         return idx, w, state, nxt, self.action[idx], self.reward[idx], self.done[idx]
 
     def update_priorities(self, indices: torch.Tensor, td_errors: torch.Tensor) -> None:
