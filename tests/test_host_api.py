@@ -152,3 +152,55 @@ def test_reference_checkpoint_format_round_trip(tmp_path):
     ref2 = get_pre_defined_ref("modern_two_headed", args)
     ref2.load_state_dict(torch.load(path2, weights_only=False)["state_dict"])
     model.import_norm_cache(None, None, None)          # norm=False: a no-op, as in the reference
+
+
+def test_vectorised_transition_assembly_matches_loop_form_on_host():
+    """Env_manager.assemble_transitions (numpy over envs) against the reference loop of get_transitions
+    (multi_env_manager.py:113-165), on fabricated histories -- no GPU involved: the manager is built without its device
+    handles and its start observation is stubbed."""
+    import numpy as np
+    from gnn_hex_amd.data import Data
+    from gnn_hex_amd.multi_env_manager import Env_manager, ObsList
+
+    class FakeObs(ObsList):
+        def __init__(self, k, maker):
+            super().__init__(None, None, None, None, None, list(range(0, 3 * k + 1, 3)), list(range(0, 2 * k + 1, 2)), None,
+                             maker, 3, None)
+            self._d = [Data(x=torch.tensor([[1.0, 1.0, float(maker)]] * 3), edge_index=torch.zeros((2, 2), dtype=torch.long))
+                       for _ in range(k)]
+
+        def __getitem__(self, i):
+            return self._d[i]
+
+    class HostOnlyManager(Env_manager):      # no device handles: only the transition maths is exercised
+        def __init__(self, n_steps, prune):
+            self.gamma, self.n_steps, self.prune_exploratories = 0.9, n_steps, prune
+            self._base, self._base_sizes, self._h = None, None, None
+
+        def _observe_handle(self, *a, **k):
+            return FakeObs(1, True)
+
+        @property
+        def starting_obs(self):
+            return Data(x=torch.zeros((3, 3)), edge_index=torch.zeros((2, 2), dtype=torch.long), backmap=torch.arange(3))
+
+    rng = np.random.default_rng(3)
+    for prune in (True, False):
+        for n_steps in ([1], [2], [1, 3]):
+            mgr = HostOnlyManager(n_steps, prune)
+            if True:
+                T, E = 14, 6
+                start = FakeObs(E, True)
+                states = [FakeObs(E, (t % 2) == 1) for t in range(T)]       # side alternates: state t+1 after move t
+                actions = [rng.integers(0, 3, E) for _ in range(T)]
+                dones = [rng.random(E) < 0.15 for _ in range(T)]
+                rewards = [np.where(d, rng.choice([-1.0, 1.0], E), 0.0) for d in dones]
+                expl = [rng.random(E) < 0.25 for _ in range(T)]
+                mb, bb = mgr.assemble_transitions(start, states, actions, rewards, dones, expl)
+                ml, bl = mgr.get_transitions(start, states, actions, rewards, dones, expl)
+                for block, lst in ((mb, ml), (bb, bl)):
+                    assert len(block) == len(lst) and len(lst) > 0
+                    assert block.action.tolist() == [int(t[1]) for t in lst]
+                    assert np.allclose(block.reward, [t[2] for t in lst])
+                    assert block.done.tolist() == [bool(t[4]) for t in lst]
+                    assert (block.next_step[block.done] == -1).all() and (block.next_step[~block.done] >= 0).all()
