@@ -138,18 +138,36 @@ __device__ __forceinline__ void mfma_chunk(const f32x4* __restrict__ wfrag /* &w
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 
-// x*s = hi + lo (+ O(2^-22 |x s|)) with hi, lo in fp16; s is the row's power-of-two scale (exact)
+// x*s = hi + lo (+ O(2^-22 |x s|)) with hi, lo in fp16; s is the row's power-of-two scale (exact).  Written pair by pair
+// on 2-vectors so that hipcc emits v_cvt_pk_f16_f32 for the hi halves and v_fma_mixlo/mixhi_f16 (x*s - hi, fused, straight
+// into the low / high half of the operand dword) for the lo halves instead of per-element converts and register shuffles.
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4v __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(const float x0, const float x1, const float s, unsigned& hi, unsigned& lo) {
+    const float v0 = x0 * s, v1 = x1 * s;
+    const f16x2 h = {(_Float16)v0, (_Float16)v1};
+    const f16x2 l = {(_Float16)(v0 - (float)h[0]), (_Float16)(v1 - (float)h[1])};
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+}
 __device__ __forceinline__ void split_pair(const f32x4 a, const f32x4 b, const float s, f16x8& hi, f16x8& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float va = a[j] * s, vb = b[j] * s;
-        hi[j] = (_Float16)va; hi[4 + j] = (_Float16)vb;
-        lo[j] = (_Float16)(va - (float)hi[j]); lo[4 + j] = (_Float16)(vb - (float)hi[4 + j]);
-    }
+    u32x4v H, L;
+    unsigned h, l;
+    split2(a[0], a[1], s, h, l); H[0] = h; L[0] = l;
+    split2(a[2], a[3], s, h, l); H[1] = h; L[1] = l;
+    split2(b[0], b[1], s, h, l); H[2] = h; L[2] = l;
+    split2(b[2], b[3], s, h, l); H[3] = h; L[3] = l;
+    hi = __builtin_bit_cast(f16x8, H);
+    lo = __builtin_bit_cast(f16x8, L);
 }
 __device__ __forceinline__ void split_one(const f32x4 a, const float s, f16x4& hi, f16x4& lo) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { const float v = a[j] * s; hi[j] = (_Float16)v; lo[j] = (_Float16)(v - (float)hi[j]); }
+    u32x2v H, L;
+    unsigned h, l;
+    split2(a[0], a[1], s, h, l); H[0] = h; L[0] = l;
+    split2(a[2], a[3], s, h, l); H[1] = h; L[1] = l;
+    hi = __builtin_bit_cast(f16x4, H);
+    lo = __builtin_bit_cast(f16x4, L);
 }
 
 __device__ __forceinline__ void row_scale(const float m, float& s, float& inv) { pow2_scale(m, s, inv); }
