@@ -421,3 +421,38 @@ def test_td_loss_matches_torch(loss_fn, weighted):
     assert torch.allclose(td.cpu(), d.detach(), atol=1e-6)
     assert torch.allclose(qh.grad.cpu(), qr.grad, atol=1e-7)
     assert not td.requires_grad
+
+
+def test_randomised_configurations():
+    """Seeded sweep over widths, depths, batch shapes, edge densities, directed / symmetric graphs, both CSR builds and both
+    arithmetic modes of the fused kernels against the oracle (1e-4 on Q, 1e-4 relative to max(1, |g|max) on gradients)."""
+    from gnn_hex_amd import ops
+    if ops.get_math() != "fp32" or not ops._FUSED_ENABLED:
+        pytest.skip("mode-independent: sets the modes itself")
+    rng = np.random.default_rng(2026)
+    for case in range(30):
+        hidden = int(rng.choice([16, 35, 48, 64, 96, 110]))
+        layers = int(rng.integers(1, 6))
+        sizes = [int(rng.integers(3, 129)) for _ in range(int(rng.integers(1, 9)))]
+        p_edge = float(rng.choice([0.02, 0.06, 0.15]))
+        grouped = bool(rng.integers(0, 2))
+        math = str(rng.choice(["fp32", "f16x3"]))
+        hip, ref = make_pair(layers, hidden, seed=case)
+        x, ei, batch, ptr = _random_batch(sizes, seed=case, directed=bool(rng.integers(0, 2)), p_edge=p_edge)
+        sel, tgt = sel_and_targets(ptr)
+        q_ref, g_ref = _step(ref, x, ei, batch, ptr, sel, tgt)
+        ops.set_math(math)
+        xd, eid = x.cuda(), ei.cuda()
+        xd._hex_is_maker, xd._hex_max_nodes = True, max(sizes)
+        if grouped:
+            eid._hex_grouped = True
+        q, g = _step(hip, xd, eid, batch.cuda(), ptr.cuda(), sel.cuda(), tgt.cuda())
+        torch.cuda.synchronize()
+        tag = "case %d: hidden %d, %d layers, sizes %s, p %.2f, grouped %s, %s" % (case, hidden, layers, sizes, p_edge, grouped, math)
+        assert (q.cpu() - q_ref).abs().max().item() < TOL, tag
+        for k in g_ref:
+            if g_ref[k] is None:
+                assert g[k] is None, tag
+                continue
+            scale = max(1.0, g_ref[k].abs().max().item())
+            assert (g[k].cpu() - g_ref[k]).abs().max().item() < TOL * scale, tag + " " + k
