@@ -629,24 +629,20 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int H2 = H / 2, H4 = 4 * H;
     constexpr int kStage = (kHalf + 511) / 512;
 
-    // stage both weight halves of the top layer (tiles t < NT -> half A, t >= NT -> half B)
+    // stage the W_l part of the top layer into half A (its W_r part is streamed inside the layer loop)
     if (L > 1) {
         const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]);
-        constexpr int kPer = (2 * LD::kHalf + 511) / 512;
-        f32x4 tmp[kPer];
+        f32x4 tmp[kStage];
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) { const int i = tid + 512 * k; if (i < 2 * kHalf) tmp[k] = src[i]; }
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
+        for (int k = 0; k < kStage; ++k) {
             const int i = tid + 512 * k;
-            if (i < 2 * kHalf) {
-                if constexpr (MATH == 1) wbuf[i] = tmp[k];
-                else {
-                    const int li = i & 63, ct = i >> 6, c = ct / (2 * NT), t = ct % (2 * NT);
-                    wbuf[(t < NT ? 0 : kHalf) + (c * NT + (t % NT)) * 64 + li] = tmp[k];
-                }
+            if (i < kHalf) {
+                if constexpr (MATH == 1) tmp[k] = src[i];
+                else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; tmp[k] = src[(c * 2 * NT + t) * 64 + li]; }
             }
         }
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = tmp[k]; }
     }
 
     // ---- head tail backward; scratch aliases dbuf (not written before the first barrier A) ----
@@ -755,25 +751,109 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     }
     __syncthreads();   // scratch consumed; dbuf may be overwritten from here on
 
-    // ---- layer chain ----
-    // y rows of the layer about to be masked are fetched one layer ahead (global latency off the critical path)
-    f32x4 ycur[NT];
+    // ---- layer chain, in the forward kernel's shape ----
+    //   dL/dy_{l-1} = [ T(G_l / deg) | G_l ] [W_l ; W_r]   (T = gather over the transposed CSR; linear, so the gather is
+    //   moved in front of the contraction): per layer  gather from LDS -> K-half over the W_l part -> barrier ->
+    //   K-half over the W_r part with G_l from registers -> mask by y_{l-1} -> publish G_{l-1} (global + LDS) -> barrier.
+    const float idg = rvalid ? a.invdeg[grow] : 0.f;
+    f32x4 ycur[NT];      // y rows of the layer masked next; re-loaded one layer ahead
 #pragma unroll
     for (int t = 0; t < NT; ++t) ycur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (rvalid && L > 1) {
+    if (rvalid) {
         const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) ycur[t] = yr[4 * t];
     }
-    for (int l = L - 1; l >= 1; --l) {
-        if (a.d_embeds && l == a.body_layers - 1 && rvalid) {
-            f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
+    // gx = dL/dy_l  ->  G_l = gx * [y_l > 0]: stored for the weight-gradient GEMM, and (l >= 1) G_l / deg placed in this
+    // lane's LDS row for the neighbours' gathers; y_{l-1} is requested for the next call.
+    auto publish = [&](const int l) {
+        if (rvalid) {
+            if (a.d_embeds && l == a.body_layers - 1) {
+                f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
+                for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
+            }
+            f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
+            const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l > 0 ? l - 1 : 0) + (size_t)grow * HP) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 yv = ycur[t];
+                if (l > 0) ycur[t] = yn[4 * t];
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
+                go[4 * t] = gx[t];
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (l > 0) {
+            f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) dr[4 * t] = gx[t] * idg;
+            if constexpr (MATH == 1) {
+                if (a.gmax) {
+                    const float wm = rows_max16(row_max4(frag_absmax<NT>(gx, 0.f)));
+                    if (lane == 0) s_max[wave] = wm;
+                }
+            }
+        }
+    };
+    if (wactive) publish(L - 1);
+    lds_barrier();
+    for (int l = L - 1; l >= 1; --l) {
         f32x4 stg[kStage];
+        {   // stream the W_r part of layer l towards half B
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l]);
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) {
+                const int i = tid + 512 * k;
+                if (i < kHalf) {
+                    if constexpr (MATH == 1) stg[k] = src[kHalf + i];
+                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
+                }
+            }
+        }
+        if constexpr (MATH == 1) {
+            if (a.gmax && tid == 0) {   // layer maximum of |G_l| over this graph -> global (order-independent)
+                float mm = 0.f;
+#pragma unroll
+                for (int w8 = 0; w8 < 8; ++w8) mm = fmaxf(mm, s_max[w8]);
+                atomicMax(a.gmax + l, __builtin_bit_cast(unsigned, mm));
+            }
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float rs = 1.f, rinv = 1.f;
+        if (wactive) {
+            // phase 1: transposed gather of G_l / deg from LDS, then K-half over the W_l part (half A)
+            f32x4 ag[NT];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (rvalid) {
+                if (csr_lds) {
+                    gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, ag);
+                } else {
+                    for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
+                        const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) ag[c] += dj[4 * c];
+                    }
+                }
+            }
+            if constexpr (MATH == 1) {   // one power-of-two scale per row over [T(G/deg) | G]
+                const float m = row_max4(frag_absmax<NT>(gx, frag_absmax<NT>(ag, 0.f)));
+                row_scale(m, rs, rinv);
+                rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
+            }
+            contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
+        }
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        lds_barrier();     // barrier 1: half B = W_r part; every gather of this layer is done (dbuf free); half A free
         const bool more = l - 1 >= 1;
-        if (more) {   // stream [W_l part] of layer l-1 towards half A
+        if (more) {   // stream the W_l part of layer l-1 towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
 #pragma unroll
             for (int k = 0; k < kStage; ++k) {
@@ -784,106 +864,18 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 }
             }
         }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float rs = 1.f, rinv = 1.f;
         if (wactive) {
-            // mask by this layer's ReLU, publish G_l
-            if (rvalid) {
-                f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
-                const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
+            // phase 2: K-half over the W_r part (half B) with G_l from registers; the result is dL/dy_{l-1}
+            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const f32x4 yv = ycur[t];
-                    ycur[t] = yn[4 * t];          // layer l-1's rows for the next iteration (layer 0's for the epilogue)
-#pragma unroll
-                    for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
-                    go[4 * t] = gx[t];
-                }
-            }
-            // phase 1: dAggS = (G W_l) / deg     (half A)
-            if constexpr (MATH == 1) {
-                const float m = row_max4(frag_absmax<NT>(gx, 0.f));
-                row_scale(m, rs, rinv);
-                if (a.gmax) { const float wm = rows_max16(m); if (lane == 0) s_max[wave] = wm; }
-                rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
-            }
-            contract_half<NT, MATH>(wbuf, lane, gx, acc, rs);
-        }
-        lds_barrier();     // barrier A: gathers of the previous layer are done (dbuf free); half A free
-        if constexpr (MATH == 1) {
-            if (a.gmax && tid == 0) {
-                float mm = 0.f;
-#pragma unroll
-                for (int w8 = 0; w8 < 8; ++w8) mm = fmaxf(mm, s_max[w8]);
-                atomicMax(a.gmax + l, __builtin_bit_cast(unsigned, mm));
-            }
+            for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
+            publish(l - 1);
         }
         if (more) {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) {   // stream [W_r part] of layer l-1 towards half B
-                const int i = tid + 512 * k;
-                if (i < kHalf) {
-                    if constexpr (MATH == 1) stg[k] = src[kHalf + i];
-                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
-                }
-            }
         }
-        f32x4 dxs[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) dxs[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        {
-            const float scl = rvalid ? a.invdeg[grow] * rinv : 0.f;
-            f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) dr[4 * t] = acc[t] * scl;
-        }
-        if (wactive) {
-            // phase 2: dXs = G W_r     (half B)
-            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, dxs, rs);
-        }
-        lds_barrier();     // barrier B: dAggS rows + half A visible; half B free
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
-        }
-        // gradient w.r.t. this layer's input = dXs + transposed gather of dAggS
-#pragma unroll
-        for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? dxs[t] * rinv : dxs[t];
-        if (rvalid) {
-            if (csr_lds) {
-                gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, gx);
-            } else {
-                for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
-                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) gx[c] += dj[4 * c];
-                }
-            }
-        }
-    }
-    // ---- layer 0: G_0 = grad * [y_0 > 0] (its weight gradient is a separate VALU kernel) ----
-    if (a.d_embeds && a.body_layers - 1 == 0 && rvalid) {
-        f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
-    }
-    if (rvalid) {
-        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + (size_t)grow * HP) + g;
-        f32x4* go = reinterpret_cast<f32x4*>(a.G + (size_t)grow * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 yv = L > 1 ? ycur[t] : yr[4 * t];
-            f32x4 v = gx[t];
-#pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) v[q4] = yv[q4] > 0.f ? v[q4] : 0.f;
-            go[4 * t] = v;
-            gx[t] = v;
-        }
+        lds_barrier();     // barrier 2: G_{l-1} rows + half A visible; half B free
     }
     // ---- raw first layer: this graph's share of dW_0 = G_0^T [agg0 | x0 | 1], reduced over the graphs afterwards ----
     if (a.first_part) {
