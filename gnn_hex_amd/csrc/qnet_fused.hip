@@ -321,4 +321,15 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     return check_launch();
 }
 
+
+#ifdef HEXGNN_STAMPS
+// profiling builds only: copies the s_memtime stamps of the exact-fp32 fused kernels to `out` (host pointer)
+int hexgnn_debug_stamps(unsigned long long* out, int capacity) {
+    const int total = 2 * (kMaxLayers + 2) * kStampPoints * 8;
+    if (capacity < total) return HEXGNN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return HEXGNN_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hexgnn::g_qstamps), sizeof(unsigned long long) * total) != hipSuccess) return HEXGNN_EHIP;
+    return total;
+}
+#endif
 }  // extern "C"

@@ -21,6 +21,16 @@ constexpr int kMaxL = kMaxLayers;
 constexpr int kRows = 128;            // rows per workgroup
 constexpr int kLdsBytes = 160 * 1024;
 
+// Profiling aid (build with `make STAMPS=1`, never shipped): lane 0 of every wave of workgroup 0 records s_memtime at the
+// marked points of each layer; tools/stamps.py prints the per-wave timeline DESIGN.md quotes.
+#ifdef HEXGNN_STAMPS
+constexpr int kStampPoints = 10;
+static __device__ unsigned long long g_qstamps[2][kMaxLayers + 2][kStampPoints][8];
+#define QSTAMP(k, l, p) do { if (blockIdx.x == 0 && lane == 0) g_qstamps[k][l][p][wave] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define QSTAMP(k, l, p) do {} while (0)
+#endif
+
 struct QFwdArgs {
     int n, b, c_in, H, L, mode, x_stride, need_backward;
     const int* gptr; const int* rowptr; const int* col; const float* invdeg;
@@ -278,6 +288,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int gi = blockIdx.x;
+    QSTAMP(0, 0, 0);
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
     if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
@@ -378,7 +389,10 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     // ---- hidden layers ----
     constexpr int kStage = (kHalf + 511) / 512;
     const size_t slab = (size_t)a.n * HP;
+    const float validf = rvalid ? 1.f : 0.f;
+    QSTAMP(0, 0, 1);
     for (int l = 1; l < a.L; ++l) {
+        QSTAMP(0, l, 0);
         f32x4 stg[kStage];
         {   // stream W_r(l) towards half B
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]) + kHalf;
@@ -417,6 +431,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                     for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
                 }
             }
+            QSTAMP(0, l, 1);
             if constexpr (MATH == 1) {   // one power-of-two scale per row over [agg | x]; the bias joins the scaled sum
                 const float m = row_max4(frag_absmax<NT>(xs, frag_absmax<NT>(ag, 0.f)));
                 row_scale(m, rs, rinv);
@@ -428,10 +443,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 for (int t = 0; t < NT; ++t) acc[t] *= up;
             }
             contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
+            QSTAMP(0, l, 2);
         }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        QSTAMP(0, l, 3);
         lds_barrier();     // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
+        QSTAMP(0, l, 4);
         if constexpr (MATH == 1) {
             if (a.xmax && tid == 0) {   // layer maximum of [agg | x] over this graph -> global (order-independent)
                 float mm = 0.f;
@@ -448,13 +466,23 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         if (wactive) {
             // phase 2: K-half over W_r (half B) with the self rows kept in registers
             contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs);
+            QSTAMP(0, l, 5);
+        }
+        // staged half A -> LDS BEFORE the epilogue's global stores: vmcnt counts loads and stores in one in-order
+        // counter, so a wait for the staged loads placed after the stores also waits for the stores' L2 acknowledgement
+        if (l + 1 < a.L) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
+        }
+        if (wactive) {
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 v = acc[t];
                 if constexpr (MATH == 1) v *= rinv;
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) v[q4] = (rvalid && v[q4] > 0.f) ? v[q4] : 0.f;
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = fmaxf(v[q4], 0.f);
+                v *= validf;              // pad rows stay exactly zero
                 xs[t] = v;
                 xr[4 * t] = v;
             }
@@ -464,11 +492,9 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
             }
         }
-        if (l + 1 < a.L) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-        }
+        QSTAMP(0, l, 6);
         lds_barrier();     // barrier 2: new rows + half A visible; half B free
+        QSTAMP(0, l, 7);
     }
 
     // ---- head tail (scratch aliases the weight halves, free after the last barrier) ----
@@ -593,6 +619,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const float V = s_misc[0];
     if (a.mode == 1 && tid == 0) a.out_v[gi] = V;
     if (g == 0 && rvalid) a.q[grow] = (a.mode == 0 ? V : 0.f) + tadv - mean_adv;
+    QSTAMP(0, 0, 2);
 }
 
 // ================================================= backward =================================================
@@ -613,6 +640,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 15, g = lane >> 4;
     const int gi = blockIdx.x;
+    QSTAMP(1, 0, 0);
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
     if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
@@ -702,6 +730,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 
     // gradient w.r.t. the top layer's output, in the chained lane layout; advantage-linear partial alongside
     f32x4 gx[NT];
+    f32x4 ytop[NT];      // y rows of the top layer: operand of the advantage-linear gradient and of the first ReLU mask
     {
         const float dar = s_dar[lrow];
         const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
@@ -711,6 +740,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
             f32x4 yv = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rvalid) yv = yr[4 * t];
+            ytop[t] = yv;
             f32x4 v;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -756,17 +786,10 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     //   moved in front of the contraction): per layer  gather from LDS -> K-half over the W_l part -> barrier ->
     //   K-half over the W_r part with G_l from registers -> mask by y_{l-1} -> publish G_{l-1} (global + LDS) -> barrier.
     const float idg = rvalid ? a.invdeg[grow] : 0.f;
-    f32x4 ycur[NT];      // y rows of the layer masked next; re-loaded one layer ahead
-#pragma unroll
-    for (int t = 0; t < NT; ++t) ycur[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (rvalid) {
-        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) ycur[t] = yr[4 * t];
-    }
-    // gx = dL/dy_l  ->  G_l = gx * [y_l > 0]: stored for the weight-gradient GEMM, and (l >= 1) G_l / deg placed in this
-    // lane's LDS row for the neighbours' gathers; y_{l-1} is requested for the next call.
-    auto publish = [&](const int l) {
+    // gx = dL/dy_l, yv = this lane's y_l chunks  ->  G_l = gx * [y_l > 0]: stored for the weight-gradient GEMM, and
+    // (l >= 1) G_l / deg placed in this lane's LDS row for the neighbours' gathers.  The y rows are loaded by the caller
+    // a whole layer ahead into iteration-local registers (a loop-carried prefetch made hipcc wait for the load in place).
+    auto publish = [&](const int l, const f32x4 (&yv)[NT]) {
         if (rvalid) {
             if (a.d_embeds && l == a.body_layers - 1) {
                 f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
@@ -774,13 +797,10 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
             }
             f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
-            const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l > 0 ? l - 1 : 0) + (size_t)grow * HP) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                const f32x4 yv = ycur[t];
-                if (l > 0) ycur[t] = yn[4 * t];
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[q4] > 0.f ? gx[t][q4] : 0.f;
+                for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[t][q4] > 0.f ? gx[t][q4] : 0.f;
                 go[4 * t] = gx[t];
             }
         } else {
@@ -799,9 +819,20 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             }
         }
     };
-    if (wactive) publish(L - 1);
+    QSTAMP(1, 0, 1);
+    if (wactive) publish(L - 1, ytop);
     lds_barrier();
+    QSTAMP(1, 0, 2);
     for (int l = L - 1; l >= 1; --l) {
+        QSTAMP(1, l, 0);
+        f32x4 yl[NT];        // y_{l-1} rows for this iteration's closing mask
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (rvalid) {
+            const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) yl[t] = yn[4 * t];
+        }
         f32x4 stg[kStage];
         {   // stream the W_r part of layer l towards half B
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l]);
@@ -842,16 +873,20 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                     }
                 }
             }
+            QSTAMP(1, l, 1);
             if constexpr (MATH == 1) {   // one power-of-two scale per row over [T(G/deg) | G]
                 const float m = row_max4(frag_absmax<NT>(gx, frag_absmax<NT>(ag, 0.f)));
                 row_scale(m, rs, rinv);
                 rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
             }
             contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
+            QSTAMP(1, l, 2);
         }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        QSTAMP(1, l, 3);
         lds_barrier();     // barrier 1: half B = W_r part; every gather of this layer is done (dbuf free); half A free
+        QSTAMP(1, l, 4);
         const bool more = l - 1 >= 1;
         if (more) {   // stream the W_l part of layer l-1 towards half A
             const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
@@ -867,15 +902,20 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         if (wactive) {
             // phase 2: K-half over the W_r part (half B) with G_l from registers; the result is dL/dy_{l-1}
             contract_half<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
-            publish(l - 1);
+            QSTAMP(1, l, 5);
         }
-        if (more) {
+        if (more) {   // before publish()'s global stores (see the forward kernel)
 #pragma unroll
             for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
         }
+        if (wactive) {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
+            publish(l - 1, yl);
+        }
+        QSTAMP(1, l, 6);
         lds_barrier();     // barrier 2: G_{l-1} rows + half A visible; half B free
+        QSTAMP(1, l, 7);
     }
     // ---- raw first layer: this graph's share of dW_0 = G_0^T [agg0 | x0 | 1], reduced over the graphs afterwards ----
     if (a.first_part) {
@@ -918,6 +958,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             if (g == 0) out[(size_t)16 * HP] = acc1[0];
         }
     }
+    QSTAMP(1, 0, 3);
 }
 
 template <int NT, int MATH>
