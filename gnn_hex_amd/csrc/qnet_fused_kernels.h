@@ -66,19 +66,20 @@ template <int NT> struct QLds {
     static constexpr int kHalf = NT * NT * 64;              // float4 per weight half
     static constexpr int off_w = 0;
     static constexpr int off_x = 2 * kHalf * 16;
-    static constexpr int off_rp = off_x + kRows * XS * 4;
+    static constexpr int off_rp = off_x + (kRows + 1) * XS * 4;   // row kRows stays all zero (gather filler)
     static constexpr int off_col = off_rp + 272;            // (kRows+2) u16, padded
-    static constexpr int col_cap = (kLdsBytes - 64 - off_col) < 8192 ? (kLdsBytes - 64 - off_col) : 8192;
+    static constexpr int col_cap = (kLdsBytes - 64 - 4 * HP - off_col) < 8192 ? (kLdsBytes - 64 - 4 * HP - off_col) : 8192;
     static constexpr int off_max = off_col + col_cap;       // 8 per-wave maxima (math 1), 64 B
+    static constexpr int off_bias = off_max + 64;           // the current layer's bias row (forward), HP floats
     // 16 KB of scratch (first-layer operands, head-tail reductions): aliases the weight halves when they are
     // large enough (NT >= 4), otherwise a region of its own (small widths leave plenty of LDS)
     static constexpr bool scr_alias = NT >= 4;
     static constexpr int scr_bytes = 16384;
     static constexpr int scr0_bytes = kRows * 48 * 4;   // backward: [rows][48] raw first-layer inputs (MFMA operand)
-    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_max + 64;   // half B
-    static constexpr int off_scr_tail = scr_alias ? off_w : off_max + 64;
-    static constexpr int off_scr_bwd0 = scr_alias ? off_w : off_max + 64;
-    static constexpr int total = off_max + 64 + (scr_alias ? 0 : (scr0_bytes > scr_bytes ? scr0_bytes : scr_bytes));
+    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_bias + 4 * HP;   // half B
+    static constexpr int off_scr_tail = scr_alias ? off_w : off_bias + 4 * HP;
+    static constexpr int off_scr_bwd0 = scr_alias ? off_w : off_bias + 4 * HP;
+    static constexpr int total = off_bias + 4 * HP + (scr_alias ? 0 : (scr0_bytes > scr_bytes ? scr0_bytes : scr_bytes));
     static_assert(col_cap >= 1024 && total <= kLdsBytes, "LDS budget");
     static_assert(!scr_alias || kHalf * 16 >= scr_bytes, "scratch must fit one weight half");
     static_assert(!scr_alias || 2 * kHalf * 16 >= scr0_bytes, "first-layer scratch must fit the weight halves");
@@ -274,6 +275,84 @@ __device__ __forceinline__ void gather_lds(const float* __restrict__ rows, const
     }
 }
 
+// The neighbour lists never change between layers: every lane keeps the LDS byte offsets of its row's first eight
+// neighbour rows in four registers (two u16 each, the lane's 16-byte column slot included), so a layer's gather issues
+// its row reads without first fetching column ids (one dependent LDS round trip per neighbour pair less).  Slots past
+// the row's degree point at the all-zero row kRows: every lane of a wave runs the same wave-uniform number of steps,
+// no divergence, and x + 0 leaves the sums unchanged.
+struct NbrRegs {
+    unsigned off[4];    // byte offsets of neighbours 0..7 within the row buffer, + 16 g
+    int eb, ee;         // edge range beyond the eighth neighbour in the LDS CSR (eb == ee: none)
+    int wmax;           // wave-uniform max of min(deg, 8)
+    bool wlong;         // wave-uniform: some row of the wave has more than eight neighbours
+};
+template <int XS>
+__device__ __forceinline__ NbrRegs load_nbrs(const unsigned short* __restrict__ s_rp, const unsigned char* __restrict__ s_col,
+                                             int lrow, bool rvalid, int g) {
+    static_assert((kRows + 1) * XS * 4 <= 65536, "row offsets are kept as u16");
+    NbrRegs nb;
+    const int eb = rvalid ? (int)s_rp[lrow] : 0;
+    nb.ee = rvalid ? (int)s_rp[lrow + 1] : 0;
+    const int deg = nb.ee - eb;
+    nb.eb = min(eb + 8, nb.ee);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nb.off[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int j = k < deg ? (int)s_col[eb + k] : kRows;
+        nb.off[k >> 1] |= (unsigned)(j * (XS * 4) + 16 * g) << (16 * (k & 1));
+    }
+    int m = deg;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    m = __builtin_amdgcn_readfirstlane(m);
+    nb.wmax = min(m, 8);
+    nb.wlong = m > 8;
+    return nb;
+}
+// ag[c] += rows[j][chunk c] over the row's neighbours j in ascending order: (.. + x_j0) + x_j1 ..., the reads of
+// neighbour k+2 in flight while neighbour k is added.
+template <int NT, int XS>
+__device__ __forceinline__ void gather_nbrs(const float* __restrict__ rows, const unsigned char* __restrict__ s_col,
+                                            const NbrRegs& nb, int g, f32x4 (&ag)[NT]) {
+    const char* base = reinterpret_cast<const char*>(rows);
+    if (nb.wmax > 0) {
+        f32x4 t0[NT], t1[NT];
+        {
+            const f32x4* x0 = reinterpret_cast<const f32x4*>(base + (nb.off[0] & 0xffffu));
+            const f32x4* x1 = reinterpret_cast<const f32x4*>(base + (nb.off[0] >> 16));
+#pragma unroll
+            for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
+#pragma unroll
+            for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k += 2) {
+            __builtin_amdgcn_sched_barrier(0);     // two neighbours in flight, not eight (register budget)
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ag[c] += t0[c];
+            __builtin_amdgcn_sched_barrier(0);     // re-use t0's registers for the next reads
+            const bool more = k + 2 < 8 && k + 2 < nb.wmax;      // wave-uniform
+            if (more) {
+                const f32x4* x0 = reinterpret_cast<const f32x4*>(base + (nb.off[((k + 2) >> 1) & 3] & 0xffffu));
+#pragma unroll
+                for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ag[c] += t1[c];
+            __builtin_amdgcn_sched_barrier(0);
+            if (!more) break;
+            {
+                const f32x4* x1 = reinterpret_cast<const f32x4*>(base + (nb.off[((k + 2) >> 1) & 3] >> 16));
+#pragma unroll
+                for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
+            }
+        }
+    }
+    if (nb.wlong) gather_lds<NT, XS>(rows, s_col, nb.eb, nb.ee, g, ag);
+}
+
 // ================================================= forward =================================================
 template <int NT, int MATH>
 __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
@@ -301,10 +380,12 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
     float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
     if (tid < 16) s_max[tid] = 0.f;
+    if (tid < XS) xbuf[kRows * XS + tid] = 0.f;                      // the gather's filler row
 
     // ---- stage W_l of layer 1 into half A; first-layer scratch lives in half B ----
     if (a.L > 1)
         copy_f4_to_lds<(LD::kHalf + 511) / 512>(wbuf, reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]), kHalf);
+    NbrRegs nbr;
     float* s_w0 = reinterpret_cast<float*>(lds + LD::off_scr_first);  // [2][HP][8]
     float* s_f = s_w0 + 2 * HP * kSmallCin;                          // [kRows][16]: agg0 | x0
     {
@@ -319,6 +400,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             s_f[rr * 16 + 8 + qq] = (rr < cnt && qq < a.c_in) ? a.x[(size_t)(r0 + rr) * a.x_stride + qq] : 0.f;
         }
         __syncthreads();
+        nbr = load_nbrs<XS>(s_rp, s_col, lrow, rvalid && csr_lds, g);
         if (tid < kRows) {
             float ag0[kSmallCin];
 #pragma unroll
@@ -390,23 +472,30 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     constexpr int kStage = (kHalf + 511) / 512;
     const size_t slab = (size_t)a.n * HP;
     const float validf = rvalid ? 1.f : 0.f;
+    const float idg = rvalid ? a.invdeg[grow] : 0.f;
     QSTAMP(0, 0, 1);
+    // Waves 0-3 and 4-7 share the four SIMDs pairwise and the MFMA pipe serves one wave of a pair at a time, so the two
+    // groups run each phase in a different order: the EARLY group (waves 0-3) goes gather -> MFMAs first and issues its
+    // global loads / stores afterwards, in the time it would otherwise wait at the barrier for its partner; the LATE group
+    // (waves 4-7) issues its memory operations first, while its partner holds the pipe.  (All eight waves issuing ~1 KB
+    // vector-memory instructions at once is bound by the CU's 64 B/clk address path, ahead of everybody's MFMAs.)
+    const bool late = wave >= 4;
+    float* s_bias = reinterpret_cast<float*>(lds + LD::off_bias);
     for (int l = 1; l < a.L; ++l) {
         QSTAMP(0, l, 0);
         f32x4 stg[kStage];
-        {   // stream W_r(l) towards half B
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]) + kHalf;
+        f32x4 bstg = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]);
+        const f32x4* bsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]);
+        if (late) {   // stream W_r(l) towards half B
 #pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = wsrc[kHalf + i]; }
         }
-        // the bias is the accumulator's initial value (loaded now, consumed by the first MFMA of each tile)
         f32x4 acc[NT];
-        {
-            const f32x4* br = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]) + g;
 #pragma unroll
-            for (int t = 0; t < NT; ++t) acc[t] = br[4 * t];
-        }
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float rs = 1.f, rinv = 1.f;
+        QSTAMP(0, l, 8);
         if (wactive) {
             // phase 1: mean-gather from LDS, then K-half over W_l (half A)
             f32x4 ag[NT];
@@ -414,7 +503,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rvalid) {
                 if (csr_lds) {
-                    gather_lds<NT, XS>(xbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, ag);
+                    gather_nbrs<NT, XS>(xbuf, s_col, nbr, g, ag);
                 } else {
                     for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
                         const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
@@ -422,33 +511,39 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                         for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
                     }
                 }
-                const float sc = a.invdeg[grow];
+                QSTAMP(0, l, 9);
 #pragma unroll
-                for (int c = 0; c < NT; ++c) ag[c] *= sc;
-                if (a.need_backward) {
-                    f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
+                for (int c = 0; c < NT; ++c) ag[c] *= idg;
+            }
+            f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
+            if (late && rvalid && a.need_backward) {
 #pragma unroll
-                    for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
-                }
+                for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
             }
             QSTAMP(0, l, 1);
-            if constexpr (MATH == 1) {   // one power-of-two scale per row over [agg | x]; the bias joins the scaled sum
+            if constexpr (MATH == 1) {   // one power-of-two scale per row over [agg | x]
                 const float m = row_max4(frag_absmax<NT>(xs, frag_absmax<NT>(ag, 0.f)));
                 row_scale(m, rs, rinv);
                 if (a.xmax) { const float wm = rows_max16(m); if (lane == 0) s_max[wave] = wm; }
-                const float* wsc = reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP;
-                const float up = rs * wsc[0];
-                rinv *= wsc[1];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] *= up;
+                rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
             }
             contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
             QSTAMP(0, l, 2);
+            if (!late && rvalid && a.need_backward) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
+            }
+        }
+        if (!late) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = wsrc[kHalf + i]; }
+            if (tid < HP / 4) bstg = bsrc[tid];      // this layer's bias row -> LDS (read in the epilogue)
         }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
+        if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg;
         QSTAMP(0, l, 3);
-        lds_barrier();     // barrier 1: half B = W_r(l); every gather of this layer is done; half A is free
+        lds_barrier();     // barrier 1: half B = W_r(l) + bias row; every gather of this layer is done; half A is free
         QSTAMP(0, l, 4);
         if constexpr (MATH == 1) {
             if (a.xmax && tid == 0) {   // layer maximum of [agg | x] over this graph -> global (order-independent)
@@ -458,34 +553,43 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 atomicMax(a.xmax + l, __builtin_bit_cast(unsigned, mm));
             }
         }
-        if (l + 1 < a.L) {   // stream W_l(l+1) towards half A
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l + 1]);
+        const bool more = l + 1 < a.L;
+        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[more ? l + 1 : l]);
+        if (late && more) {   // stream W_l(l+1) towards half A
 #pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = src[i]; }
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = nsrc[i]; }
         }
         if (wactive) {
             // phase 2: K-half over W_r (half B) with the self rows kept in registers
             contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs);
             QSTAMP(0, l, 5);
         }
-        // staged half A -> LDS BEFORE the epilogue's global stores: vmcnt counts loads and stores in one in-order
-        // counter, so a wait for the staged loads placed after the stores also waits for the stores' L2 acknowledgement
-        if (l + 1 < a.L) {
+        if (!late && more) {
 #pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = nsrc[i]; }
         }
-        if (wactive) {
+        if (wactive) {   // epilogue, part 1: bias, ReLU, new rows -> LDS
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
+            const f32x4* bl = reinterpret_cast<const f32x4*>(s_bias) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 v = acc[t];
                 if constexpr (MATH == 1) v *= rinv;
+                v += bl[4 * t];
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) v[q4] = fmaxf(v[q4], 0.f);
                 v *= validf;              // pad rows stay exactly zero
                 xs[t] = v;
                 xr[4 * t] = v;
             }
+        }
+        // staged half A -> LDS BEFORE the epilogue's global stores: vmcnt counts loads and stores in one in-order
+        // counter, so a wait for the staged loads placed after the stores also waits for the stores' L2 acknowledgement
+        if (more) {
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
+        }
+        if (wactive) {
             if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == l)) {
                 f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
 #pragma unroll
@@ -653,6 +757,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const bool csr_lds = load_csr<NT>(lds, a.rowptr_t, a.col_t, r0, cnt, e0, ne, a.status);
     float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
     if (tid < 16) s_max[tid] = 0.f;
+    if (tid < XS) dbuf[kRows * XS + tid] = 0.f;                      // the gather's filler row
     const size_t slab = (size_t)a.n * HP;
     const int H2 = H / 2, H4 = 4 * H;
     constexpr int kStage = (kHalf + 511) / 512;
@@ -664,10 +769,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
             const int i = tid + 512 * k;
-            if (i < kHalf) {
-                if constexpr (MATH == 1) tmp[k] = src[i];
-                else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; tmp[k] = src[(c * 2 * NT + t) * 64 + li]; }
-            }
+            if (i < kHalf) tmp[k] = src[i];
         }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = tmp[k]; }
@@ -727,6 +829,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         s_dar[tid] = dar;
     }
     __syncthreads();
+    const NbrRegs nbr = load_nbrs<XS>(s_rp, s_col, lrow, rvalid && csr_lds, g);
 
     // gradient w.r.t. the top layer's output, in the chained lane layout; advantage-linear partial alongside
     f32x4 gx[NT];
@@ -786,22 +889,22 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     //   moved in front of the contraction): per layer  gather from LDS -> K-half over the W_l part -> barrier ->
     //   K-half over the W_r part with G_l from registers -> mask by y_{l-1} -> publish G_{l-1} (global + LDS) -> barrier.
     const float idg = rvalid ? a.invdeg[grow] : 0.f;
-    // gx = dL/dy_l, yv = this lane's y_l chunks  ->  G_l = gx * [y_l > 0]: stored for the weight-gradient GEMM, and
-    // (l >= 1) G_l / deg placed in this lane's LDS row for the neighbours' gathers.  The y rows are loaded by the caller
-    // a whole layer ahead into iteration-local registers (a loop-carried prefetch made hipcc wait for the load in place).
-    auto publish = [&](const int l, const f32x4 (&yv)[NT]) {
+    // gx = dL/dy_l, yv = this lane's y_l chunks  ->  G_l = gx * [y_l > 0]; (l >= 1) G_l / deg goes to this lane's LDS row
+    // for the neighbours' gathers.  The y rows are loaded by the caller a whole layer ahead into iteration-local
+    // registers (a loop-carried prefetch made hipcc wait for the load in place).  store_G() then writes G_l for the
+    // weight-gradient GEMM; it is a separate step so that the weight-half LDS writes can sit between the two (see the
+    // forward kernel: a wait for staged loads placed after global stores also waits for the stores).
+    auto mask_rows = [&](const int l, const f32x4 (&yv)[NT]) {
         if (rvalid) {
             if (a.d_embeds && l == a.body_layers - 1) {
                 f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
             }
-            f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[t][q4] > 0.f ? gx[t][q4] : 0.f;
-                go[4 * t] = gx[t];
             }
         } else {
 #pragma unroll
@@ -819,31 +922,41 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             }
         }
     };
+    auto store_G = [&](const int l) {
+        if (rvalid) {
+            f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) go[4 * t] = gx[t];
+        }
+    };
     QSTAMP(1, 0, 1);
-    if (wactive) publish(L - 1, ytop);
+    if (wactive) { mask_rows(L - 1, ytop); store_G(L - 1); }
     lds_barrier();
     QSTAMP(1, 0, 2);
+    // early / late wave groups: see the forward kernel
+    const bool late = wave >= 4;
     for (int l = L - 1; l >= 1; --l) {
         QSTAMP(1, l, 0);
         f32x4 yl[NT];        // y_{l-1} rows for this iteration's closing mask
+        f32x4 stg[kStage];
 #pragma unroll
         for (int t = 0; t < NT; ++t) yl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (rvalid) {
-            const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) yl[t] = yn[4 * t];
-        }
-        f32x4 stg[kStage];
-        {   // stream the W_r part of layer l towards half B
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l]);
+        const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l]);
+        // W_r part of layer l -> registers (towards half B)
+        auto load_half_b = [&]() {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) {
                 const int i = tid + 512 * k;
-                if (i < kHalf) {
-                    if constexpr (MATH == 1) stg[k] = src[kHalf + i];
-                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + NT + t) * 64 + li]; }
-                }
+                if (i < kHalf) stg[k] = wsrc[kHalf + i];
             }
+        };
+        if (late) {
+            if (rvalid) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) yl[t] = yn[4 * t];
+            }
+            load_half_b();
         }
         if constexpr (MATH == 1) {
             if (a.gmax && tid == 0) {   // layer maximum of |G_l| over this graph -> global (order-independent)
@@ -857,6 +970,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         float rs = 1.f, rinv = 1.f;
+        QSTAMP(1, l, 8);
         if (wactive) {
             // phase 1: transposed gather of G_l / deg from LDS, then K-half over the W_l part (half A)
             f32x4 ag[NT];
@@ -864,7 +978,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             if (rvalid) {
                 if (csr_lds) {
-                    gather_lds<NT, XS>(dbuf, s_col, s_rp[lrow], s_rp[lrow + 1], g, ag);
+                    gather_nbrs<NT, XS>(dbuf, s_col, nbr, g, ag);
                 } else {
                     for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
                         const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
@@ -882,37 +996,45 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
             QSTAMP(1, l, 2);
         }
+        if (!late) {
+            if (rvalid) {
+#pragma unroll
+                for (int t = 0; t < NT; ++t) yl[t] = yn[4 * t];
+            }
+            load_half_b();
+        }
 #pragma unroll
         for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
         QSTAMP(1, l, 3);
         lds_barrier();     // barrier 1: half B = W_r part; every gather of this layer is done (dbuf free); half A free
         QSTAMP(1, l, 4);
         const bool more = l - 1 >= 1;
-        if (more) {   // stream the W_l part of layer l-1 towards half A
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l - 1]);
+        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[more ? l - 1 : l]);
+        // W_l part of layer l-1 -> registers (towards half A)
+        auto load_half_a = [&]() {
 #pragma unroll
             for (int k = 0; k < kStage; ++k) {
                 const int i = tid + 512 * k;
-                if (i < kHalf) {
-                    if constexpr (MATH == 1) stg[k] = src[i];
-                    else { const int li = i & 63, ct = i >> 6, c = ct / NT, t = ct % NT; stg[k] = src[(c * 2 * NT + t) * 64 + li]; }
-                }
+                if (i < kHalf) stg[k] = nsrc[i];
             }
-        }
+        };
+        if (late && more) load_half_a();
         if (wactive) {
             // phase 2: K-half over the W_r part (half B) with G_l from registers; the result is dL/dy_{l-1}
             contract_half<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs);
             QSTAMP(1, l, 5);
         }
-        if (more) {   // before publish()'s global stores (see the forward kernel)
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-        }
+        if (!late && more) load_half_a();
         if (wactive) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
-            publish(l - 1, yl);
+            mask_rows(l - 1, yl);
         }
+        if (more) {   // before the global stores
+#pragma unroll
+            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
+        }
+        if (wactive) store_G(l - 1);
         QSTAMP(1, l, 6);
         lds_barrier();     // barrier 2: G_{l-1} rows + half A visible; half B free
         QSTAMP(1, l, 7);

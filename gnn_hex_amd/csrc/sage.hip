@@ -86,12 +86,14 @@ __global__ void sage_pack_kernel(PackArgs a, char* __restrict__ wpack) {
         const float* w = c < nt ? wl : wr;
         pf[tid] = (k < in && o < H) ? w[o * in + k] : 0.f;
     }
-    {   // backward pack PB[c][t][lane][j], c < NT (k chunk over outputs o), t < 2NT (tile of [dAgg|dXs])
-        const int c = tid / (2 * nt * 256), rem = tid % (2 * nt * 256);
+    {   // backward pack PB[h][c][t][lane][j]: h = 0 the W_l part (dAgg), 1 the W_r part (dXs), each a contiguous half;
+        // c < NT (k chunk over outputs o), t < NT (tile of input features)
+        const int h = tid / (nt * nt * 256), rem0 = tid % (nt * nt * 256);
+        const int c = rem0 / (nt * 256), rem = rem0 % (nt * 256);
         const int t = rem / 256, lj = rem % 256, lane = lj >> 2, j = lj & 3;
         const int g = lane >> 4, cx = lane & 15;
-        const int o = 16 * c + 4 * g + j, i = 16 * (t % nt) + cx;
-        const float* w = t < nt ? wl : wr;
+        const int o = 16 * c + 4 * g + j, i = 16 * t + cx;
+        const float* w = h == 0 ? wl : wr;
         pb[tid] = (o < H && i < in) ? w[o * in + i] : 0.f;
     }
 }
@@ -346,7 +348,7 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
     const float* __restrict__ y, const f32x4* __restrict__ wpackb,
     float* __restrict__ g_out, float* __restrict__ dagg_out, float* __restrict__ dxs_out) {
     constexpr int HP = 16 * NT;
-    extern __shared__ f32x4 wlds[];  // [NT][2NT][64]
+    extern __shared__ f32x4 wlds[];  // [2][NT][NT][64]: W_l part, W_r part
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = tid; i < 2 * NT * NT * 64; i += 512) wlds[i] = wpackb[i];
 
@@ -380,7 +382,7 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
         for (int t = 0; t < 2 * NT; ++t) {
-            const f32x4 b = wlds[(c * 2 * NT + t) * 64 + lane];
+            const f32x4 b = wlds[((t / NT) * NT * NT + c * NT + (t % NT)) * 64 + lane];
             acc[t] = mfma16x16x4(b[0], gx[c][0], acc[t]);
             acc[t] = mfma16x16x4(b[1], gx[c][1], acc[t]);
             acc[t] = mfma16x16x4(b[2], gx[c][2], acc[t]);

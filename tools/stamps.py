@@ -24,7 +24,7 @@ from gnn_hex_amd import _lib  # noqa: E402
 from gnn_hex_amd import ops as hexops  # noqa: E402
 
 KMAXL, POINTS = 64, 10
-NAMES = ["top", "gather", "M1", "pre-b1", "b1", "M2", "epilogue", "b2"]
+NAMES = ["top", "gather", "M1", "pre-b1", "b1", "M2", "epilogue", "b2", "loads-out", "reads-in"]
 
 
 def main():
@@ -62,13 +62,13 @@ def main():
         rows = []
         for l in layers:
             base = s[l, 0].min()       # earliest wave entering the layer
-            rows.append(s[l, :8, :] - base)
+            rows.append(s[l, :POINTS, :] - base)
         a = np.stack(rows)              # [layers][point][wave]
         lay_span = np.array([st[k][l, 7].max() - st[k][l, 0].min() for l in layers])
         print("   per-layer span (ticks): mean %.0f  min %.0f  max %.0f" % (lay_span.mean(), lay_span.min(), lay_span.max()))
         mean = a.mean(0)                # [point][wave]
         print("   point      " + "  ".join("w%d    " % w for w in range(8)))
-        for p in range(8):
+        for p in [0, 8, 9, 1, 2, 3, 4, 5, 6, 7]:
             print("   %-9s " % NAMES[p] + "  ".join("%6.0f" % mean[p, w] for w in range(8)))
         if k == 0:
             print("   prologue %.0f ticks, tail %.0f ticks" % (s[0, 1].max() - t0, end - s[L - 1, 7].max()))
