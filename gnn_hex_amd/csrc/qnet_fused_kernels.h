@@ -13,6 +13,8 @@
 //   other half of the next phase/layer is streamed L2 -> registers -> LDS (two barriers per layer).
 //   fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): exact fmaf chains, deterministic.
 #pragma once
+#include <type_traits>
+#include <utility>
 #include "hexgnn_internal.h"
 
 namespace hexgnn {
@@ -76,7 +78,7 @@ template <int NT> struct QLds {
     static constexpr bool scr_alias = NT >= 4;
     static constexpr int scr_bytes = 16384;
     static constexpr int scr0_bytes = kRows * 48 * 4;   // backward: [rows][48] raw first-layer inputs (MFMA operand)
-    static constexpr int off_scr_first = scr_alias ? off_w + kHalf * 16 : off_bias + 4 * HP;   // half B
+    static constexpr int off_scr_first = scr_alias ? off_w : off_bias + 4 * HP;   // half A
     static constexpr int off_scr_tail = scr_alias ? off_w : off_bias + 4 * HP;
     static constexpr int off_scr_bwd0 = scr_alias ? off_w : off_bias + 4 * HP;
     static constexpr int total = off_bias + 4 * HP + (scr_alias ? 0 : (scr0_bytes > scr_bytes ? scr0_bytes : scr_bytes));
@@ -353,6 +355,158 @@ __device__ __forceinline__ void gather_nbrs(const float* __restrict__ rows, cons
     if (nb.wlong) gather_lds<NT, XS>(rows, s_col, nb.eb, nb.ee, g, ag);
 }
 
+// ---- filler-carrying contraction ---------------------------------------------------------------------------------
+// A wave's non-MFMA work issued under its PARTNER's MFMA stream runs ~3x slower (measured: gathers, epilogues, even
+// vector-memory issue), but small groups of instructions placed between a wave's OWN MFMAs are nearly free.  So each K-half
+// contraction carries "fillers": fill(integral_constant<q>) is called after every group of MFMAs (kGaps groups per half)
+// and issues a few instructions of independent work - the LDS gather of the aggregate, global stores / loads, LDS-DMA.
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
+}
+template <int NT, int MATH> struct Gaps {
+    static constexpr int value = MATH == 0 ? 4 * NT : (NT / 2) * NT + (NT & 1) * NT;
+};
+template <int NT, int MATH, typename F>
+__device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
+                                                   f32x4 (&acc)[NT], const float scale, F&& fill) {
+    // The scheduling barriers pin the fillers between the MFMA groups, so the weight fragments of the next group are
+    // requested explicitly ahead of a filler instead of by the compiler's own hoisting.
+    if constexpr (MATH == 0) {
+        // one fragment set: the next chunk's fragments are requested into the same registers right behind the chunk's last
+        // MFMA group (an MFMA reads its operands at issue); the SIMD's other wave covers the LDS round trip
+        f32x4 w[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) w[t] = whalf[t * 64 + lane];
+        static_for<0, NT>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            static_for<0, 4>([&](auto jj) {
+                constexpr int j = decltype(jj)::value;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) acc[t] = mfma16x16x4(w[t][j], x[c][j], acc[t]);
+                if constexpr (j == 3 && c + 1 < NT) {
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) w[t] = whalf[((c + 1) * NT + t) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                fill(std::integral_constant<int, 4 * c + j>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+    } else {
+        const char* wb = reinterpret_cast<const char*>(whalf);
+        constexpr int kUnits = (NT / 2) * NT + (NT & 1) * NT;     // (chunk pair | odd last chunk) x output tile
+        // unit u: pair p = u / NT (p == NT/2: the odd last chunk), tile t = u % NT
+        f16x8 wh[2], wl[2];      // the odd chunk's fragments use the low halves
+        auto wload = [&](auto uu, f16x8& h, f16x8& l) {
+            constexpr int u = decltype(uu)::value, p = u / NT, t = u % NT;
+            if constexpr (p < NT / 2) {
+                const char* ub = wb + (2 * p) * NT * 1024 + lane * 16 + t * 2048;
+                h = *reinterpret_cast<const f16x8*>(ub);
+                l = *reinterpret_cast<const f16x8*>(ub + 1024);
+            } else {
+                const char* ub = wb + (NT - 1) * NT * 1024 + lane * 8 + t * 1024;
+                const f16x4 h4 = *reinterpret_cast<const f16x4*>(ub);
+                const f16x4 l4 = *reinterpret_cast<const f16x4*>(ub + 512);
+                h = __builtin_shufflevector(h4, h4, 0, 1, 2, 3, 0, 1, 2, 3);
+                l = __builtin_shufflevector(l4, l4, 0, 1, 2, 3, 0, 1, 2, 3);
+            }
+        };
+        wload(std::integral_constant<int, 0>{}, wh[0], wl[0]);
+        f16x8 xh, xl;
+        static_for<0, kUnits>([&](auto uu) {
+            constexpr int u = decltype(uu)::value, p = u / NT, t = u % NT;
+            if constexpr (t == 0) {
+                if constexpr (p < NT / 2) split_pair(x[2 * p], x[2 * p + 1], scale, xh, xl);
+                else {
+                    f16x4 h4, l4;
+                    split_one(x[NT - 1], scale, h4, l4);
+                    xh = __builtin_shufflevector(h4, h4, 0, 1, 2, 3, 0, 1, 2, 3);
+                    xl = __builtin_shufflevector(l4, l4, 0, 1, 2, 3, 0, 1, 2, 3);
+                }
+            }
+            if constexpr (u + 1 < kUnits) wload(std::integral_constant<int, u + 1>{}, wh[(u + 1) & 1], wl[(u + 1) & 1]);
+            if constexpr (p < NT / 2) {
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl[u & 1], xh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1], xl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh[u & 1], xh, acc[t], 0, 0, 0);
+            } else {
+                const f16x4 h4 = __builtin_shufflevector(wh[u & 1], wh[u & 1], 0, 1, 2, 3);
+                const f16x4 l4 = __builtin_shufflevector(wl[u & 1], wl[u & 1], 0, 1, 2, 3);
+                const f16x4 xh4 = __builtin_shufflevector(xh, xh, 0, 1, 2, 3), xl4 = __builtin_shufflevector(xl, xl, 0, 1, 2, 3);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(l4, xh4, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(h4, xl4, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(h4, xh4, acc[t], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            fill(std::integral_constant<int, u>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+}
+
+// The gather of the first eight neighbours as 32 micro-ops spread over the G gaps of a contraction: for neighbour k the
+// read of its row chunks into ONE landing buffer, then three add steps (thirds of the chunks); the MFMA group between two
+// gaps covers the LDS latency.  Ascending order of the sums is kept.
+template <int NT>
+__device__ __forceinline__ void gather_read(const char* base, unsigned off, f32x4 (&t)[NT]) {
+    const f32x4* x = reinterpret_cast<const f32x4*>(base + off);
+#pragma unroll
+    for (int c = 0; c < NT; ++c) t[c] = x[4 * c];
+}
+template <int NT, int Q, int G>
+__device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb, f32x4 (&ag)[NT], f32x4 (&tb)[NT]) {
+    const char* base = reinterpret_cast<const char*>(rows);
+    static_for<0, 32>([&](auto mm) {
+        constexpr int m = decltype(mm)::value;
+        if constexpr (m * G / 32 == Q) {
+            constexpr int k = m / 4, part = m % 4;
+            if (k < nb.wmax) {       // wave-uniform
+                if constexpr (part == 0) {
+                    const unsigned o = nb.off[k >> 1];
+                    gather_read<NT>(base, (k & 1) ? (o >> 16) : (o & 0xffffu), tb);
+                } else {
+                    constexpr int c0 = (part - 1) * NT / 3, c1 = part * NT / 3;
+#pragma unroll
+                    for (int c = c0; c < c1; ++c) ag[c] += tb[c];
+                }
+            }
+        }
+    });
+}
+
+// Saved-tensor traffic goes through raw buffer instructions: a wave-uniform resource (SGPRs) + one 32-bit lane offset +
+// an immediate, instead of a 64-bit address pair per access (the fused kernels run at the register ceiling).
+typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const void* base) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ void buf_store(const f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, v), r, off, 0, 0);
+}
+__device__ __forceinline__ f32x4 buf_load(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
+
+// LDS-DMA of one 1-KiB piece (64 lanes x 16 B, lane-linear on both sides) as an asm statement: hipcc then neither
+// tracks it nor drains vmcnt before later LDS accesses; the issuing wave waits with wait_vmem() before the barrier that
+// publishes the bytes.  lds_dst = wave-uniform LDS byte address.
+__device__ __forceinline__ void dma_piece(const void* gsrc_piece /* wave-uniform */, unsigned lane_off, unsigned lds_dst) {
+    unsigned keep;
+    lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    const unsigned long long sb = (unsigned long long)gsrc_piece;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
+    const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(lane_off), "s"(lds_dst), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// piece index of this wave's q-th share of a weight half (NT*NT pieces over 8 waves); -1: none
+template <int NT> __device__ __forceinline__ int dma_share(int wave, int q) {
+    const int p = wave + 8 * q;
+    return p < NT * NT ? p : -1;
+}
+
 // ================================================= forward =================================================
 template <int NT, int MATH>
 __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
@@ -364,7 +518,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const unsigned short* s_rp = reinterpret_cast<const unsigned short*>(lds + LD::off_rp);
     const unsigned char* s_col = reinterpret_cast<const unsigned char*>(lds + LD::off_col);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int gi = blockIdx.x;
     QSTAMP(0, 0, 0);
@@ -382,9 +536,9 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     if (tid < 16) s_max[tid] = 0.f;
     if (tid < XS) xbuf[kRows * XS + tid] = 0.f;                      // the gather's filler row
 
-    // ---- stage W_l of layer 1 into half A; first-layer scratch lives in half B ----
+    // ---- stage W_r of layer 1 into half B (the self half runs first); first-layer scratch lives in half A ----
     if (a.L > 1)
-        copy_f4_to_lds<(LD::kHalf + 511) / 512>(wbuf, reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]), kHalf);
+        copy_f4_to_lds<(LD::kHalf + 511) / 512>(wbuf + kHalf, reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]) + kHalf, kHalf);
     NbrRegs nbr;
     float* s_w0 = reinterpret_cast<float*>(lds + LD::off_scr_first);  // [2][HP][8]
     float* s_f = s_w0 + 2 * HP * kSmallCin;                          // [kRows][16]: agg0 | x0
@@ -466,109 +620,116 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
         }
     }
-    __syncthreads();   // xbuf + half A visible; half B (scratch) free
+    __syncthreads();   // xbuf + half B visible; half A (scratch) free
 
     // ---- hidden layers ----
-    constexpr int kStage = (kHalf + 511) / 512;
     const size_t slab = (size_t)a.n * HP;
     const float validf = rvalid ? 1.f : 0.f;
     const float idg = rvalid ? a.invdeg[grow] : 0.f;
     QSTAMP(0, 0, 1);
-    // Waves 0-3 and 4-7 share the four SIMDs pairwise and the MFMA pipe serves one wave of a pair at a time, so the two
-    // groups run each phase in a different order: the EARLY group (waves 0-3) goes gather -> MFMAs first and issues its
-    // global loads / stores afterwards, in the time it would otherwise wait at the barrier for its partner; the LATE group
-    // (waves 4-7) issues its memory operations first, while its partner holds the pipe.  (All eight waves issuing ~1 KB
-    // vector-memory instructions at once is bound by the CU's 64 B/clk address path, ahead of everybody's MFMAs.)
-    const bool late = wave >= 4;
+    // Per layer two phases, each a K-half contraction that carries the layer's other work as fillers between its MFMAs:
+    //   phase S: self half (W_r, half B) on the rows kept in registers; fillers = the LDS gather of the aggregate, the
+    //            previous layer's saved-activation stores, LDS-DMA of W_l(l) into half A           -> barrier 1
+    //   phase A: aggregate half (W_l, half A); fillers = the aggregate's saved-tensor stores, LDS-DMA of W_r(l+1) into
+    //            half B; then bias + ReLU + new rows to LDS                                        -> barrier 2
+    constexpr int kGaps = Gaps<NT, MATH>::value;
+    constexpr int kDma = (NT * NT + 7) / 8;                  // LDS-DMA pieces per wave and half
+    constexpr int kFill = kDma + NT;                         // filler slots used per phase
+    constexpr int kTail = kFill > kGaps ? kGaps : kFill;     // narrow widths: the slots past the last gap run after the MFMAs
     float* s_bias = reinterpret_cast<float*>(lds + LD::off_bias);
-    for (int l = 1; l < a.L; ++l) {
-        QSTAMP(0, l, 0);
-        f32x4 stg[kStage];
-        f32x4 bstg = f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]);
-        const f32x4* bsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l]);
-        if (late) {   // stream W_r(l) towards half B
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = wsrc[kHalf + i]; }
-        }
-        f32x4 acc[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float rs = 1.f, rinv = 1.f;
-        QSTAMP(0, l, 8);
-        if (wactive) {
-            // phase 1: mean-gather from LDS, then K-half over W_l (half A)
-            f32x4 ag[NT];
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid) {
-                if (csr_lds) {
-                    gather_nbrs<NT, XS>(xbuf, s_col, nbr, g, ag);
-                } else {
-                    for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
-                        const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
-#pragma unroll
-                        for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
-                    }
-                }
-                QSTAMP(0, l, 9);
-#pragma unroll
-                for (int c = 0; c < NT; ++c) ag[c] *= idg;
-            }
-            f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[l]) + (size_t)grow * HP) + g;
-            if (late && rvalid && a.need_backward) {
-#pragma unroll
-                for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
-            }
-            QSTAMP(0, l, 1);
-            if constexpr (MATH == 1) {   // one power-of-two scale per row over [agg | x]
-                const float m = row_max4(frag_absmax<NT>(xs, frag_absmax<NT>(ag, 0.f)));
-                row_scale(m, rs, rinv);
-                if (a.xmax) { const float wm = rows_max16(m); if (lane == 0) s_max[wave] = wm; }
-                rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
-            }
-            contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
-            QSTAMP(0, l, 2);
-            if (!late && rvalid && a.need_backward) {
-#pragma unroll
-                for (int c = 0; c < NT; ++c) ao[4 * c] = ag[c];
-            }
-        }
-        if (!late) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = wsrc[kHalf + i]; }
-            if (tid < HP / 4) bstg = bsrc[tid];      // this layer's bias row -> LDS (read in the epilogue)
-        }
-#pragma unroll
-        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
-        if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg;
-        QSTAMP(0, l, 3);
-        lds_barrier();     // barrier 1: half B = W_r(l) + bias row; every gather of this layer is done; half A is free
-        QSTAMP(0, l, 4);
-        if constexpr (MATH == 1) {
-            if (a.xmax && tid == 0) {   // layer maximum of [agg | x] over this graph -> global (order-independent)
+    const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + LD::off_w);
+    const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
+    const unsigned lane16 = 16 * lane;
+    auto store_acts = [&](const int l, const int t) {     // chunk t of this lane's row of layer l's output
+        if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == l))
+            buf_store(xs[t], slab_rsrc(a.acts + slab * l), rowoff + 64 * t);
+    };
+    auto publish_xmax = [&](const int l) {   // layer maximum of [agg | x] over this graph -> global (order-independent);
+        if constexpr (MATH == 1) {           // called one barrier after the waves wrote s_max
+            if (a.xmax && tid == 0) {
                 float mm = 0.f;
 #pragma unroll
                 for (int w8 = 0; w8 < 8; ++w8) mm = fmaxf(mm, s_max[w8]);
                 atomicMax(a.xmax + l, __builtin_bit_cast(unsigned, mm));
             }
         }
+    };
+    for (int l = 1; l < a.L; ++l) {
+        QSTAMP(0, l, 0);
+        if (l > 1) publish_xmax(l - 1);
+        const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]);
+        f32x4 bstg = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < HP / 4) bstg = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l])[tid];
+        f32x4 acc[NT], ag[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[t] = acc[t]; }
+        float rs = 1.f, rinv = 1.f, mx = 0.f;
+        const bool fastg = csr_lds && wactive;
+        f32x4 tb[NT];
+        if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(xs, 0.f)); row_scale(mx, rs, rinv); }
+        // ---- phase S ----
+        auto fillS = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            if (fastg) gather_gap<NT, Q, kGaps>(xbuf, nbr, ag, tb);
+            if constexpr (Q < kDma) {
+                const int p = dma_share<NT>(wave, Q);
+                if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
+            } else if constexpr (Q < kDma + NT) {
+                if (l > 1) store_acts(l - 1, Q - kDma);
+            }
+        };
+        if (wactive) { contract_half_fill<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs, fillS); static_for<kTail, kFill>(fillS); }
+        else static_for<0, kDma>(fillS);      // idle waves still move their weight pieces
+        if (wactive && rvalid) {
+            if (csr_lds) {
+                if (nbr.wlong) gather_lds<NT, XS>(xbuf, s_col, nbr.eb, nbr.ee, g, ag);
+            } else {
+                for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
+                    const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] *= idg;          // idg == 0 on pad rows
+        QSTAMP(0, l, 1);
+        wait_vmem();
+        if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg;
+        QSTAMP(0, l, 3);
+        lds_barrier();     // barrier 1: half A = W_l(l) + bias row; every gather of this layer is done; half B is free
+        QSTAMP(0, l, 4);
+        // ---- phase A ----
+        float rsa = 1.f;
+        if constexpr (MATH == 1) {
+            // the aggregate gets its own power-of-two row scale (it was not known when the self half ran); the self
+            // half's sums are carried over by the exact ratio of the two scales
+            float ma = row_max4(frag_absmax<NT>(ag, 0.f));
+            if (a.xmax) { const float wm = rows_max16(fmaxf(ma, mx)); if (lane == 0) s_max[wave] = wm; }
+            ma = fmaxf(ma, mx * 0x1p-40f);
+            float rinva;
+            row_scale(ma, rsa, rinva);
+            const float carry = rsa * rinv;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] *= carry;
+            rinv = rinva * (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
+        }
         const bool more = l + 1 < a.L;
-        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[more ? l + 1 : l]);
-        if (late && more) {   // stream W_l(l+1) towards half A
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = nsrc[i]; }
-        }
-        if (wactive) {
-            // phase 2: K-half over W_r (half B) with the self rows kept in registers
-            contract_half<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs);
-            QSTAMP(0, l, 5);
-        }
-        if (!late && more) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) stg[k] = nsrc[i]; }
-        }
-        if (wactive) {   // epilogue, part 1: bias, ReLU, new rows -> LDS
+        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[more ? l + 1 : l]) + kHalf;
+        const __amdgpu_buffer_rsrc_t ao = slab_rsrc(a.saved + a.agg_off[l]);
+        auto fillA = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            if constexpr (Q < kDma) {
+                const int p = dma_share<NT>(wave, Q);
+                if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+            } else if constexpr (Q < kDma + NT) {
+                if (rvalid && a.need_backward) buf_store(ag[Q - kDma], ao, rowoff + 64 * (Q - kDma));
+            }
+        };
+        if (wactive) { contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA); static_for<kTail, kFill>(fillA); }
+        else static_for<0, kDma>(fillA);
+        QSTAMP(0, l, 5);
+        if (wactive) {   // epilogue: bias, ReLU, new rows -> registers and LDS
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
             const f32x4* bl = reinterpret_cast<const f32x4*>(s_bias) + g;
 #pragma unroll
@@ -583,22 +744,15 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 xr[4 * t] = v;
             }
         }
-        // staged half A -> LDS BEFORE the epilogue's global stores: vmcnt counts loads and stores in one in-order
-        // counter, so a wait for the staged loads placed after the stores also waits for the stores' L2 acknowledgement
-        if (more) {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-        }
-        if (wactive) {
-            if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == l)) {
-                f32x4* yo = reinterpret_cast<f32x4*>(a.acts + slab * l + (size_t)grow * HP) + g;
-#pragma unroll
-                for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
-            }
-        }
+        wait_vmem();
         QSTAMP(0, l, 6);
-        lds_barrier();     // barrier 2: new rows + half A visible; half B free
+        lds_barrier();     // barrier 2: new rows + half B = W_r(l+1) visible; half A free
         QSTAMP(0, l, 7);
+    }
+    if (a.L > 1) {
+        publish_xmax(a.L - 1);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) store_acts(a.L - 1, t);
     }
 
     // ---- head tail (scratch aliases the weight halves, free after the last barrier) ----
