@@ -895,7 +895,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const unsigned short* s_rp = reinterpret_cast<const unsigned short*>(lds + LD::off_rp);
     const unsigned char* s_col = reinterpret_cast<const unsigned char*>(lds + LD::off_col);
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 15, g = lane >> 4;
     const int gi = blockIdx.x;
     QSTAMP(1, 0, 0);
@@ -916,9 +916,9 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int H2 = H / 2, H4 = 4 * H;
     constexpr int kStage = (kHalf + 511) / 512;
 
-    // stage the W_l part of the top layer into half A (its W_r part is streamed inside the layer loop)
+    // stage the W_r part of the top layer into half B (the self half runs first; everything else arrives by LDS-DMA)
     if (L > 1) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]);
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]) + kHalf;
         f32x4 tmp[kStage];
 #pragma unroll
         for (int k = 0; k < kStage; ++k) {
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             if (i < kHalf) tmp[k] = src[i];
         }
 #pragma unroll
-        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = tmp[k]; }
+        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = tmp[k]; }
     }
 
     // ---- head tail backward; scratch aliases dbuf (not written before the first barrier A) ----
@@ -1076,42 +1076,32 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             }
         }
     };
-    auto store_G = [&](const int l) {
-        if (rvalid) {
-            f32x4* go = reinterpret_cast<f32x4*>(a.G + slab * l + (size_t)grow * HP) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) go[4 * t] = gx[t];
-        }
+    const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
+    const unsigned lane16 = 16 * lane;
+    auto store_G = [&](const int l, const int t) {       // chunk t of this lane's row of G_l (held in gx)
+        if (rvalid) buf_store(gx[t], slab_rsrc(a.G + slab * l), rowoff + 64 * t);
     };
     QSTAMP(1, 0, 1);
-    if (wactive) { mask_rows(L - 1, ytop); store_G(L - 1); }
+    if (wactive) {
+        mask_rows(L - 1, ytop);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) store_G(L - 1, t);
+    }
     lds_barrier();
     QSTAMP(1, 0, 2);
-    // early / late wave groups: see the forward kernel
-    const bool late = wave >= 4;
+    // Per layer two phases in the forward kernel's shape (fillers between the MFMA groups):
+    //   phase S: G_l (registers) x W_r part (half B); fillers = transposed LDS gather of G_l / deg, the deferred store of
+    //            G_l, LDS-DMA of the W_l part into half A                                          -> barrier 1
+    //   phase A: gathered rows x W_l part (half A); fillers = loads of y_{l-1}, LDS-DMA of layer l-1's W_r part into
+    //            half B; then mask by y_{l-1}, G_{l-1} / deg -> LDS                                -> barrier 2
+    constexpr int kGaps = Gaps<NT, MATH>::value;
+    constexpr int kDma = (NT * NT + 7) / 8;
+    constexpr int kFill = kDma + NT;
+    constexpr int kTail = kFill > kGaps ? kGaps : kFill;
+    const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + LD::off_w);
     for (int l = L - 1; l >= 1; --l) {
         QSTAMP(1, l, 0);
-        f32x4 yl[NT];        // y_{l-1} rows for this iteration's closing mask
-        f32x4 stg[kStage];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) yl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const f32x4* yn = reinterpret_cast<const f32x4*>(a.acts + slab * (l - 1) + (size_t)grow * HP) + g;
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l]);
-        // W_r part of layer l -> registers (towards half B)
-        auto load_half_b = [&]() {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) {
-                const int i = tid + 512 * k;
-                if (i < kHalf) stg[k] = wsrc[kHalf + i];
-            }
-        };
-        if (late) {
-            if (rvalid) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) yl[t] = yn[4 * t];
-            }
-            load_half_b();
-        }
         if constexpr (MATH == 1) {
             if (a.gmax && tid == 0) {   // layer maximum of |G_l| over this graph -> global (order-independent)
                 float mm = 0.f;
@@ -1120,78 +1110,85 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 atomicMax(a.gmax + l, __builtin_bit_cast(unsigned, mm));
             }
         }
-        f32x4 acc[NT];
+        f32x4 acc[NT], ag[NT];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-        float rs = 1.f, rinv = 1.f;
-        QSTAMP(1, l, 8);
-        if (wactive) {
-            // phase 1: transposed gather of G_l / deg from LDS, then K-half over the W_l part (half A)
-            f32x4 ag[NT];
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid) {
-                if (csr_lds) {
-                    gather_nbrs<NT, XS>(dbuf, s_col, nbr, g, ag);
-                } else {
-                    for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
-                        const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
-#pragma unroll
-                        for (int c = 0; c < NT; ++c) ag[c] += dj[4 * c];
-                    }
-                }
-            }
-            QSTAMP(1, l, 1);
-            if constexpr (MATH == 1) {   // one power-of-two scale per row over [T(G/deg) | G]
-                const float m = row_max4(frag_absmax<NT>(gx, frag_absmax<NT>(ag, 0.f)));
-                row_scale(m, rs, rinv);
-                rinv *= (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
-            }
-            contract_half<NT, MATH>(wbuf, lane, ag, acc, rs);
-            QSTAMP(1, l, 2);
-        }
-        if (!late) {
-            if (rvalid) {
-#pragma unroll
-                for (int t = 0; t < NT; ++t) yl[t] = yn[4 * t];
-            }
-            load_half_b();
-        }
-#pragma unroll
-        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = stg[k]; }
-        QSTAMP(1, l, 3);
-        lds_barrier();     // barrier 1: half B = W_r part; every gather of this layer is done (dbuf free); half A free
-        QSTAMP(1, l, 4);
-        const bool more = l - 1 >= 1;
-        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[more ? l - 1 : l]);
-        // W_l part of layer l-1 -> registers (towards half A)
-        auto load_half_a = [&]() {
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) {
-                const int i = tid + 512 * k;
-                if (i < kHalf) stg[k] = nsrc[i];
+        for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[t] = acc[t]; }
+        float rs = 1.f, rinv = 1.f, mx = 0.f;
+        const bool fastg = csr_lds && wactive;
+        f32x4 tb[NT];
+        if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(gx, 0.f)); row_scale(mx, rs, rinv); }
+        // ---- phase S ----
+        auto fillS = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            if (fastg) gather_gap<NT, Q, kGaps>(dbuf, nbr, ag, tb);
+            if constexpr (Q < kDma) {
+                const int p = dma_share<NT>(wave, Q);
+                if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
+            } else if constexpr (Q < kDma + NT) {
+                if (l < L - 1) store_G(l, Q - kDma);
             }
         };
-        if (late && more) load_half_a();
-        if (wactive) {
-            // phase 2: K-half over the W_r part (half B) with G_l from registers; the result is dL/dy_{l-1}
-            contract_half<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs);
-            QSTAMP(1, l, 5);
+        if (wactive) { contract_half_fill<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs, fillS); static_for<kTail, kFill>(fillS); }
+        else static_for<0, kDma>(fillS);      // idle waves still move their weight pieces
+        if (wactive && rvalid) {
+            if (csr_lds) {
+                if (nbr.wlong) gather_lds<NT, XS>(dbuf, s_col, nbr.eb, nbr.ee, g, ag);
+            } else {
+                for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
+                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) ag[c] += dj[4 * c];
+                }
+            }
         }
-        if (!late && more) load_half_a();
+        QSTAMP(1, l, 1);
+        wait_vmem();
+        QSTAMP(1, l, 3);
+        lds_barrier();     // barrier 1: half A = W_l part; every gather of this layer is done (dbuf free); half B free
+        QSTAMP(1, l, 4);
+        // ---- phase A ----
+        float rsa = 1.f;
+        if constexpr (MATH == 1) {   // own power-of-two row scale for the gathered rows, exact carry of the self half's sums
+            float ma = row_max4(frag_absmax<NT>(ag, 0.f));
+            ma = fmaxf(ma, mx * 0x1p-40f);
+            float rinva;
+            row_scale(ma, rsa, rinva);
+            const float carry = rsa * rinv;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] *= carry;
+            rinv = rinva * (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
+        }
+        const bool more = l - 1 >= 1;
+        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[more ? l - 1 : l]) + kHalf;
+        const __amdgpu_buffer_rsrc_t yr = slab_rsrc(a.acts + slab * (l - 1));
+        f32x4 yl[NT];        // y_{l-1} rows for this iteration's closing mask
+#pragma unroll
+        for (int t = 0; t < NT; ++t) yl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto fillA = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            if constexpr (Q < NT) {
+                if (rvalid) yl[Q] = buf_load(yr, rowoff + 64 * Q);
+            } else if constexpr (Q < NT + kDma) {
+                const int p = dma_share<NT>(wave, Q - NT);
+                if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+            }
+        };
+        if (wactive) { contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA); static_for<kTail, kFill>(fillA); }
+        else static_for<NT, NT + kDma>(fillA);
+        QSTAMP(1, l, 5);
         if (wactive) {
 #pragma unroll
             for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
             mask_rows(l - 1, yl);
         }
-        if (more) {   // before the global stores
-#pragma unroll
-            for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[i] = stg[k]; }
-        }
-        if (wactive) store_G(l - 1);
+        wait_vmem();
         QSTAMP(1, l, 6);
-        lds_barrier();     // barrier 2: G_{l-1} rows + half A visible; half B free
+        lds_barrier();     // barrier 2: G_{l-1} rows + half B visible; half A free
         QSTAMP(1, l, 7);
+    }
+    if (wactive && L > 1) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) store_G(0, t);
     }
     // ---- raw first layer: this graph's share of dW_0 = G_0^T [agg0 | x0 | 1], reduced over the graphs afterwards ----
     if (a.first_part) {
