@@ -476,7 +476,10 @@ __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb,
 }
 
 // Saved-tensor traffic goes through raw buffer instructions: a wave-uniform resource (SGPRs) + one 32-bit lane offset +
-// an immediate, instead of a 64-bit address pair per access (the fused kernels run at the register ceiling).
+// an immediate, instead of a 64-bit address pair per access (the fused kernels run at the register ceiling).  A lane
+// that must not take part (pad row, tensor not requested) uses the offset kOob: the hardware drops stores and returns
+// zeros for loads beyond num_records, so a filler is ONE instruction, with no exec-mask branch around it.
+constexpr unsigned kOob = 0x80000000u;
 typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t slab_rsrc(const void* base) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
@@ -640,9 +643,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + LD::off_w);
     const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
     const unsigned lane16 = 16 * lane;
-    auto store_acts = [&](const int l, const int t) {     // chunk t of this lane's row of layer l's output
-        if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == l))
-            buf_store(xs[t], slab_rsrc(a.acts + slab * l), rowoff + 64 * t);
+    auto acts_off = [&](const int l) -> unsigned {        // lane offset for storing layer l's rows (kOob: not stored)
+        return (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == l)) ? rowoff : kOob;
     };
     auto publish_xmax = [&](const int l) {   // layer maximum of [agg | x] over this graph -> global (order-independent);
         if constexpr (MATH == 1) {           // called one barrier after the waves wrote s_max
@@ -668,6 +670,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         f32x4 tb[NT];
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(xs, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
+        const __amdgpu_buffer_rsrc_t yprev = slab_rsrc(a.acts + slab * (l - 1));
+        const unsigned yprev_off = l > 1 ? acts_off(l - 1) : kOob;     // layer 0's rows were stored by the first-layer code
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             if (fastg) gather_gap<NT, Q, kGaps>(xbuf, nbr, ag, tb);
@@ -675,7 +679,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 const int p = dma_share<NT>(wave, Q);
                 if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
             } else if constexpr (Q < kDma + NT) {
-                if (l > 1) store_acts(l - 1, Q - kDma);
+                buf_store(xs[Q - kDma], yprev, yprev_off + 64 * (Q - kDma));
             }
         };
         if (wactive) { contract_half_fill<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs, fillS); static_for<kTail, kFill>(fillS); }
@@ -717,13 +721,14 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         const bool more = l + 1 < a.L;
         const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[more ? l + 1 : l]) + kHalf;
         const __amdgpu_buffer_rsrc_t ao = slab_rsrc(a.saved + a.agg_off[l]);
+        const unsigned ao_off = (rvalid && a.need_backward) ? rowoff : kOob;
         auto fillA = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             if constexpr (Q < kDma) {
                 const int p = dma_share<NT>(wave, Q);
                 if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
             } else if constexpr (Q < kDma + NT) {
-                if (rvalid && a.need_backward) buf_store(ag[Q - kDma], ao, rowoff + 64 * (Q - kDma));
+                buf_store(ag[Q - kDma], ao, ao_off + 64 * (Q - kDma));
             }
         };
         if (wactive) { contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA); static_for<kTail, kFill>(fillA); }
@@ -751,8 +756,10 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     }
     if (a.L > 1) {
         publish_xmax(a.L - 1);
+        const __amdgpu_buffer_rsrc_t ylast = slab_rsrc(a.acts + slab * (a.L - 1));
+        const unsigned ylast_off = acts_off(a.L - 1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) store_acts(a.L - 1, t);
+        for (int t = 0; t < NT; ++t) buf_store(xs[t], ylast, ylast_off + 64 * t);
     }
 
     // ---- head tail (scratch aliases the weight halves, free after the last barrier) ----
@@ -1078,8 +1085,9 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     };
     const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
     const unsigned lane16 = 16 * lane;
+    const unsigned rowoff_v = rvalid ? rowoff : kOob;    // pad rows: stores dropped, loads return zeros
     auto store_G = [&](const int l, const int t) {       // chunk t of this lane's row of G_l (held in gx)
-        if (rvalid) buf_store(gx[t], slab_rsrc(a.G + slab * l), rowoff + 64 * t);
+        buf_store(gx[t], slab_rsrc(a.G + slab * l), rowoff_v + 64 * t);
     };
     QSTAMP(1, 0, 1);
     if (wactive) {
@@ -1118,6 +1126,8 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         f32x4 tb[NT];
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(gx, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
+        const __amdgpu_buffer_rsrc_t gcur = slab_rsrc(a.G + slab * l);
+        const unsigned gcur_off = l < L - 1 ? rowoff_v : kOob;      // the top layer's G was stored ahead of the loop
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             if (fastg) gather_gap<NT, Q, kGaps>(dbuf, nbr, ag, tb);
@@ -1125,7 +1135,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 const int p = dma_share<NT>(wave, Q);
                 if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
             } else if constexpr (Q < kDma + NT) {
-                if (l < L - 1) store_G(l, Q - kDma);
+                buf_store(gx[Q - kDma], gcur, gcur_off + 64 * (Q - kDma));
             }
         };
         if (wactive) { contract_half_fill<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs, fillS); static_for<kTail, kFill>(fillS); }
@@ -1162,12 +1172,10 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[more ? l - 1 : l]) + kHalf;
         const __amdgpu_buffer_rsrc_t yr = slab_rsrc(a.acts + slab * (l - 1));
         f32x4 yl[NT];        // y_{l-1} rows for this iteration's closing mask
-#pragma unroll
-        for (int t = 0; t < NT; ++t) yl[t] = f32x4{0.f, 0.f, 0.f, 0.f};
         auto fillA = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             if constexpr (Q < NT) {
-                if (rvalid) yl[Q] = buf_load(yr, rowoff + 64 * Q);
+                yl[Q] = buf_load(yr, rowoff_v + 64 * Q);
             } else if constexpr (Q < NT + kDma) {
                 const int p = dma_share<NT>(wave, Q - NT);
                 if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
