@@ -459,7 +459,11 @@ __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb,
     const char* base = reinterpret_cast<const char*>(rows);
     static_for<0, 32>([&](auto mm) {
         constexpr int m = decltype(mm)::value;
-        if constexpr (m * G / 32 == Q) {
+        // 28 gaps (width 97..112, the GNN-L case): shifted by 4/32 so that a neighbour's read and its first add never share
+        // a gap and an MFMA group covers the LDS latency (other widths: the shift only moved hipcc into spilling)
+        constexpr int kShift = G == 28 ? 4 : 0;
+        constexpr int gap = (m * G + kShift) / 32;
+        if constexpr (gap == Q) {
             constexpr int k = m / 4, part = m % 4;
             if (k < nb.wmax) {       // wave-uniform
                 if constexpr (part == 0) {
