@@ -1,9 +1,9 @@
 #!/bin/bash
-# Round-1 profile collection (run on the MI355X box through gpurun from the repo root; outputs under gpurun_out/p5).
+# Round-1 profile collection (run on the MI355X box through gpurun from the repo root; outputs under gpurun_out/$PROFILE_TAG, default p6).
 # Kernel times and PMC counters are taken in SEPARATE runs; FETCH_SIZE and WRITE_SIZE need separate passes (TCC slots).
 set -e
 R=${GRAFT_REPO_ROOT:-$PWD}
-O=$R/gpurun_out/p5
+O=$R/gpurun_out/${PROFILE_TAG:-p6}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for m in fp32 f16x3; do
