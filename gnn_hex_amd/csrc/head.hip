@@ -333,16 +333,23 @@ __global__ __launch_bounds__(256) void td_loss_fwd_kernel(int n, int k, const fl
     if (threadIdx.x == 0) loss[0] = red[0] / (float)(k > 0 ? k : 1);
 }
 
-__global__ void td_loss_bwd_kernel(int n, int k, const int64_t* __restrict__ sel, const float* __restrict__ td,
-                                   const float* __restrict__ w, int loss_fn, const float* __restrict__ gloss,
-                                   float* __restrict__ dq) {
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= k) return;
-    const int64_t i = sel[j];
-    if (i < 0 || i >= n) return;
-    const float d = td[j];
-    const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
-    atomicAdd(dq + i, gloss[0] * (w ? w[j] : 1.f) * dl / (float)k);   // one add per selected node (duplicates: two adds commute)
+// One launch: every workgroup clears its 1024-entry range of dq, then adds the selected nodes that fall into it (the
+// zeroing memset used to be a launch of its own).
+__global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const int64_t* __restrict__ sel,
+                                                         const float* __restrict__ td, const float* __restrict__ w,
+                                                         int loss_fn, const float* __restrict__ gloss,
+                                                         float* __restrict__ dq) {
+    const int lo = blockIdx.x * 1024, hi = min(lo + 1024, n);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) dq[i] = 0.f;
+    __syncthreads();
+    const float gl = gloss[0] / (float)k;
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const int64_t i = sel[j];
+        if (i < lo || i >= hi) continue;
+        const float d = td[j];
+        const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
+        atomicAdd(dq + i, gl * (w ? w[j] : 1.f) * dl);   // one add per selected node (duplicates: two adds commute)
+    }
 }
 
 
@@ -411,8 +418,7 @@ int hexgnn_td_loss_backward(int n, int k, const int64_t* sel, const float* td, c
                             const float* grad_loss, float* dq, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 0 || k < 0 || loss_fn < 0 || loss_fn > 1 || !grad_loss || (n > 0 && !dq) || (k > 0 && (!sel || !td))) return HEXGNN_EINVAL;
-    if (n > 0) (void)hipMemsetAsync(dq, 0, sizeof(float) * (size_t)n, st);
-    if (k > 0 && n > 0) td_loss_bwd_kernel<<<(k + 255) / 256, 256, 0, st>>>(n, k, sel, td, weights, loss_fn, grad_loss, dq);
+    if (n > 0) td_loss_bwd_kernel<<<(n + 1023) / 1024, 256, 0, st>>>(n, k, sel, td, weights, loss_fn, grad_loss, dq);
     return check_launch();
 }
 

@@ -55,22 +55,30 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(GradReduceArgs a)
     int blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, hp = a.hp;
-    if (blk < a.n0) {                     // ---- R0
+    if (blk < a.n0) {                     // ---- R0: slice slabs -> dW_l / dW_r / db of one hidden layer
+        // one thread per float4 of the [hp][2hp] slab (+ the bias row), S independent 16-byte loads in flight
         const int li = blk / a.blk_per_layer, idx = (blk % a.blk_per_layer) * 256 + tid;
-        const int per = 2 * H + 1;
-        if (idx >= H * per) return;
-        const int o = idx / per, c = idx % per;
+        const int q_row = 2 * hp / 4, q_w = hp * q_row, q_all = q_w + hp / 4;
+        if (idx >= q_all) return;
         const size_t slab_sz = (size_t)hp * (2 * hp + 1);
-        size_t off;
-        if (c < H) off = (size_t)o * 2 * hp + c;
-        else if (c < 2 * H) off = (size_t)o * 2 * hp + hp + (c - H);
-        else off = (size_t)hp * 2 * hp + o;
-        const float* p = a.part + (size_t)li * a.S * slab_sz + off;
-        float sum = 0.f;
-        for (int s = 0; s < a.S; ++s) sum += p[(size_t)s * slab_sz];
-        if (c < H) a.dwl[li][o * H + c] = sum;
-        else if (c < 2 * H) a.dwr[li][o * H + (c - H)] = sum;
-        else a.dbl[li][o] = sum;
+        const f32x4* p = reinterpret_cast<const f32x4*>(a.part + (size_t)li * a.S * slab_sz) + idx;   // slab_sz % 4 == 0
+        f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+        for (int s = 0; s < a.S; ++s) sum += p[(size_t)s * (slab_sz / 4)];
+        if (idx < q_w) {
+            const int o = idx / q_row, c0 = (idx % q_row) * 4;
+            if (o >= H) return;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + j;
+                if (c < H) a.dwl[li][o * H + c] = sum[j];
+                else if (c >= hp && c - hp < H) a.dwr[li][o * H + (c - hp)] = sum[j];
+            }
+        } else {
+            const int o0 = (idx - q_w) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (o0 + j < H) a.dbl[li][o0 + j] = sum[j];
+        }
         return;
     }
     blk -= a.n0;
@@ -302,7 +310,7 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
         const int nh = total_layers - 1;
         for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[i + 1]; r.dbl[i] = d_bl[i + 1]; r.dwr[i] = d_wr[i + 1]; }
         r.part = part; r.S = dw_slices_for(n, nh, math); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
-        r.blk_per_layer = (hidden * (2 * hidden + 1) + 255) / 256;
+        r.blk_per_layer = (qp.sp.hp * (2 * qp.sp.hp + 1) / 4 + 255) / 256;      // one thread per float4 of a slab
         r.first_part = a.first_part; r.b = b; r.c_in = c_in; r.dwl0 = d_wl[0]; r.dbl0 = d_bl[0]; r.dwr0 = d_wr[0];
         r.lin_part = a.lin_part; r.d_lin_w = d_lin_w; r.d_lin_b = d_lin_b;
         r.dz = a.dz; r.dvr = a.dvr; r.pooled = (const float*)(hsv + qp.hs.pooled_off); r.z = (const float*)(hsv + qp.hs.z_off);
