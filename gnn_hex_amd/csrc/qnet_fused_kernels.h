@@ -5,12 +5,13 @@
 //
 // MI355X design.  A Hex-11 graph is 123 x 110 fp32 = 54 KB: the node features of ALL layers stay in the CU's
 // 160 KB LDS, so neighbour gathers are LDS reads and nothing but the saved activations goes to HBM.
-//   LDS:  [ W half A | W half B | node rows 128 x (HP+4) | CSR (u16 rowptr, u8 col) ]
+//   LDS:  [ W half A | W half B | node rows 129 x (HP+4) (row 128 all zero) | CSR (u16 rowptr, u8 col) | maxima | bias row ]
 //   wave w owns rows 16w..16w+15; lane (r = l&15, g = l>>4) holds, for its row r, the 4-float feature chunks
 //   {16c+4g..+3}, c < NT.  MFMAs run with SWAPPED operands (a = packed weights, b = row fragment): the tile comes
 //   out transposed, i.e. in the SAME lane layout, so a layer's output registers are the next layer's self operand.
-//   Per layer the [agg|x] contraction is split in two K phases (W_l half, W_r half); while one half is in use the
-//   other half of the next phase/layer is streamed L2 -> registers -> LDS (two barriers per layer).
+//   Per layer the [agg|x] contraction is split in two K phases, self half (W_r) first, then the aggregate half (W_l);
+//   the layer's other work (LDS gather, saved-tensor stores / loads, LDS-DMA of the weight half the other phase needs)
+//   is issued in small pieces between the MFMA groups of the two contractions (two barriers per layer).
 //   fp32 in / fp32 accumulate (v_mfma_f32_16x16x4_f32): exact fmaf chains, deterministic.
 #pragma once
 #include <type_traits>
@@ -85,6 +86,7 @@ template <int NT> struct QLds {
     static_assert(col_cap >= 1024 && total <= kLdsBytes, "LDS budget");
     static_assert(!scr_alias || kHalf * 16 >= scr_bytes, "scratch must fit one weight half");
     static_assert(!scr_alias || 2 * kHalf * 16 >= scr0_bytes, "first-layer scratch must fit the weight halves");
+    static_assert((1160 + 20 * HP) <= (kRows + 1) * XS, "backward head-tail scratch must fit the row buffer");
 };
 
 __device__ __forceinline__ float wsum64(float v) {
@@ -131,22 +133,6 @@ __device__ __forceinline__ void copy_f4_to_lds(f32x4* __restrict__ dst, const f3
 #pragma unroll
     for (int k = 0; k < kMaxPer; ++k) { const int i = threadIdx.x + 512 * k; if (i < count) dst[i] = tmp[k]; }
 }
-
-// acc[t] += W-fragment(c,t) x row-fragment(c), all NT output tiles per k-chunk with the accumulators ROTATING
-// (consecutive v_mfma never touch the same accumulator: 16x16x4 has a 40-cycle dependent latency, 32-cycle issue).
-template <int NT>
-__device__ __forceinline__ void mfma_chunk(const f32x4* __restrict__ wfrag /* &w[(c*NT)*64 + lane] */, const f32x4 a,
-                                           f32x4 (&acc)[NT]) {
-    f32x4 w[NT];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) w[t] = wfrag[t * 64];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) acc[t] = mfma16x16x4(w[t][j], a[j], acc[t]);
-    }
-}
-
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -198,49 +184,6 @@ __device__ __forceinline__ float rows_max16(float m) {  // ... then over the wav
 #pragma unroll
     for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o));
     return m;
-}
-
-// One K-half of a layer: acc[t] += sum_c W(c,t)^T * x[c] over the NT feature chunks of this lane's row.
-//   MATH 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), weights packed as float4 fragments; `scale` unused.
-//   MATH 1: split precision ("f16x3"): W s_W = Whi + Wlo, x s = xhi + xlo in fp16 (s = this row's power-of-two scale),
-//           acc += Wlo*xhi + Whi*xlo + Whi*xhi on v_mfma_f32_16x16x32_f16 (chunk pairs) / v_mfma_f32_16x16x16_f16
-//           (odd last chunk), fp32 accumulate; the caller multiplies by 1/(s s_W).
-template <int NT, int MATH>
-__device__ __forceinline__ void contract_half(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
-                                              f32x4 (&acc)[NT], const float scale = 1.f) {
-    if constexpr (MATH == 0) {
-#pragma unroll
-        for (int c = 0; c < NT; ++c) mfma_chunk<NT>(whalf + (c * NT) * 64 + lane, x[c], acc);
-    } else {
-        const char* wb = reinterpret_cast<const char*>(whalf);
-#pragma unroll
-        for (int p = 0; p < NT / 2; ++p) {
-            f16x8 xh, xl;
-            split_pair(x[2 * p], x[2 * p + 1], scale, xh, xl);
-            const char* ub = wb + (2 * p) * NT * 1024 + lane * 16;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f16x8 wh = *reinterpret_cast<const f16x8*>(ub + t * 2048);
-                const f16x8 wl = *reinterpret_cast<const f16x8*>(ub + t * 2048 + 1024);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wl, xh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wh, xh, acc[t], 0, 0, 0);
-            }
-        }
-        if constexpr (NT & 1) {
-            f16x4 xh, xl;
-            split_one(x[NT - 1], scale, xh, xl);
-            const char* ub = wb + (NT - 1) * NT * 1024 + lane * 8;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const f16x4 wh = *reinterpret_cast<const f16x4*>(ub + t * 1024);
-                const f16x4 wl = *reinterpret_cast<const f16x4*>(ub + t * 1024 + 512);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wl, xh, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xl, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(wh, xh, acc[t], 0, 0, 0);
-            }
-        }
-    }
 }
 
 // ag[c] += rows[j][chunk c] for every neighbour j of this lane's row; the NT reads of one neighbour are issued
@@ -312,49 +255,6 @@ __device__ __forceinline__ NbrRegs load_nbrs(const unsigned short* __restrict__ 
     nb.wlong = m > 8;
     return nb;
 }
-// ag[c] += rows[j][chunk c] over the row's neighbours j in ascending order: (.. + x_j0) + x_j1 ..., the reads of
-// neighbour k+2 in flight while neighbour k is added.
-template <int NT, int XS>
-__device__ __forceinline__ void gather_nbrs(const float* __restrict__ rows, const unsigned char* __restrict__ s_col,
-                                            const NbrRegs& nb, int g, f32x4 (&ag)[NT]) {
-    const char* base = reinterpret_cast<const char*>(rows);
-    if (nb.wmax > 0) {
-        f32x4 t0[NT], t1[NT];
-        {
-            const f32x4* x0 = reinterpret_cast<const f32x4*>(base + (nb.off[0] & 0xffffu));
-            const f32x4* x1 = reinterpret_cast<const f32x4*>(base + (nb.off[0] >> 16));
-#pragma unroll
-            for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
-#pragma unroll
-            for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
-        }
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-            __builtin_amdgcn_sched_barrier(0);     // two neighbours in flight, not eight (register budget)
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ag[c] += t0[c];
-            __builtin_amdgcn_sched_barrier(0);     // re-use t0's registers for the next reads
-            const bool more = k + 2 < 8 && k + 2 < nb.wmax;      // wave-uniform
-            if (more) {
-                const f32x4* x0 = reinterpret_cast<const f32x4*>(base + (nb.off[((k + 2) >> 1) & 3] & 0xffffu));
-#pragma unroll
-                for (int c = 0; c < NT; ++c) t0[c] = x0[4 * c];
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ag[c] += t1[c];
-            __builtin_amdgcn_sched_barrier(0);
-            if (!more) break;
-            {
-                const f32x4* x1 = reinterpret_cast<const f32x4*>(base + (nb.off[((k + 2) >> 1) & 3] >> 16));
-#pragma unroll
-                for (int c = 0; c < NT; ++c) t1[c] = x1[4 * c];
-            }
-        }
-    }
-    if (nb.wlong) gather_lds<NT, XS>(rows, s_col, nb.eb, nb.ee, g, ag);
-}
-
 // ---- filler-carrying contraction ---------------------------------------------------------------------------------
 // A wave's non-MFMA work issued under its PARTNER's MFMA stream runs ~3x slower (measured: gathers, epilogues, even
 // vector-memory issue), but small groups of instructions placed between a wave's OWN MFMAs are nearly free.  So each K-half
@@ -364,9 +264,28 @@ template <int B, int E, typename F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for<B + 1, E>(f); }
 }
+// hipcc 7.2 lets the destination of an MFMA whose accumulator moves (vdst != srcC) overlap a source operand that dies at
+// that instruction (seen at NT = 2: `v_mfma_f32_16x16x4_f32 v[12:15], v29, v15, v[34:37]`, the 4th result register wrong
+// on the hardware; found by the width-24 parity test).  An empty asm that names the operands after the MFMA group keeps
+// them alive across it, so the allocator cannot place a destination on them.
+template <typename T> __device__ __forceinline__ void keep_alive(const T& v) { asm volatile("" :: "v"(v)); }
+// Found by the width-24 parity test (NT = 2): with fewer than three accumulators in rotation an MFMA waits inside the
+// matrix pipe for its srcC (the previous result on the same accumulator); when the accumulator moves (vdst != srcC) hipcc
+// hands the dead srcC registers to the next LDS read (the fragment reload or a gather filler behind the group), and that
+// read's data came back before the queued MFMA had read srcC: the 4th accumulator register of a tile was wrong.  Nothing
+// interlocks an LDS return against a pending MFMA source, so narrow widths wait out the dependent chain (2 x 40 cycles)
+// before anything else is issued; from three tiles on the accumulators rotate further apart than the MFMA latency.
+__device__ __forceinline__ void mfma_drain() {
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+}
 template <int NT, int MATH> struct Gaps {
     static constexpr int value = MATH == 0 ? 4 * NT : (NT / 2) * NT + (NT & 1) * NT;
 };
+// One K-half of a layer: acc[t] += sum_c W(c,t)^T * x[c] over the NT feature chunks of this lane's row.
+//   MATH 0: exact fp32 MFMA (v_mfma_f32_16x16x4_f32), weights packed as float4 fragments; `scale` unused.
+//   MATH 1: split precision ("f16x3"): W s_W = Whi + Wlo, x s = xhi + xlo in fp16 (s = this row's power-of-two scale),
+//           acc += Wlo*xhi + Whi*xlo + Whi*xhi on v_mfma_f32_16x16x32_f16 (chunk pairs) / v_mfma_f32_16x16x16_f16
+//           (odd last chunk), fp32 accumulate; the caller multiplies by 1/(s s_W).
 template <int NT, int MATH, typename F>
 __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
                                                    f32x4 (&acc)[NT], const float scale, F&& fill) {
@@ -384,6 +303,11 @@ __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ wha
                 constexpr int j = decltype(jj)::value;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) acc[t] = mfma16x16x4(w[t][j], x[c][j], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NT < 3) mfma_drain();
+                keep_alive(x[c][j]);
+#pragma unroll
+                for (int t = 0; t < NT; ++t) keep_alive(w[t]);
                 if constexpr (j == 3 && c + 1 < NT) {
 #pragma unroll
                     for (int t = 0; t < NT; ++t) w[t] = whalf[((c + 1) * NT + t) * 64 + lane];
@@ -414,8 +338,13 @@ __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ wha
         };
         wload(std::integral_constant<int, 0>{}, wh[0], wl[0]);
         f16x8 xh, xl;
+        // The three MFMAs of a unit form a dependent chain on one accumulator, so the last one waits inside the matrix pipe
+        // (see mfma_drain): the accumulator's previous registers stay reserved for one more unit, which keeps hipcc from
+        // handing them to the LDS reads that follow the unit.
+        f32x4 held = acc[0];
         static_for<0, kUnits>([&](auto uu) {
             constexpr int u = decltype(uu)::value, p = u / NT, t = u % NT;
+            const f32x4 before = acc[t];
             if constexpr (t == 0) {
                 if constexpr (p < NT / 2) split_pair(x[2 * p], x[2 * p + 1], scale, xh, xl);
                 else {
@@ -439,6 +368,10 @@ __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ wha
                 acc[t] = __builtin_amdgcn_mfma_f32_16x16x16f16(h4, xh4, acc[t], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);
+            keep_alive(wh[u & 1]); keep_alive(wl[u & 1]); keep_alive(xh); keep_alive(xl);
+            keep_alive(held);
+            held = before;
+            if constexpr (NT < 3) mfma_drain();      // (wider kernels: load_guard() inside the fillers that issue loads)
             fill(std::integral_constant<int, u>{});
             __builtin_amdgcn_sched_barrier(0);
         });
@@ -454,7 +387,12 @@ __device__ __forceinline__ void gather_read(const char* base, unsigned off, f32x
 #pragma unroll
     for (int c = 0; c < NT; ++c) t[c] = x[4 * c];
 }
-template <int NT, int Q, int G>
+// A filler that issues a load right behind a split-precision unit first gives the unit's dependent MFMA chain 48 cycles to
+// start its last link (see mfma_drain; exact fp32 rotates 3+ accumulators and needs no guard).
+template <int MATH> __device__ __forceinline__ void load_guard() {
+    if constexpr (MATH == 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+}
+template <int NT, int Q, int G, int MATH>
 __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb, f32x4 (&ag)[NT], f32x4 (&tb)[NT]) {
     const char* base = reinterpret_cast<const char*>(rows);
     static_for<0, 32>([&](auto mm) {
@@ -467,6 +405,7 @@ __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb,
             constexpr int k = m / 4, part = m % 4;
             if (k < nb.wmax) {       // wave-uniform
                 if constexpr (part == 0) {
+                    load_guard<MATH>();
                     const unsigned o = nb.off[k >> 1];
                     gather_read<NT>(base, (k & 1) ? (o >> 16) : (o & 0xffffu), tb);
                 } else {
@@ -504,7 +443,9 @@ __device__ __forceinline__ void dma_piece(const void* gsrc_piece /* wave-uniform
     const unsigned long long sb = (unsigned long long)gsrc_piece;
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)sb), hi = __builtin_amdgcn_readfirstlane((unsigned)(sb >> 32));
     const unsigned long long sbase = ((unsigned long long)hi << 32) | lo;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+    // s_nop 4: lds_dst / sbase may come straight from v_readfirstlane, and a VALU-written SGPR needs 5 wait states before
+    // a vector-memory instruction reads it as its base (hipcc pads nothing inside an asm string)
+    asm volatile("s_nop 4\n\ts_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(lane_off), "s"(lds_dst), "s"(sbase) : "memory");
 }
 __device__ __forceinline__ void wait_vmem() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -678,7 +619,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         const unsigned yprev_off = l > 1 ? acts_off(l - 1) : kOob;     // layer 0's rows were stored by the first-layer code
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
-            if (fastg) gather_gap<NT, Q, kGaps>(xbuf, nbr, ag, tb);
+            if (fastg) gather_gap<NT, Q, kGaps, MATH>(xbuf, nbr, ag, tb);
             if constexpr (Q < kDma) {
                 const int p = dma_share<NT>(wave, Q);
                 if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
@@ -918,13 +859,32 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const bool rvalid = lrow < cnt;
     const bool wactive = wave * 16 < cnt;
     const int grow = r0 + lrow;
+    const int H2 = H / 2;
+    const size_t slab = (size_t)a.n * HP;
+    // Every global value the head-tail backward needs is requested here, before the CSR / weight staging, so that the
+    // chain below waits for ONE memory round trip instead of one per barrier-separated step.
+    const float dq_t = tid < cnt ? a.dq[r0 + tid] : 0.f;
+    const float advr_t = tid < cnt ? a.adv_raw[r0 + tid] : 0.f;
+    const float linw_t = (tid < 128 && tid < H) ? a.lin_w[tid] : 0.f;
+    float vraw_g = 0.f, doutv_g = 0.f, z_t = 0.f, v1w_t = 0.f;
+    int ax_t = -1, an_t = -1;
+    if (a.mode != 2) {
+        vraw_g = a.vraw[gi];
+        if (a.mode != 0) doutv_g = a.d_out_v[gi];
+        if (tid < H2) { z_t = a.z[(size_t)gi * H2 + tid]; v1w_t = a.v1_w[tid]; }
+        if (tid < H) { ax_t = a.amax[(size_t)gi * H + tid]; an_t = a.amin[(size_t)gi * H + tid]; }
+    }
+    f32x4 ytop[NT];      // y rows of the top layer: operand of the advantage-linear gradient and of the first ReLU mask
+    {
+        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) ytop[t] = rvalid ? yr[4 * t] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     const int e0 = a.rowptr_t[r0], ne = a.rowptr_t[r1] - e0;
     const bool csr_lds = load_csr<NT>(lds, a.rowptr_t, a.col_t, r0, cnt, e0, ne, a.status);
     float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
     if (tid < 16) s_max[tid] = 0.f;
     if (tid < XS) dbuf[kRows * XS + tid] = 0.f;                      // the gather's filler row
-    const size_t slab = (size_t)a.n * HP;
-    const int H2 = H / 2, H4 = 4 * H;
     constexpr int kStage = (kHalf + 511) / 512;
 
     // stage the W_r part of the top layer into half B (the self half runs first; everything else arrives by LDS-DMA)
@@ -950,45 +910,53 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     int* s_ax = reinterpret_cast<int*>(sc + 896);    // [128] local row of the max
     int* s_an = reinterpret_cast<int*>(sc + 1024);
     float* s_lin = sc + 1152;         // [8][HP+1]
-    if (tid < 128) s_w[tid] = tid < H ? a.lin_w[tid] : 0.f;
+    float* s_part = sc + ((1152 + 8 * (HP + 1) + 3) & ~3);   // [3][HP] float4 partial sums of the value-MLP product (narrow widths: the row buffer is small)
+    if (tid < 128) s_w[tid] = linw_t;
     float mean_dq = 0.f;
     const float inv_cnt = 1.f / (float)max(cnt, 1);
     if (a.mode != 2) {
-        float ps = 0.f;
-        if (tid < cnt) ps = a.dq[r0 + tid];
-        ps = wsum64(ps);
+        float ps = wsum64(dq_t);
         if (lane == 0) s_red[wave] = ps;
         if (tid < H) {
-            const int ax = a.amax[(size_t)gi * H + tid], an = a.amin[(size_t)gi * H + tid];
-            s_ax[tid] = ax >= 0 ? ax - r0 : -1;
-            s_an[tid] = an >= 0 ? an - r0 : -1;
+            s_ax[tid] = ax_t >= 0 ? ax_t - r0 : -1;
+            s_an[tid] = an_t >= 0 ? an_t - r0 : -1;
         }
         __syncthreads();
         float sdq = 0.f;
 #pragma unroll
         for (int w = 0; w < 8; ++w) sdq += s_red[w];
         mean_dq = sdq * inv_cnt;
-        const float dV = a.mode == 0 ? sdq : a.d_out_v[gi];
-        const float dv = dV * sech2f(a.vraw[gi]);
+        const float dV = a.mode == 0 ? sdq : doutv_g;
+        const float dv = dV * sech2f(vraw_g);
         if (tid == 0) a.dvr[gi] = dv;
         if (tid < H2) {
-            const float zz = a.z[(size_t)gi * H2 + tid];
-            const float d = zz > 0.f ? a.v1_w[tid] * dv : 0.f;
+            const float d = z_t > 0.f ? v1w_t * dv : 0.f;
             s_dz[tid] = d;
             a.dz[(size_t)gi * H2 + tid] = d;
         }
         __syncthreads();
-        for (int c = tid; c < H4; c += 512) {
-            float p = 0.f;
-#pragma unroll 16
-            for (int k = 0; k < H2; ++k) p += a.v0_w[(size_t)k * H4 + c] * s_dz[k];   // independent loads, 16 in flight
-            s_dp[c] = p;
+        // d pooled = v0_w^T dz  ([H2] x [H2][4H]): 16-byte column groups x four k phases, every load independent
+        {
+            const int cq = tid & 127, kg = tid >> 7;
+            f32x4 p4 = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (cq < H) {
+                const f32x4* wq = reinterpret_cast<const f32x4*>(a.v0_w) + cq;
+#pragma unroll 4
+                for (int k = kg; k < H2; k += 4) p4 += wq[(size_t)k * H] * s_dz[k];
+            }
+            if (kg > 0 && cq < H) reinterpret_cast<f32x4*>(s_part)[(kg - 1) * HP + cq] = p4;
+            __syncthreads();
+            if (kg == 0 && cq < H) {
+                const f32x4* sp = reinterpret_cast<const f32x4*>(s_part) + cq;
+                p4 += sp[0]; p4 += sp[HP]; p4 += sp[2 * HP];      // fixed order: deterministic
+                reinterpret_cast<f32x4*>(s_dp)[cq] = p4;
+            }
         }
     }
     if (tid < kRows) {
         float dar = 0.f;
         if (tid < cnt) {
-            dar = (a.dq[r0 + tid] - mean_dq) * 2.f * sech2f(a.adv_raw[r0 + tid]);
+            dar = (dq_t - mean_dq) * 2.f * sech2f(advr_t);
             a.dadv[r0 + tid] = dar;
         }
         s_dar[tid] = dar;
@@ -998,17 +966,13 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
 
     // gradient w.r.t. the top layer's output, in the chained lane layout; advantage-linear partial alongside
     f32x4 gx[NT];
-    f32x4 ytop[NT];      // y rows of the top layer: operand of the advantage-linear gradient and of the first ReLU mask
     {
         const float dar = s_dar[lrow];
-        const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
         float lacc[NT * 4];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
-            f32x4 yv = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (rvalid) yv = yr[4 * t];
-            ytop[t] = yv;
+            const f32x4 yv = ytop[t];
             f32x4 v;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
@@ -1134,7 +1098,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         const unsigned gcur_off = l < L - 1 ? rowoff_v : kOob;      // the top layer's G was stored ahead of the loop
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
-            if (fastg) gather_gap<NT, Q, kGaps>(dbuf, nbr, ag, tb);
+            if (fastg) gather_gap<NT, Q, kGaps, MATH>(dbuf, nbr, ag, tb);
             if constexpr (Q < kDma) {
                 const int p = dma_share<NT>(wave, Q);
                 if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
@@ -1179,6 +1143,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         auto fillA = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             if constexpr (Q < NT) {
+                load_guard<MATH>();
                 yl[Q] = buf_load(yr, rowoff_v + 64 * Q);
             } else if constexpr (Q < NT + kDma) {
                 const int p = dma_share<NT>(wave, Q - NT);

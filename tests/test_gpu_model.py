@@ -161,7 +161,7 @@ def test_mixed_sizes_ragged():
     _compare(hip, ref, x, ei, batch, ptr)
 
 
-@pytest.mark.parametrize("hidden", [16, 33, 64, 128])
+@pytest.mark.parametrize("hidden", [16, 24, 33, 64, 72, 96, 112, 128])
 def test_other_widths(hidden):
     hip, ref = make_pair(3, hidden, seed=hidden)
     x, ei, batch, ptr = batch_tensors("D1", [5, 6, 7, 8])
@@ -431,7 +431,7 @@ def test_randomised_configurations():
         pytest.skip("mode-independent: sets the modes itself")
     rng = np.random.default_rng(2026)
     for case in range(30):
-        hidden = int(rng.choice([16, 35, 48, 64, 96, 110]))
+        hidden = int(rng.choice([16, 30, 35, 48, 64, 80, 96, 110]))
         layers = int(rng.integers(1, 6))
         sizes = [int(rng.integers(3, 129)) for _ in range(int(rng.integers(1, 9)))]
         p_edge = float(rng.choice([0.02, 0.06, 0.15]))
