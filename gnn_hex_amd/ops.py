@@ -14,7 +14,14 @@ import torch
 from . import _lib
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """Raw hipStream_t of the current torch stream (the private fast accessor when this torch has it: the public
+    ``torch.cuda.current_stream()`` costs ~17 us per call, three times per step)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
