@@ -89,6 +89,18 @@ template <int NT> struct QLds {
     static_assert((1160 + 20 * HP) <= (kRows + 1) * XS, "backward head-tail scratch must fit the row buffer");
 };
 
+// sum over the 16 lanes of a DPP row (lanes 16k..16k+15), every lane receiving the total; same pairing as the xor butterfly
+// 1, 2, 4, 8, on the VALU instead of through the LDS crossbar
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});     // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});     // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});    // row_mirror
+    return v;
+}
 __device__ __forceinline__ float wsum64(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -989,13 +1001,11 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             gx[t] = v;
         }
         // d lin_w[c] partial = sum_rows dar*h[row][c]: reduce over the 16 rows of the wave, then over waves
-        float bacc = g == 0 ? dar : 0.f;
+        // (DPP row operations: the 16 rows of a wave are the 16 lanes of one DPP row; as __shfl_xor this butterfly was 116
+        // ds_bpermute per wave and took 7.7 us of the prologue)
+        float bacc = row16_sum(g == 0 ? dar : 0.f);
 #pragma unroll
-        for (int off = 1; off <= 8; off <<= 1) {
-#pragma unroll
-            for (int k = 0; k < NT * 4; ++k) lacc[k] += __shfl_xor(lacc[k], off);
-            bacc += __shfl_xor(bacc, off);
-        }
+        for (int k = 0; k < NT * 4; ++k) lacc[k] = row16_sum(lacc[k]);
         if (r == 0) {
 #pragma unroll
             for (int t = 0; t < NT; ++t)
