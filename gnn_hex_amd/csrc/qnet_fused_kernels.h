@@ -961,7 +961,9 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             if (kg == 0 && cq < H) {
                 const f32x4* sp = reinterpret_cast<const f32x4*>(s_part) + cq;
                 p4 += sp[0]; p4 += sp[HP]; p4 += sp[2 * HP];      // fixed order: deterministic
-                reinterpret_cast<f32x4*>(s_dp)[cq] = p4;
+                // s_dp = [sum | max | min | mean][128]: each pooled block on its own 16-byte aligned row
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const int f = 4 * cq + j; s_dp[(f / H) * 128 + f % H] = p4[j]; }
             }
         }
     }
@@ -981,19 +983,27 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     {
         const float dar = s_dar[lrow];
         float lacc[NT * 4];
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             const f32x4 w = reinterpret_cast<const f32x4*>(s_w)[4 * t + g];
             const f32x4 yv = ytop[t];
+            // this lane's four columns of the pooled gradients in 16-byte reads (as scalars: 168 ds_read_b32 per lane)
+            const f32x4 d_sum = reinterpret_cast<const f32x4*>(s_dp)[4 * t + g];
+            const f32x4 d_max = reinterpret_cast<const f32x4*>(s_dp + 128)[4 * t + g];
+            const f32x4 d_min = reinterpret_cast<const f32x4*>(s_dp + 256)[4 * t + g];
+            const f32x4 d_mean = reinterpret_cast<const f32x4*>(s_dp + 384)[4 * t + g];
+            const i32x4 axv = reinterpret_cast<const i32x4*>(s_ax)[4 * t + g];
+            const i32x4 anv = reinterpret_cast<const i32x4*>(s_an)[4 * t + g];
             f32x4 v;
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int c = 16 * t + 4 * g + q4;
                 float s = dar * w[q4];
                 if (a.mode != 2 && c < H) {
-                    s += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
-                    if (s_ax[c] == lrow) s += s_dp[H + c];
-                    if (s_an[c] == lrow) s += s_dp[2 * H + c];
+                    s += d_sum[q4] + d_mean[q4] * inv_cnt;
+                    if (axv[q4] == lrow) s += d_max[q4];
+                    if (anv[q4] == lrow) s += d_min[q4];
                 }
                 v[q4] = (rvalid && c < H) ? s : 0.f;
                 lacc[4 * t + q4] = dar * yv[q4];
