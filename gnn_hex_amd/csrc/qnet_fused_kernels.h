@@ -101,6 +101,16 @@ __device__ __forceinline__ float row16_sum(float v) {
     v += dpp(v, std::integral_constant<int, 0x140>{});    // row_mirror
     return v;
 }
+// sum over the 8 lanes 8k..8k+7 (DPP, same scheme as row16_sum)
+__device__ __forceinline__ float oct_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});
+    v += dpp(v, std::integral_constant<int, 0x4E>{});
+    v += dpp(v, std::integral_constant<int, 0x141>{});    // row_half_mirror: lane i <-> 7 - i within each 8
+    return v;
+}
 __device__ __forceinline__ float wsum64(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -565,8 +575,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                 const float* wl0 = s_w0 + o * kSmallCin;
                 const float* wr0 = s_w0 + HP * kSmallCin + o * kSmallCin;
                 float s = v[q4];
+                if (a.c_in <= 2) {   // the model's raw features [degree, is_terminal]: the remaining packed weights are zero
+                    s += wl0[0] * f[0] + wr0[0] * f[8];
+                    s += wl0[1] * f[1] + wr0[1] * f[9];
+                } else {
 #pragma unroll
-                for (int qq = 0; qq < kSmallCin; ++qq) s += wl0[qq] * f[qq] + wr0[qq] * f[8 + qq];
+                    for (int qq = 0; qq < kSmallCin; ++qq) s += wl0[qq] * f[qq] + wr0[qq] * f[8 + qq];
+                }
                 v[q4] = rvalid ? fmaxf(s, 0.f) : 0.f;
             }
             xs[t] = v;
@@ -574,11 +589,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
 #pragma unroll
         for (int t = 0; t < NT; ++t) xr[4 * t] = xs[t];
-        if (rvalid && (a.need_backward || a.acts_layer < 0 || a.acts_layer == 0)) {
-            f32x4* yo = reinterpret_cast<f32x4*>(a.acts + (size_t)grow * HP) + g;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) yo[4 * t] = xs[t];
-        }
+        // (layer 0's rows go to global memory with the first hidden layer's fillers, like every other layer's: a store
+        // here would be waited for at the barrier below)
     }
     __syncthreads();   // xbuf + half B visible; half A (scratch) free
 
@@ -628,7 +640,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(xs, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
         const __amdgpu_buffer_rsrc_t yprev = slab_rsrc(a.acts + slab * (l - 1));
-        const unsigned yprev_off = l > 1 ? acts_off(l - 1) : kOob;     // layer 0's rows were stored by the first-layer code
+        const unsigned yprev_off = acts_off(l - 1);
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             if (fastg) gather_gap<NT, Q, kGaps, MATH>(xbuf, nbr, ag, tb);
@@ -711,8 +723,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         lds_barrier();     // barrier 2: new rows + half B = W_r(l+1) visible; half A free
         QSTAMP(0, l, 7);
     }
-    if (a.L > 1) {
-        publish_xmax(a.L - 1);
+    {   // the last layer's rows (the only layer when L == 1)
+        if (a.L > 1) publish_xmax(a.L - 1);
         const __amdgpu_buffer_rsrc_t ylast = slab_rsrc(a.acts + slab * (a.L - 1));
         const unsigned ylast_off = acts_off(a.L - 1);
 #pragma unroll
@@ -755,16 +767,17 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         v = wsum64(v);
         if (lane == 0) s_red[wave] = v;
     }
-    // value-MLP weights of this wave's hidden units (k = wave + 8i) -> registers now; the loads fly during pooling
-    constexpr int kKI = 8, kCJ = 8;     // up to 64 hidden units, 4H <= 512 columns
-    float wv[kKI][kCJ];
+    // value-MLP weights -> registers now (the loads fly during pooling): thread (k = tid / 8, part = tid % 8) takes hidden
+    // unit k (up to 64) and the 16-byte column groups part, part + 8, ... of its 4H-wide row (H groups, H <= 112: 14 loads)
+    constexpr int kVQ = 14;
+    const int vk = tid >> 3, vpart = tid & 7;
+    f32x4 wv[kVQ];
+    {
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(a.v0_w + (size_t)vk * H4);
 #pragma unroll
-    for (int i = 0; i < kKI; ++i) {
-        const int k = wave + 8 * i;
-#pragma unroll
-        for (int j = 0; j < kCJ; ++j) {
-            const int c = lane + 64 * j;
-            wv[i][j] = (k < H2 && c < H4) ? a.v0_w[(size_t)k * H4 + c] : 0.f;
+        for (int j = 0; j < kVQ; ++j) {
+            const int q = vpart + 8 * j;
+            wv[j] = (vk < H2 && q < H) ? wrow[q] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     }
     // pooling straight from the LDS rows: column c = tid&127, four row phases
@@ -806,21 +819,18 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     }
     __syncthreads();
     {
-        float pl[kCJ];
+        f32x4 p4 = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int j = 0; j < kCJ; ++j) { const int c = lane + 64 * j; pl[j] = c < H4 ? s_pool[c] : 0.f; }
-#pragma unroll
-        for (int i = 0; i < kKI; ++i) {
-            const int k = wave + 8 * i;
-            float p = 0.f;
-#pragma unroll
-            for (int j = 0; j < kCJ; ++j) p += wv[i][j] * pl[j];     // same column order as the layered kernel
-            p = wsum64(p);
-            if (lane == 0 && k < H2) {
-                const float zz = fmaxf(p + a.v0_b[k], 0.f);
-                s_z[k] = zz;
-                a.z[(size_t)gi * H2 + k] = zz;
-            }
+        for (int j = 0; j < kVQ; ++j) {
+            const int q = vpart + 8 * j;
+            if (q < H) p4 += wv[j] * reinterpret_cast<const f32x4*>(s_pool)[q];
+        }
+        float p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        p = oct_sum(p);          // over the 8 lanes that share the hidden unit
+        if (vpart == 0 && vk < H2) {
+            const float zz = fmaxf(p + a.v0_b[vk], 0.f);
+            s_z[vk] = zz;
+            a.z[(size_t)gi * H2 + vk] = zz;
         }
     }
     __syncthreads();
