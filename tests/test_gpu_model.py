@@ -456,3 +456,35 @@ def test_randomised_configurations():
                 continue
             scale = max(1.0, g_ref[k].abs().max().item())
             assert (g[k].cpu() - g_ref[k]).abs().max().item() < TOL * scale, tag + " " + k
+
+
+def test_full_batch_is_bit_reproducible_and_paths_agree():
+    """The BASELINE batch shape (GNN-L, 256 Hex-11 boards: every CU busy, both waves of every SIMD contending for the MFMA
+    pipe) run repeatedly: Q and every gradient must be bit-identical from run to run (the kernels have no float atomics and
+    a timing-dependent hazard between MFMAs and the fillers issued around them would show up here first), and the fused
+    kernels must agree with the layer-major kernels, which share no code with the filler structure."""
+    from gnn_hex_amd import ops
+    if not ops._FUSED_ENABLED:
+        pytest.skip("a test of the fused kernels (both arithmetic modes)")
+    hip, _ = make_pair(15, 110, seed=11)
+    x, ei, batch, ptr = batch_tensors("D1", [11] * 256, maker=True)
+    sel, tgt = sel_and_targets(ptr)
+    args = [t.cuda() for t in (x, ei, batch, ptr, sel, tgt)]
+    q0, g0 = _step(hip, *args)
+    for _ in range(12):
+        q, g = _step(hip, *args)
+        assert torch.equal(q, q0)
+        for k in g0:
+            assert (g[k] is None) == (g0[k] is None)
+            if g0[k] is not None:
+                assert torch.equal(g[k], g0[k]), k
+    ops.set_fused(False)
+    try:
+        ql, gl = _step(hip, *args)
+    finally:
+        ops.set_fused(True)
+    assert (ql - q0).abs().max().item() < TOL
+    for k in g0:
+        if g0[k] is not None:
+            scale = max(1.0, g0[k].abs().max().item())
+            assert (gl[k] - g0[k]).abs().max().item() < TOL * scale, k
