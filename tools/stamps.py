@@ -6,8 +6,8 @@
     make -C gnn_hex_amd/csrc clean && make -C gnn_hex_amd/csrc      # back to the shipped build
 
 Workgroup 0 records s_memtime at fixed points of every layer (QSTAMP in qnet_fused_kernels.h); this script runs
-one GNN-L Hex-11 B=256 forward + backward, reads the stamps and prints, per kernel, the phase durations averaged over
-the hidden layers for the two wave groups that share SIMDs (waves 0-3 / 4-7), in microseconds.
+one GNN-L Hex-11 B=256 forward + backward, reads the stamps and prints, per kernel, for every wave the time of each
+stamp point, averaged over the hidden layers, in s_memtime ticks from the layer's start (about 2.29 ticks per ns).
 """
 import ctypes as C
 import os
@@ -24,7 +24,8 @@ from gnn_hex_amd import _lib  # noqa: E402
 from gnn_hex_amd import ops as hexops  # noqa: E402
 
 KMAXL, POINTS = 64, 10
-NAMES = ["top", "gather", "M1", "pre-b1", "b1", "M2", "epilogue", "b2", "loads-out", "reads-in"]
+NAMES = {0: "layer top", 1: "phase S done", 3: "before barrier 1", 4: "barrier 1", 5: "phase A MFMAs done", 6: "rows published",
+         7: "barrier 2"}
 
 
 def main():
@@ -67,9 +68,9 @@ def main():
         lay_span = np.array([st[k][l, 7].max() - st[k][l, 0].min() for l in layers])
         print("   per-layer span (ticks): mean %.0f  min %.0f  max %.0f" % (lay_span.mean(), lay_span.min(), lay_span.max()))
         mean = a.mean(0)                # [point][wave]
-        print("   point      " + "  ".join("w%d    " % w for w in range(8)))
-        for p in [0, 8, 9, 1, 2, 3, 4, 5, 6, 7]:
-            print("   %-9s " % NAMES[p] + "  ".join("%6.0f" % mean[p, w] for w in range(8)))
+        print("   point                 " + "  ".join("w%d    " % w for w in range(8)))
+        for p in sorted(NAMES):
+            print("   %-20s " % NAMES[p] + "  ".join("%6.0f" % mean[p, w] for w in range(8)))
         if k == 0:
             print("   prologue %.0f ticks, tail %.0f ticks" % (s[0, 1].max() - t0, end - s[L - 1, 7].max()))
         else:
