@@ -59,6 +59,43 @@ def test_lockstep_random_play_bit_exact(hexref, size, num_envs, steps):
     assert finished > 0
 
 
+@pytest.mark.parametrize("size,num_envs,steps", [(11, 128, 70), (7, 128, 40), (11, 1024, 45)])
+def test_lockstep_at_benchmark_env_counts(hexref, size, num_envs, steps):
+    """The env counts of BASELINE.json configs 2-4 (parallel_envs = 128 and 1024): every env's adjacency bit matrix,
+    alive set, side and move count bit-exact against the oracle after every step; rewards / dones / episode metrics
+    equal; the BATCHED observation (x, edge_index, backmap, ptr) bit-exact against the collated oracle observations."""
+    from gnn_hex_amd.data import Batch
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    mgr = Env_manager(num_envs, size, gamma=0.97)
+    ref = hexref.RefEnvManager(num_envs, size, gamma=0.97)
+    mgr.reset()
+    ref.reset()
+    rng = np.random.default_rng(1000 * size + num_envs)
+    finished = 0
+    for t in range(steps):
+        rvalid = ref.get_valid_actions()
+        acts = [int(v[rng.integers(len(v))]) for v in rvalid]
+        obs, rew, done, infos = mgr.step(acts)
+        robs, rrew, rdone, rinfos = ref.step(acts)
+        assert np.array_equal(rew, rrew) and np.array_equal(done, rdone)
+        assert mgr.global_onturn == ref.global_onturn
+        st = mgr._state()
+        for i in range(num_envs):
+            _assert_env_equals_oracle(st, i, ref.envs[i])
+            if done[i]:
+                finished += 1
+                for k in ("return", "discounted_return", "length"):
+                    assert infos[i]["episode_metrics"][k] == rinfos[i]["episode_metrics"][k]
+        b = Batch.from_data_list(obs)
+        offs = np.cumsum([0] + [o.x.shape[0] for o in robs])
+        assert np.array_equal(b.ptr.cpu().numpy(), offs)
+        assert np.array_equal(b.x.cpu().numpy(), np.concatenate([o.x for o in robs], 0))
+        assert np.array_equal(b.edge_index.cpu().numpy(),
+                              np.concatenate([o.edge_index + int(off) for o, off in zip(robs, offs[:-1])], 1))
+        assert np.array_equal(obs.backmap.cpu().numpy(), np.concatenate([o.backmap for o in robs]))
+    assert finished >= num_envs // 4
+
+
 def test_batched_observation_matches_collation_and_csr(hexref):
     from gnn_hex_amd import ops
     from gnn_hex_amd.data import Batch

@@ -1,0 +1,85 @@
+"""Oracle parity AT THE BENCHMARK SIZES (BASELINE.json configs 2 and 3, B = 256 graphs per step).
+
+The other parity files top out at 32 graphs; here the CPU oracle runs the whole 256-graph batch -- GNN-L Hex-11
+(N = 31 488 for start positions: the weight-gradient GEMM runs its full slice count + slab reduce, every CU holds a
+graph), mid-game Hex-11 boards, GNN-S Hex-7 and the ragged Hex-5..13 batch -- and Q plus every parameter gradient of
+the HIP path are held to the same 1e-4 bar on all arithmetic / kernel paths.  The oracle result is computed once per
+batch and reused across the path fixture.
+"""
+import pytest
+import torch
+
+from helpers import batch_tensors, make_pair, sel_and_targets
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+CASES = {
+    # name: (num_layers, hidden, kind, sizes, maker)
+    "L256-D0": (15, 110, "D0", [11] * 256, True),
+    "L256-D1": (15, 110, "D1", [11] * 256, False),
+    "S256-D1": (10, 35, "D1", [7] * 256, True),
+    "S256-D0": (10, 35, "D0", [7] * 256, False),
+    "MIX256-D1": (15, 110, "D1", [5 + (g % 9) for g in range(256)], True),
+}
+_oracle_cache = {}
+
+
+def _oracle(name):
+    if name not in _oracle_cache:
+        layers, hidden, kind, sizes, maker = CASES[name]
+        _, ref = make_pair(layers, hidden, seed=0, device="cpu")
+        x, ei, batch, ptr = batch_tensors(kind, sizes, maker=maker)
+        sel, tgt = sel_and_targets(ptr)
+        ref.zero_grad(set_to_none=True)
+        q = ref(x, ei, batch, ptr)
+        torch.nn.functional.mse_loss(q[sel], tgt).backward()
+        grads = {k: (None if p.grad is None else p.grad.detach().clone()) for k, p in ref.named_parameters()}
+        _oracle_cache[name] = (ref.state_dict(), (x, ei, batch, ptr, sel, tgt), q.detach(), grads)
+    return _oracle_cache[name]
+
+
+@pytest.fixture(params=[(True, "fp32"), (True, "f16x3"), (False, "fp32")], ids=["fused", "fused-f16x3", "layered"])
+def path(request):
+    from gnn_hex_amd import ops
+    ops.set_fused(request.param[0])
+    ops.set_math(request.param[1])
+    yield request.param
+    ops.set_fused(True)
+    ops.set_math("fp32")
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("hinted", [True, False], ids=["hints", "plain"])
+def test_full_batch_against_oracle(name, hinted, path):
+    """`hinted`: the batch carries the host-known metadata bench.py / the env manager attach (side to move, largest
+    graph, grouped edge list -> one-launch CSR build); `plain`: bare tensors as train.py would hand them over."""
+    from gnn_hex_amd.models import get_pre_defined
+    from helpers import model_args
+    layers, hidden, kind, sizes, maker = CASES[name]
+    if not hinted and path != (True, "fp32"):
+        pytest.skip("the un-hinted entry differs only in host logic: run once")
+    state, (x, ei, batch, ptr, sel, tgt), q_ref, g_ref = _oracle(name)
+    hip = get_pre_defined("modern_two_headed", model_args(layers, hidden))
+    hip.load_state_dict(state)
+    hip = hip.cuda()
+    xd, eid = x.cuda(), ei.cuda()
+    if hinted:
+        xd._hex_is_maker = maker
+        xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())
+        eid._hex_grouped = True
+    q = hip(xd, eid, batch.cuda(), ptr.cuda())
+    torch.nn.functional.mse_loss(q[sel.cuda()], tgt.cuda()).backward()
+    torch.cuda.synchronize()
+    err = (q.detach().cpu() - q_ref).abs().max().item()
+    assert err < TOL, "%s: Q max abs err %g" % (name, err)
+    worst = 0.0
+    for k, p in hip.named_parameters():
+        if g_ref[k] is None:
+            assert p.grad is None, k
+            continue
+        assert p.grad is not None, k
+        gerr = (p.grad.cpu() - g_ref[k]).abs().max().item()
+        worst = max(worst, gerr)
+        assert gerr < TOL * max(1.0, g_ref[k].abs().max().item()), "%s: %s grad max abs err %g" % (name, k, gerr)
+    print("%s %s: Q err %.3g, worst grad err %.3g" % (name, path, err, worst))
