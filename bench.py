@@ -28,6 +28,9 @@ import torch.distributed as dist  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TFLOPS = 157.3
+# useful-FLOP peak of each arithmetic: exact fp32 MFMA; split modes issue 3 (f16x3) f16 MFMAs (2516 TFLOP/s dense) per product
+MFMA_PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2516.6 / 3}
+PROFILE_ROUND = "r02"
 
 CONFIGS = {
     # name: (num_layers, hidden, sizes-per-graph fn, label)
@@ -38,6 +41,11 @@ CONFIGS = {
 
 KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel",
           8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
+
+
+def flops_fwd(n, b, h, layers):
+    """dense FLOPs of one forward (= of one backward data chain, = of the weight-gradient GEMMs)."""
+    return 4.0 * n * 2 * h + (layers + 1) * 4.0 * n * h * h + 2.0 * n * h + 2.0 * b * (4 * h * (h // 2) + h // 2)
 
 
 def bytes_fwd(n, e, c):
@@ -69,12 +77,21 @@ def main():
     ap.add_argument("--no-split", action="store_true", help="skip the informational split-precision timing (clean profiles)")
     args = ap.parse_args()
 
+    ndev = torch.cuda.device_count()       # does not initialise HIP
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # not under a launcher: bring up the N ranks ourselves, as fresh child processes, BEFORE any GPU call
+        # (this process never creates a HIP context; it only waits and passes rank 0's JSON line through)
+        if args.backend == "nccl" and args.gpus > ndev:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible (RCCL needs one GPU per rank; "
+                             "--backend gloo rehearses the multi-rank path on fewer GPUs)" % (args.gpus, ndev))
+        from gnn_hex_amd.dist import launch_ranks
+        raise SystemExit(launch_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
-    ndev = torch.cuda.device_count()
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d but --gpus=%d: refusing to report a line whose n_gpus is not the requested one"
+                         % (world, args.gpus))
     if args.backend == "nccl" and world > ndev:
         raise SystemExit("%d ranks but %d GPUs (RCCL needs one GPU per rank)" % (world, ndev))
     dev = torch.device("cuda", local_rank % max(ndev, 1))
@@ -116,7 +133,7 @@ def main():
                 off += gx.shape[0]; ptrs.append(off)
             x, ei, bv, ptr = (torch.from_numpy(np.concatenate(xs, 0)), torch.from_numpy(np.concatenate(eis, 1)),
                               torch.from_numpy(np.concatenate(bvs)), torch.tensor(ptrs, dtype=torch.long))
-        sel, tgt = sel_and_targets(ptr)
+        sel, tgt = sel_and_targets(ptr, seed=1 + rank)       # every rank regresses on its own targets
         xd = x.to(dev)
         xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
         xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
@@ -165,6 +182,11 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    def note(msg):
+        if rank == 0:
+            print("[bench] " + msg, file=sys.stderr, flush=True)
+
+    note("setup done (%s, %d ranks); warm-up" % (label, world))
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -174,14 +196,34 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
 
+    # N > 1: the replicas must stay identical -- one more step, a plain SGD update from the all-reduced gradients on every
+    # rank, then the parameter checksums of all ranks are compared (a rank that reduced a different bucket would diverge)
+    replicas_identical = None
+    if world > 1:
+        step(0)
+        with torch.no_grad():
+            for p in plist:
+                if p.grad is not None:
+                    p.add_(p.grad, alpha=-1e-3)
+            flat = torch.cat([p.detach().double().reshape(-1) for p in plist])
+            cs = torch.stack([flat.sum(), flat.abs().sum(), (flat * flat).sum()])
+        if args.backend == "gloo":
+            cs = cs.cpu()
+        gathered = [torch.empty_like(cs) for _ in range(world)]
+        dist.all_gather(gathered, cs)
+        replicas_identical = all(torch.equal(g, gathered[0]) for g in gathered)
+        if not replicas_identical:
+            raise SystemExit("rank %d: parameter replicas diverged after the gradient all-reduce: %s" % (rank, gathered))
+
     out = None
     if rank == 0:
+        note("timed region done: %.4f ms/step; per-kernel HIP-event passes" % ms_per_step)
         # ---- live per-kernel timing (HIP events on the launch stream) over the same steps ---------------
         L = _lib.lib()
         per_kernel = {}
@@ -211,10 +253,19 @@ def main():
             flops = 2.0 * n * (2 * hidden) * hidden * hidden_layers / (launches / args.steps)
             roof = dict(bound="mfma", achieved=flops / avg_s / 1e12, peak=MFMA_F32_PEAK_TFLOPS, unit="TFLOP/s")
         roof["frac"] = roof["achieved"] / roof["peak"]
+        # the same launch priced against the OTHER roof as well: the fused kernels keep a graph's rows in LDS, so their HBM
+        # traffic is far below the un-fused algorithmic bytes and the binding roof is the MFMA pipe of the arithmetic in use
+        launch_flops = (flops_fwd(n, B, hidden, num_layers) if dom in (8, 9)
+                        else 2.0 * n * (2 * hidden) * hidden * (hidden_layers / max(launches / args.steps, 1)) if dom == 2
+                        else 4.0 * n * hidden * hidden)
+        mfma_peak = MFMA_PEAK_TFLOPS[args.math]
+        roof["mfma_tflops"] = launch_flops / avg_s / 1e12
+        roof["mfma_peak_tflops"] = mfma_peak
+        roof["mfma_frac"] = roof["mfma_tflops"] / mfma_peak
         # measured HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs,
         # gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), committed under profiles/; same config only
         roof["traffic"] = None
-        tpath = os.path.join(ROOT, "profiles", "r01", "traffic_pmc.json")
+        tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_pmc.json")
         if args.config == "L256" and args.data == "D0" and B == 256 and os.path.exists(tpath):
             mid = 1 if args.math == "f16x3" else 0
             want = {2: "sage_dw16_kernel<" if mid else "sage_dw_kernel<"}.get(dom, "%s<7, %d>" % (KNAMES[dom], mid))
@@ -247,6 +298,7 @@ def main():
 
         cpu = None
         if world == 1 and not args.no_cpu_baseline:      # rank 0 at N=1 only (bench contract)
+            note("CPU baseline sweep (bounded: ~40 s)")
             cpu = cpu_baseline(ref, batches, B)
 
         out = {
@@ -261,6 +313,10 @@ def main():
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * world},
             "roofline": roof, "cpu_baseline": cpu, "split_precision_mode": split,
         }
+        if world > 1:
+            out["replicas_identical"] = replicas_identical
+            out["config"]["collective"] = {"backend": "rccl" if args.backend == "nccl" else "gloo (rehearsal)",
+                                           "bucket_bytes": 4 * sum(p.numel() for p in plist if p.grad is not None)}
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
@@ -329,36 +385,71 @@ def step_local(hip, batches, i):
     hexops.td_loss(q, bt["sel"], bt["tgt"])[0].backward()
 
 
-def cpu_baseline(ref, batches, B):
-    """CPU restatement of the torch_geometric path (oracle/model_ref.py) timed on the host cores of this
-    box, on a bounded sample: the first 32 graphs of the same batch, all torch threads."""
-    import numpy as np
-    sample_graphs = min(32, B)
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(ref, batches, B, total_budget_s=40.0):
+    """CPU restatement of the torch_geometric path (oracle/model_ref.py) timed on the host cores of this box, on the
+    FULL batch of the same workload (same graphs, weights, targets), fwd + bwd, for torch thread counts 1, 8, 16, 32 and
+    all usable cores (SURVEY 8d / BASELINE.md section 3): per thread count 1 warm-up iteration, then the median of up to
+    10 timed iterations inside its share of a ~40 s budget (at least 2; a thread count is skipped once the budget is
+    spent; more threads than 64 are not tried: the GPU boxes expose 256 logical cpus of which a 1-GPU lease owns a
+    16-core share, and 128 oversubscribed threads ran slower than one).  The best thread count is reported; the whole
+    sweep is kept beside it."""
+    import statistics
     x, ei, bv, ptr, sel, tgt = batches[0]["cpu"]
-    n_s = int(ptr[sample_graphs])
-    keep = (ei[0] < n_s) & (ei[1] < n_s)
-    xs, eis, bvs, ptrs = x[:n_s], ei[:, keep], bv[:n_s], ptr[:sample_graphs + 1]
-    sels, tgts = sel[:sample_graphs], tgt[:sample_graphs]
-    threads = torch.get_num_threads()
+    ncpu = os.cpu_count() or 1
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = ncpu
+    saved = torch.get_num_threads()
 
     def one():
         ref.zero_grad(set_to_none=True)
-        q = ref(xs, eis, bvs, ptrs)
-        torch.nn.functional.mse_loss(q[sels], tgts).backward()
+        q = ref(x, ei, bv, ptr)
+        torch.nn.functional.mse_loss(q[sel], tgt).backward()
 
-    one()
-    t0 = time.perf_counter()
-    it = 0
-    while True:
-        one()
-        it += 1
-        el = time.perf_counter() - t0
-        if el > 10.0 or it >= 20:
+    counts = sorted({c for c in (8, 16, 32, 1, min(usable, 64)) if c <= usable}, key=lambda c: (c == 1, c))   # 1 thread last
+    sweep, t_all = {}, time.perf_counter()
+    for k, th in enumerate(counts):
+        left = total_budget_s - (time.perf_counter() - t_all)
+        if left <= 0:
             break
-    return {"value": sample_graphs * it / el, "unit": "graphs/s", "cores": threads, "kind": "port",
-            "sample": "%d iterations of fwd+bwd on the first %d graphs of the same batch (%d nodes), "
-                      "CPU restatement of the torch_geometric path, %d torch threads of %d host cpus"
-                      % (it, sample_graphs, n_s, threads, os.cpu_count())}
+        share = left / (len(counts) - k)
+        torch.set_num_threads(th)
+        t_start = time.perf_counter()
+        one()
+        times = []
+        if time.perf_counter() - t_start > share:        # one iteration already exceeds this count's share: keep it, move on
+            times.append(time.perf_counter() - t_start)
+        while len(times) < 10 and (len(times) < 2 or time.perf_counter() - t_start < share) \
+                and not (times and time.perf_counter() - t_start > share):
+            t0 = time.perf_counter()
+            one()
+            times.append(time.perf_counter() - t0)
+            if len(times) >= 2 and time.perf_counter() - t_all > 2.5 * total_budget_s:
+                break
+        sweep[th] = {"graphs_per_s": B / statistics.median(times), "median_s": statistics.median(times),
+                     "iterations": len(times)}
+        print("[bench] cpu baseline: %d threads %.1f graphs/s (%d iterations)" % (th, sweep[th]["graphs_per_s"], len(times)),
+              file=sys.stderr, flush=True)
+    torch.set_num_threads(saved)
+    best = max(sweep, key=lambda k: sweep[k]["graphs_per_s"])
+    return {"value": sweep[best]["graphs_per_s"], "unit": "graphs/s", "cores": best, "kind": "port",
+            "sample": "median of %d fwd+bwd iterations on the full %d-graph batch of the same workload (%d nodes, %d edges), "
+                      "CPU restatement of the torch_geometric path (oracle/model_ref.py), best of torch threads %s; "
+                      "host: %s, %d cpus (%d usable)"
+                      % (sweep[best]["iterations"], B, int(x.shape[0]), int(ei.shape[1]), sorted(sweep), _cpu_model(),
+                         ncpu, usable),
+            "threads_sweep": {str(k): v for k, v in sweep.items()}}
 
 
 if __name__ == "__main__":

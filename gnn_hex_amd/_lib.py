@@ -15,6 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
 _lib = None
+ABI_VERSION = 2          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
 
 vp = C.c_void_p
 ci = C.c_int
@@ -31,10 +32,10 @@ _SIGS = {
     "hexgnn_graph_ptr": (ci, [ci, ci, vp, vp, vp]),
     "hexgnn_sage_stack_pack_bytes": (sz, [ci, ci, ci]),
     "hexgnn_sage_stack_saved_bytes": (sz, [ci, ci, ci, ci]),
-    "hexgnn_sage_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, vp]),
+    "hexgnn_sage_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
     "hexgnn_sage_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "hexgnn_sage_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
-                                        vp, vp, vp, vp, sz, vp]),
+                                        vp, vp, vp, vp, sz, ci, vp]),
     "hexgnn_head_saved_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),
@@ -90,7 +91,7 @@ def lib():
             fn = getattr(L, name)
             fn.restype = res
             fn.argtypes = args
-        if L.hexgnn_abi_version() != 1:
+        if L.hexgnn_abi_version() != ABI_VERSION:
             raise HexGnnError("libhexgnn.so ABI version mismatch")
         _lib = L
     return _lib

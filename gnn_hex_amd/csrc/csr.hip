@@ -208,6 +208,8 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
             if (i <= cnt) s_start[t][i] = run;
             run += local[k];
         }
+        // entry [cnt] of a graph with exactly kCsrMaxGraph nodes lies past the last scanned index: the block total
+        if (tid == 255) s_start[t][cnt] = s_part[t][255];
     }
     __syncthreads();
     for (int i = tid; i < cnt; i += 256) {

@@ -34,8 +34,9 @@ struct Env {   // host handle
     void* blob;
 };
 
-// WT = compile-time number of 64-bit words per vertex set.  WT < WT instantiations assume Wr() == WT (register-resident
-// sets, fully unrolled); WT == WT is the generic fallback with a runtime Wr().
+// WT = compile-time number of 64-bit words per vertex set.  WT < kMaxW instantiations are launched only for boards with
+// exactly W == WT words (hexgnn_env_step's switch), so Wr() is the constant WT there (register-resident sets, row strides
+// and word loops fully unrolled); WT == kMaxW is the generic fallback with the runtime W.
 template <int WT> struct SetsT { uint64_t w[WT]; };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -48,7 +49,7 @@ struct GameT {
     uint8_t* alive;    // LDS [nv]
     uint64_t* scr;     // LDS scratch [4][kMaxW]
     int nv, W, K, lane;
-    __device__ __forceinline__ int Wr() const { if constexpr (WT == WT) return W; else return WT; }
+    __device__ __forceinline__ int Wr() const { if constexpr (WT == kMaxW) return W; else return WT; }
     bool maker_won;
 
     __device__ __forceinline__ uint64_t* row(int v) const { return adj + v * Wr(); }

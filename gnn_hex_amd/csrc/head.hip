@@ -87,8 +87,9 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
         const float t = 2.f * tanhf(a);
         tsum += t;
         if (mode == 2) q[row] = t;
+        if (mode >= 3) q[row] = a;          // raw advantages (HeadNetwork.forward)
     }
-    if (mode == 2) return;
+    if (mode == 2 || mode == 4) return;
     const float adv_total = block_sum_256(tsum, s_red);
 
     // 2. pooling: column c = tid & 127, two row phases (even / odd rows), first-index ties
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
         if (lane == 0) {
             const float v = p + v1_b[0];
             vraw[g] = v;
-            s_v = tanhf(v);
+            s_v = mode == 3 ? v : tanhf(v);
         }
     }
     __syncthreads();
@@ -150,7 +151,8 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     // 4. dueling combine (each thread re-reads the adv_raw it wrote itself)
     const float mean_adv = adv_total / (float)max(cnt, 1);
     const float V = s_v;
-    if (mode == 1 && tid == 0) out_v[g] = V;
+    if ((mode == 1 || mode == 3) && tid == 0) out_v[g] = V;
+    if (mode == 3) return;
     for (int row = r0 + tid; row < r1; row += 256) {
         const float t = 2.f * tanhf(adv_raw[row]);
         q[row] = (mode == 0 ? V : 0.f) + t - mean_adv;
@@ -178,14 +180,15 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float w1 = lane + 64 < H ? lin_w[lane + 64] : 0.f;
 
     float mean_dq = 0.f, inv_cnt = 1.f / (float)max(cnt, 1);
-    if (mode != 2) {
+    const bool has_value = mode != 2 && mode != 4, raw = mode >= 3;
+    if (has_value) {
         float ps = 0.f;
         for (int row = r0 + tid; row < r1; row += 256) ps += dq[row];
         const float sdq = block_sum_256(ps, s_red);
-        mean_dq = sdq * inv_cnt;
+        mean_dq = raw ? 0.f : sdq * inv_cnt;
         if (tid < H) { s_ax[tid] = amax[(size_t)g * H + tid]; s_an[tid] = amin[(size_t)g * H + tid]; }
         const float dV = mode == 0 ? sdq : d_out_v[g];
-        const float dv = dV * sech2f(vraw[g]);
+        const float dv = raw ? dV : dV * sech2f(vraw[g]);
         if (tid == 0) dvr[g] = dv;
         if (tid < H2) {
             const float zz = z[(size_t)g * H2 + tid];
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     }
     // per-row advantage gradient: thread per row
     for (int row = r0 + tid; row < r1; row += 256) {
-        const float dar = (dq[row] - mean_dq) * 2.f * sech2f(adv_raw[row]);
+        const float dar = raw ? dq[row] : (dq[row] - mean_dq) * 2.f * sech2f(adv_raw[row]);
         dadv[row] = dar;
         if (row - r0 < 1024) s_dar[row - r0] = dar;
     }
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
                 float v = 0.f;
                 if (c < H) {
                     v = dar * (half ? w1 : w0);
-                    if (mode != 2) {
+                    if (has_value) {
                         v += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
                         if (s_ax[c] == row) v += s_dp[H + c];
                         if (s_an[c] == row) v += s_dp[2 * H + c];
@@ -297,7 +300,7 @@ int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const 
                             const float* z, const float* lin_part, float* d_lin_w, float* d_lin_b, float* d_v0_w,
                             float* d_v0_b, float* d_v1_w, float* d_v1_b, hipStream_t st) {
     const int hp = padded_width(hidden), H2 = hidden / 2, H4 = 4 * hidden;
-    if (mode != 2 && H2 > 0)
+    if (mode != 2 && mode != 4 && H2 > 0)
         head_value_wgrad_kernel<<<dim3((H4 + 63) / 64, H2), 256, 0, st>>>(b, hidden, dz, dvr, pooled, z, d_v0_w, d_v0_b,
                                                                           d_v1_w, d_v1_b);
     head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, lin_part, d_lin_w, d_lin_b);
@@ -333,22 +336,41 @@ __global__ __launch_bounds__(256) void td_loss_fwd_kernel(int n, int k, const fl
     if (threadIdx.x == 0) loss[0] = red[0] / (float)(k > 0 ? k : 1);
 }
 
-// One launch: every workgroup clears its 1024-entry range of dq, then adds the selected nodes that fall into it (the
-// zeroing memset used to be a launch of its own).
+// One launch: every workgroup clears its 1024-entry range of dq, then accumulates the selected nodes that fall into it
+// (the zeroing memset used to be a launch of its own).  No float atomics: of the entries naming the same node, the FIRST
+// one sums all of them in list order and stores once, so duplicated selections (PER samples with replacement) give a
+// bit-reproducible gradient.  The pairwise scan runs over the <= 1024 entries staged in LDS per chunk.
 __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const int64_t* __restrict__ sel,
                                                          const float* __restrict__ td, const float* __restrict__ w,
                                                          int loss_fn, const float* __restrict__ gloss,
                                                          float* __restrict__ dq) {
+    __shared__ int s_i[1024];
+    __shared__ float s_g[1024];
     const int lo = blockIdx.x * 1024, hi = min(lo + 1024, n);
     for (int i = lo + threadIdx.x; i < hi; i += 256) dq[i] = 0.f;
-    __syncthreads();
     const float gl = gloss[0] / (float)k;
-    for (int j = threadIdx.x; j < k; j += 256) {
-        const int64_t i = sel[j];
-        if (i < lo || i >= hi) continue;
-        const float d = td[j];
-        const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
-        atomicAdd(dq + i, gl * (w ? w[j] : 1.f) * dl);   // one add per selected node (duplicates: two adds commute)
+    for (int c0 = 0; c0 < k; c0 += 1024) {
+        const int kk = min(1024, k - c0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < kk; j += 256) {
+            const int64_t i = sel[c0 + j];
+            const bool mine = i >= lo && i < hi;
+            const float d = td[c0 + j];
+            const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
+            s_i[j] = mine ? (int)i : -1;
+            s_g[j] = gl * (w ? w[c0 + j] : 1.f) * dl;
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kk; j += 256) {
+            const int i = s_i[j];
+            if (i < 0) continue;
+            bool first = true;
+            for (int q = 0; q < j && first; ++q) first = s_i[q] != i;
+            if (!first) continue;
+            float acc = s_g[j];
+            for (int q = j + 1; q < kk; ++q) if (s_i[q] == i) acc += s_g[q];
+            dq[i] += acc;          // only this thread touches dq[i] in this chunk; chunks are separated by the barrier
+        }
     }
 }
 
@@ -432,10 +454,10 @@ int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, con
                         const float* v1_b, float* q, float* out_v, void* saved, hexgnn_stream_t stream_) {
     const int hp = padded_width(hidden);
     if (hp < 0 || hidden < 2) return HEXGNN_EUNSUPPORTED;
-    if (n < 0 || b < 0 || mode < 0 || mode > 2) return HEXGNN_EINVAL;
+    if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
     if (!gptr || !lin_w || !lin_b || !saved) return HEXGNN_EINVAL;
-    if (mode != 2 && (!v0_w || !v0_b || !v1_w || !v1_b)) return HEXGNN_EINVAL;
-    if (mode == 1 && !out_v) return HEXGNN_EINVAL;
+    if (mode != 2 && mode != 4 && (!v0_w || !v0_b || !v1_w || !v1_b)) return HEXGNN_EINVAL;
+    if ((mode == 1 || mode == 3) && !out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!h || !q)) return HEXGNN_EINVAL;
     if (b == 0) return HEXGNN_OK;
     const HeadSaved s = head_saved_plan(n, b, hidden);
@@ -461,10 +483,10 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
     hipStream_t st = (hipStream_t)stream_;
     const int hp = padded_width(hidden);
     if (hp < 0 || hidden < 2) return HEXGNN_EUNSUPPORTED;
-    if (n < 0 || b < 0 || mode < 0 || mode > 2) return HEXGNN_EINVAL;
+    if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
     if (!gptr || !lin_w || !saved || !d_lin_w || !d_lin_b) return HEXGNN_EINVAL;
-    if (mode != 2 && (!v0_w || !v1_w || !d_v0_w || !d_v0_b || !d_v1_w || !d_v1_b)) return HEXGNN_EINVAL;
-    if (mode == 1 && !d_out_v) return HEXGNN_EINVAL;
+    if (mode != 2 && mode != 4 && (!v0_w || !v1_w || !d_v0_w || !d_v0_b || !d_v1_w || !d_v1_b)) return HEXGNN_EINVAL;
+    if ((mode == 1 || mode == 3) && !d_out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!h || !dq || !dh)) return HEXGNN_EINVAL;
     const HeadWs w = head_ws_plan(n, b, hidden);
     if (!workspace || workspace_bytes < w.total) return HEXGNN_EWORKSPACE;

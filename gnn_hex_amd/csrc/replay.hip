@@ -12,21 +12,36 @@
 
 namespace hexgnn {
 
-// set leaves then rebuild the touched ancestors level by level; one workgroup (updates per call <= a few thousand)
+// set leaves then rebuild the touched ancestors level by level; one workgroup (updates per call <= a few thousand).
+// A slot listed more than once (PER samples with replacement, so update_priorities sees duplicates) takes the priority of
+// its LAST occurrence, as a sequential loop would: an occurrence writes only if no later entry names the same slot
+// (pairwise scan of the list in LDS; the host entry point feeds at most 2048 entries per launch), so sum and min tree
+// always agree.
 __global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const int* __restrict__ idx,
                                                          const double* __restrict__ prio_alpha,
                                                          double* __restrict__ sum_tree, double* __restrict__ min_tree) {
+    __shared__ int s_idx[2048];
+    const bool in_lds = k <= 2048;
+    if (in_lds) {
+        for (int i = threadIdx.x; i < k; i += 1024) s_idx[i] = idx[i];
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < k; i += 1024) {
-        if (idx[i] < 0 || idx[i] >= cap) continue;          // out-of-range slots are ignored
-        const int leaf = cap + idx[i];
+        const int slot = in_lds ? s_idx[i] : idx[i];
+        if (slot < 0 || slot >= cap) continue;               // out-of-range slots are ignored
+        bool last = true;
+        for (int j = i + 1; j < k && last; ++j) last = (in_lds ? s_idx[j] : idx[j]) != slot;
+        if (!last) continue;
+        const int leaf = cap + slot;
         sum_tree[leaf] = prio_alpha[i];
         min_tree[leaf] = prio_alpha[i];
     }
     __syncthreads();
     for (int width = cap >> 1, shift = 1; width >= 1; width >>= 1, ++shift) {
         for (int i = threadIdx.x; i < k; i += 1024) {
-            if (idx[i] < 0 || idx[i] >= cap) continue;
-            const int node = (cap + idx[i]) >> shift;       // duplicates recompute the same value
+            const int slot = in_lds ? s_idx[i] : idx[i];
+            if (slot < 0 || slot >= cap) continue;
+            const int node = (cap + slot) >> shift;         // duplicates recompute the same value
             const double l = sum_tree[2 * node], r = sum_tree[2 * node + 1];
             sum_tree[node] = l + r;
             const double ml = min_tree[2 * node], mr = min_tree[2 * node + 1];
@@ -82,7 +97,12 @@ int hexgnn_per_update(int capacity_pow2, int k, const int* idx, const double* pr
     if (capacity_pow2 < 1 || (capacity_pow2 & (capacity_pow2 - 1)) || k < 0 || !sum_tree || !min_tree) return HEXGNN_EINVAL;
     if (k == 0) return HEXGNN_OK;
     if (!idx || !prio_alpha) return HEXGNN_EINVAL;
-    per_update_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(capacity_pow2, k, idx, prio_alpha, sum_tree, min_tree);
+    // chunks of <= 2048 entries in list order: the duplicate scan stays in LDS, and a slot repeated across chunks still ends
+    // with its last occurrence (stream order)
+    for (int o = 0; o < k; o += 2048) {
+        const int kk = k - o < 2048 ? k - o : 2048;
+        per_update_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(capacity_pow2, kk, idx + o, prio_alpha + o, sum_tree, min_tree);
+    }
     return check_launch();
 }
 

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void sage_first_fwd_kernel(
     int n, int c_in, int hp, const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ invdeg, const float* __restrict__ x, int x_stride,
     const float* __restrict__ w0 /*[hp][8] Wl then [hp][8] Wr*/, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ agg_out /*[n][8] or null*/) {
+    float* __restrict__ y, float* __restrict__ agg_out /*[n][8] or null*/, int relu) {
     __shared__ float sA[32][kSmallCin], sX[32][kSmallCin];
     __shared__ float sW[2 * 128 * kSmallCin + 128];
     const int tid = threadIdx.x;
@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256) void sage_first_fwd_kernel(
         float v = sB[c];
 #pragma unroll
         for (int q = 0; q < kSmallCin; ++q) v += sWl[c * kSmallCin + q] * sA[r][q] + sWr[c * kSmallCin + q] * sX[r][q];
-        y[(size_t)row * hp + c] = v > 0.f ? v : 0.f;
+        y[(size_t)row * hp + c] = (v > 0.f || !relu) ? v : 0.f;
     }
 }
 
@@ -272,7 +272,7 @@ template <int NT>
 __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
     int n, const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ invdeg,
     const float* __restrict__ x, const f32x4* __restrict__ wpack, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ agg_out) {
+    float* __restrict__ y, float* __restrict__ agg_out, int relu) {
     constexpr int HP = 16 * NT;
     extern __shared__ f32x4 wlds[];  // [2NT][NT][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
         for (int t = 0; t < NT; ++t) {
             f32x4 v = acc[t] + br[4 * t];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+            for (int q = 0; q < 4; ++q) v[q] = (v[q] > 0.f || !relu) ? v[q] : 0.f;
             yr[4 * t] = v;
         }
     }
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
     int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t, const float* __restrict__ invdeg,
     const float* __restrict__ dxs_in, const float* __restrict__ dagg_in /*null: dxs_in is dY*/,
     const float* __restrict__ y, const f32x4* __restrict__ wpackb,
-    float* __restrict__ g_out, float* __restrict__ dagg_out, float* __restrict__ dxs_out) {
+    float* __restrict__ g_out, float* __restrict__ dagg_out, float* __restrict__ dxs_out, int relu) {
     constexpr int HP = 16 * NT;
     extern __shared__ f32x4 wlds[];  // [2][NT][NT][64]: W_l part, W_r part
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
         for (int c = 0; c < NT; ++c) {
             const f32x4 yv = yr[4 * c];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) gx[c][j] = yv[j] > 0.f ? gx[c][j] : 0.f;
+            for (int j = 0; j < 4; ++j) gx[c][j] = (yv[j] > 0.f || !relu) ? gx[c][j] : 0.f;
             go[4 * c] = gx[c];
         }
     }
@@ -792,7 +792,7 @@ __global__ __launch_bounds__(64) void sage_first_dw_reduce_kernel(
 // ---- host-side dispatch ---------------------------------------------------------------------------------
 template <int NT>
 static void launch_fwd(int n, const int* rowptr, const int* col, const float* invdeg, const float* x,
-                       const void* wp, const float* bias, float* y, float* agg, hipStream_t st) {
+                       const void* wp, const float* bias, float* y, float* agg, int relu, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_fwd_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
@@ -801,13 +801,13 @@ static void launch_fwd(int n, const int* rowptr, const int* col, const float* in
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
     sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
-        n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg);
+        n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg, relu);
 }
 
 template <int NT>
 static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float* invdeg, const float* dxs_in,
                        const float* dagg_in, const float* y, const void* wpb, float* g_out, float* dagg_out,
-                       float* dxs_out, hipStream_t st) {
+                       float* dxs_out, int relu, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_bwd_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
@@ -816,7 +816,7 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
     sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
-        n, rowptr_t, col_t, invdeg, dxs_in, dagg_in, y, (const f32x4*)wpb, g_out, dagg_out, dxs_out);
+        n, rowptr_t, col_t, invdeg, dxs_in, dagg_in, y, (const f32x4*)wpb, g_out, dagg_out, dxs_out, relu);
 }
 
 template <int NT>
@@ -844,17 +844,26 @@ static void launch_dw16(const Dw16Args& a, int layers, float* part, hipStream_t 
         default: return HEXGNN_EUNSUPPORTED;       \
     }
 
-// Row slices per layer of the batched weight-gradient GEMM.  Exact fp32 (MFMA-bound, one workgroup per CU): ~1024-row
-// slices, two rounds of workgroups overlap each other's staging.  Split f16 (HBM-bound): (slices x hidden layers) fills the
-// 256 CUs in ONE round and halves the slab traffic of the reduce.  The plan sizes its workspace for the larger count.
-static int dw_slices_fp32(int n) {
-    int s = (n + 1023) / 1024;
-    if (s < 1) s = 1;
+// Row slices per layer of the batched weight-gradient GEMM.  Exact fp32 (MFMA-bound; two 8-wave workgroups are resident
+// per CU): slices of at most ~1024 rows, their number chosen so that (slices x hidden layers) fills a whole number of
+// rounds of the 512 resident workgroups -- otherwise the CUs that draw a workgroup of the last, partial round set the
+// kernel time (a 256-graph batch of mid-game boards, N = 19 938: 20 x 16 = 320 workgroups took as long as the 496 of the
+// start-position batch; 32 x 16 = 512 do not).  Slices stay >= 256 rows.  Split f16 (HBM-bound): (slices x hidden layers)
+// fills the 256 CUs in ONE round and halves the slab traffic of the reduce.  The plan sizes its workspace for the larger.
+static int dw_slices_fp32(int n, int hidden_layers) {
+    const int nh = hidden_layers > 0 ? hidden_layers : 1;
+    int base = (n + 1023) / 1024;
+    if (base < 1) base = 1;
+    constexpr int kSlots = 512;
+    const int rounds = (base * nh + kSlots - 1) / kSlots;
+    int s = rounds * kSlots / nh;
+    if (s > n / 256) s = n / 256;
+    if (s < base) s = base;
     if (s > 64) s = 64;
     return s;
 }
 int dw_slices_for(int n, int hidden_layers, int math) {
-    const int s0 = dw_slices_fp32(n);
+    const int s0 = dw_slices_fp32(n, hidden_layers);
     if (math != 1) return s0;
     int s = 256 / (hidden_layers > 0 ? hidden_layers : 1);
     if (s > n / 256) s = n / 256;
@@ -872,7 +881,7 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     size_t off = 0;
     b->g_off = off; off += slab * p.L;
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { b->pair_off[i][j] = off; off += slab; }
-    b->S = dw_slices_fp32(n);
+    b->S = dw_slices_fp32(n, p.L - (p.small_first ? 1 : 0));
     b->rps = dw_rows_per_slice(n, b->S);
     b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * b->S * p.hp * (2 * p.hp + 1), 256);
     b->rps0 = 128;
@@ -971,10 +980,10 @@ size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers
 int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
                               const float* invdeg, const float* x, int x_stride, const float* const* wl,
                               const float* const* bl, const float* const* wr, void* wpack, float* acts,
-                              void* saved, int need_backward, hexgnn_stream_t stream_) {
+                              void* saved, int need_backward, int flags, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
-    if (n < 0) return HEXGNN_EINVAL;
+    if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
@@ -993,13 +1002,14 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
         float* y = acts + slab * l;
         const float* bias = (const float*)(wp + p.bias_off[l]);
         float* agg = need_backward ? (float*)(sv + p.agg_off[l]) : nullptr;
+        const int relu = !(l == p.L - 1 && (flags & HEXGNN_SAGE_LINEAR_LAST));
         if (l == 0 && p.small_first) {
             KernelTimer kt(HEXGNN_K_SAGE_FIRST, st);
             sage_first_fwd_kernel<<<(n + 31) / 32, 256, 0, st>>>(n, c_in, p.hp, rowptr, col, invdeg, x, x_stride,
-                                                              (const float*)(wp + p.fwd_off[0]), bias, y, agg);
+                                                              (const float*)(wp + p.fwd_off[0]), bias, y, agg, relu);
         } else {
             const float* xin = l == 0 ? x : acts + slab * (l - 1);
-            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, st)));
+            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, relu, st)));
         }
     }
     return check_launch();
@@ -1017,12 +1027,12 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
                                const int* rowptr_t, const int* col_t, const float* invdeg, const float* x,
                                int x_stride, const float* acts, const void* saved, const void* wpack,
                                const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
-                               float* const* d_wr, void* workspace, size_t workspace_bytes,
+                               float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
                                hexgnn_stream_t stream_) {
     (void)rowptr; (void)col;
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
-    if (n < 0) return HEXGNN_EINVAL;
+    if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     BwdPlan b;
@@ -1059,8 +1069,9 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
     const float* in_dagg = nullptr;
     for (int l = p.L - 1; l >= first_hidden; --l) {
         const float* y = acts + slab * l;
+        const int relu = !(l == p.L - 1 && (flags & HEXGNN_SAGE_LINEAR_LAST));
         HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, in_dxs, in_dagg, y, wp + p.bwd_off[l],
-                                                G + slab * l, pair[cur][0], pair[cur][1], st)));
+                                                G + slab * l, pair[cur][0], pair[cur][1], relu, st)));
         in_dagg = pair[cur][0];
         in_dxs = pair[cur][1];
         cur ^= 1;
@@ -1070,7 +1081,8 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
     if (p.small_first) {
         // G_0 = (dXs_1 + gather dAggS_1) * [y_0 > 0]   (or dy * mask when the stack is a single raw layer)
         KernelTimer kt(HEXGNN_K_COMBINE, st);
-        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, acts, G);
+        const bool relu0 = !(p.L == 1 && (flags & HEXGNN_SAGE_LINEAR_LAST));
+        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, relu0 ? acts : nullptr, G);
     } else if (dx) {
         KernelTimer kt(HEXGNN_K_COMBINE, st);
         sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, nullptr, dx);

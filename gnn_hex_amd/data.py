@@ -92,6 +92,7 @@ class Batch(Data):
         if len(sides) == 1 and None not in sides:
             out.x._hex_is_maker = sides.pop()
         out.x._hex_max_nodes = max(sizes)
+        out.x._hex_hint_version = out.x._version
         out.edge_index._hex_grouped = True      # collated graph by graph: the one-launch CSR build applies
         return out
 

@@ -18,16 +18,18 @@ import torch.distributed as dist
 class GradSync:
     """Flatten -> all_reduce(SUM) -> scale -> unflatten, over the parameters that received a gradient.
 
-    Parameters whose ``.grad`` is None on this step (e.g. the head of the side not to move) contribute
-    zeros and keep ``.grad is None`` only if no rank produced a gradient for them -- every rank must
-    therefore process the same side per step (Env_manager keeps all envs on one side, and the replay
-    shards are sampled per side), which makes the participating set identical on all ranks."""
+    The bucket holds ONLY the parameters whose ``.grad`` is not None on this step (the head of the side
+    not to move stays out and keeps ``.grad is None``).  Every rank must therefore train the same side and
+    mode per step -- Env_manager keeps all envs on one side and the replay shards are sampled per side --
+    so that the participating set is identical on all ranks; ``check=True`` verifies that with one small
+    extra collective per step and raises on a mismatch instead of reducing mismatched buckets."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
-                 average: bool = True):
+                 average: bool = True, check: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.average = average
+        self.check = check
         self._flat: Optional[torch.Tensor] = None
         self._key = None
 
@@ -67,11 +69,11 @@ class GradSync:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
             return sum(p.numel() for p in active)
+        if self.check:
+            self._check_same_set(active, world)
         flat = self._adopt_flat(active)
         if flat is not None:            # zero-copy: one collective on the buffer the backward wrote
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.average:
-                flat.mul_(1.0 / world)
+            self._reduce(flat, world)
             return flat.numel()
         flat = self._bucket(active)
         off = 0
@@ -81,11 +83,86 @@ class GradSync:
             views.append(v)
             off += p.numel()
         torch._foreach_copy_(views, [p.grad for p in active])
+        self._reduce(flat, world)
+        torch._foreach_copy_([p.grad for p in active], views)
+        return off
+
+    def _reduce(self, flat: torch.Tensor, world: int) -> None:
+        """SUM all-reduce (+ 1/world) of one flat fp32 buffer, in place.  RCCL takes the device buffer as it is; the gloo
+        backend (CPU tests, and rehearsals of more ranks than GPUs) is given a host copy of a device buffer."""
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            host = flat.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            if self.average:
+                host.mul_(1.0 / world)
+            flat.copy_(host)
+            return
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
         if self.average:
             flat.mul_(1.0 / world)
-        torch._foreach_copy_([p.grad for p in active], views)
-        return off
+
+    def _check_same_set(self, active: List[torch.nn.Parameter], world: int) -> None:
+        """``check=True``: one tiny extra collective per step that verifies every rank reduces the SAME parameter set
+        (same side to move, same mode) before the gradient bucket goes out; a mismatch would otherwise mix the maker and
+        the breaker head's gradients (equal sizes) or hang on unequal counts."""
+        index = {id(p): i for i, p in enumerate(self.params)}
+        sig = 0
+        for p in active:
+            sig = (sig * 1000003 + index[id(p)] + 1) % 2147483629
+        t = torch.tensor([sig, -sig, len(active), -len(active)], dtype=torch.int64)      # MAX of (v, -v): equal iff all equal
+        if dist.get_backend(self.group) != "gloo":
+            t = t.to(active[0].device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        t = t.cpu()
+        if int(t[0]) != -int(t[1]) or int(t[2]) != -int(t[3]):
+            raise RuntimeError("GradSync: the ranks hold gradients for different parameter sets this step (every rank "
+                               "must train the same side / mode per step)")
+
+
+def launch_ranks(argv: List[str], world: int, timeout_s: Optional[float] = None) -> int:
+    """Start ``world`` copies of ``argv`` (one process per GPU; RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR /
+    MASTER_PORT in their environment, rendezvous on 127.0.0.1) and wait for them.  The caller must NOT have touched the
+    GPU: the ranks are fresh child processes (no exec of a process that holds a HIP context).  Rank 0 inherits stdout
+    (it prints the result line), every rank inherits stderr.  If a rank fails, the others are terminated by PID and the
+    failing exit code is returned."""
+    import os
+    import socket
+    import subprocess
+    import time
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on this driver
+        procs.append(subprocess.Popen(argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    t0 = time.monotonic()
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.05)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+        if rc != 0 or (timeout_s is not None and time.monotonic() - t0 > timeout_s):
+            if rc == 0:
+                rc = 124
+            for p in live:
+                p.terminate()
+            for p in live:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+            break
+    return rc
 
 
 def shard_range(total: int, rank: int, world: int):

@@ -7,13 +7,17 @@ Same module tree, attribute names, method signatures and state-dict keys as the 
 torch_geometric / torch_scatter: every forward/backward is a call into the hand-written HIP kernels
 of libhexgnn.so (gnn_hex_amd/ops.py).  CUDA(HIP) tensors only -- there is no CPU fallback.
 
-Out of scope here (raise NotImplementedError): ``--norm=True`` (LayerNorm / CachedGraphNorm),
-``--noisy_dqn=True`` (FactorizedNoisyLinear) and the other model families of the reference factory;
-all BASELINE configs run ``--norm=False --noisy_dqn=False`` (README.md:5,7).
+``--noisy_dqn=True`` (FactorizedNoisyLinear as the heads' advantage linear, GN0/models.py:84-141,331-334) is
+supported on every kernel path: the effective weight ``mu + sigma * eps`` is formed per forward and handed to the
+kernels like a plain Linear; autograd carries the kernel's gradient back to ``mu`` and ``sigma``.
+Out of scope here (raise NotImplementedError): ``--norm=True`` (torch_geometric LayerNorm in its whole-batch
+"graph" mode / CachedGraphNorm) and the other model families of the reference factory; all BASELINE configs run
+``--norm=False --noisy_dqn=False`` (README.md:5,7).
 """
 from __future__ import annotations
 
 from argparse import Namespace
+from math import sqrt
 from typing import Optional, Tuple, Union
 
 import torch
@@ -62,6 +66,62 @@ class MLP(torch.nn.Module):
         self.hidden_channels = new_hidden_channels
 
 
+class FactorizedNoisyLinear(torch.nn.Module):
+    """Factorised Gaussian noise layer of noisy-net DQN, same parameters / buffers / methods as GN0/models.py:84-141
+    (state-dict keys weight_mu, weight_sigma, bias_mu, bias_sigma + buffers weight_epsilon, bias_epsilon).  As the heads'
+    advantage linear it is evaluated inside the head-tail kernels: ``effective()`` forms w = mu_w + sigma_w * eps_w and
+    b = mu_b + sigma_b * eps_b (two tiny element-wise ops on [out, in] = [1, H]) and autograd routes the kernel's
+    d w / d b to the four parameters."""
+
+    def __init__(self, in_features: int, out_features: int, sigma_0: float) -> None:
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.sigma_0 = sigma_0
+        self.weight_mu = torch.nn.Parameter(torch.empty(out_features, in_features))
+        self.weight_sigma = torch.nn.Parameter(torch.empty(out_features, in_features))
+        self.register_buffer("weight_epsilon", torch.empty(out_features, in_features))
+        self.bias_mu = torch.nn.Parameter(torch.empty(out_features))
+        self.bias_sigma = torch.nn.Parameter(torch.empty(out_features))
+        self.register_buffer("bias_epsilon", torch.empty(out_features))
+        self.reset_parameters()
+        self.reset_noise()
+
+    @torch.no_grad()
+    def reset_parameters(self) -> None:
+        scale = 1 / sqrt(self.in_features)
+        torch.nn.init.uniform_(self.weight_mu, -scale, scale)
+        torch.nn.init.uniform_(self.bias_mu, -scale, scale)
+        torch.nn.init.constant_(self.weight_sigma, self.sigma_0 * scale)
+        torch.nn.init.constant_(self.bias_sigma, self.sigma_0 * scale)
+
+    @torch.no_grad()
+    def _get_noise(self, size: int) -> Tensor:
+        noise = torch.randn(size, device=self.weight_mu.device)
+        return noise.sign().mul_(noise.abs().sqrt_())            # f(x) = sgn(x) sqrt(|x|)
+
+    @torch.no_grad()
+    def reset_noise(self) -> None:
+        epsilon_in = self._get_noise(self.in_features)
+        epsilon_out = self._get_noise(self.out_features)
+        self.weight_epsilon.copy_(epsilon_out.outer(epsilon_in))
+        self.bias_epsilon.copy_(epsilon_out)
+
+    @torch.no_grad()
+    def disable_noise(self) -> None:
+        self.weight_epsilon[:] = 0
+        self.bias_epsilon[:] = 0
+
+    def effective(self) -> Tuple[Tensor, Tensor]:
+        return (self.weight_mu + self.weight_sigma * self.weight_epsilon,
+                self.bias_mu + self.bias_sigma * self.bias_epsilon)
+
+    def forward(self, input: Tensor) -> Tensor:
+        """Stand-alone use (not the hot path, which evaluates the layer inside the head-tail kernel)."""
+        w, b = self.effective()
+        return torch.nn.functional.linear(input, w, b)
+
+
 class SAGEConv(torch.nn.Module):
     """Parameter holder for pyg SAGEConv(aggr='mean', root_weight=True, bias=True): ``lin_l`` (with bias)
     acts on the neighbour mean, ``lin_r`` (no bias) on the root (GN0/torch_script_models.py:52-73)."""
@@ -73,10 +133,16 @@ class SAGEConv(torch.nn.Module):
         self.lin_l = Linear(in_channels, out_channels, bias=True)
         self.lin_r = Linear(in_channels, out_channels, bias=False)
 
-    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
-        raise NotImplementedError(
-            "a single SAGEConv is not evaluated on its own in this build; run it through GraphSAGE "
-            "(the kernels fuse the ReLU that CachifiedGNN applies after every layer)")
+    def forward(self, x: Tensor, edge_index, _graph: Optional[ops.GraphStructure] = None) -> Tensor:
+        """``lin_l(mean_{j in N(i)} x_j) + lin_r(x_i)``, no activation (GN0/torch_script_models.py:52-73): a 1-layer
+        stack of the layer-major kernels with the ReLU switched off.  Shapes the kernels cover: in_channels <= 8 (raw
+        features) or in_channels == out_channels (hidden layer)."""
+        ops._require_cuda(x, "x")
+        if not (self.in_channels <= 8 or self.in_channels == self.out_channels):
+            raise NotImplementedError("SAGEConv(%d, %d): the kernels cover in_channels <= 8 or in_channels == out_channels"
+                                      % (self.in_channels, self.out_channels))
+        gs = _graph if _graph is not None else ops.GraphStructure(edge_index, x.shape[0])
+        return ops.sage_stack(x, gs, self.in_channels, self.out_channels, [self], linear_last=True)
 
 
 class GraphSAGE(torch.nn.Module):
@@ -210,8 +276,6 @@ class HeadNetwork(torch.nn.Module):
     def __init__(self, in_channels, hidden_channels, out_channels, GNN, value_head_type="linear",
                  value_aggr_types=("mean",), noisy_dqn=True, noise_sigma=0, **gnn_kwargs):
         super().__init__()
-        if noisy_dqn:
-            raise NotImplementedError("--noisy_dqn=True is outside the accelerated hot path (README.md:5,7)")
         if value_head_type != "mlp" or tuple(value_aggr_types) != ("sum", "max", "min", "mean") or out_channels != 1:
             raise NotImplementedError("head kernel implements value_head_type='mlp' over (sum,max,min,mean), out=1")
         self.gnn = GNN(in_channels=in_channels, hidden_channels=hidden_channels, **gnn_kwargs)
@@ -221,10 +285,20 @@ class HeadNetwork(torch.nn.Module):
         self.value_head = MLP(self.hidden_channels // 2, 1, self.hidden_channels * len(value_aggr_types), 1)
         self.out_channels = out_channels
         self.value_aggr_types = value_aggr_types
-        self.linear = Linear(hidden_channels, out_channels)
+        if noisy_dqn:
+            self.linear = FactorizedNoisyLinear(hidden_channels, out_channels, noise_sigma)
+        else:
+            self.linear = Linear(hidden_channels, out_channels)
+
+    def _lin_params(self) -> Tuple[Tensor, Tensor]:
+        """(weight [1,H], bias [1]) of the advantage linear as the kernels take them."""
+        if isinstance(self.linear, FactorizedNoisyLinear):
+            return self.linear.effective()
+        return self.linear.weight, self.linear.bias
 
     def grow_width(self, new_width, new_in_channels=None):
         """GN0/models.py:336-357."""
+        assert isinstance(self.linear, Linear)
         self.gnn.grow_width(new_width, new_in_channels=new_in_channels)
         old = self.linear
         self.linear = Linear(new_width, self.out_channels).to(old.weight.device)
@@ -245,14 +319,24 @@ class HeadNetwork(torch.nn.Module):
 
     def _tail(self, x, gptr, b, mode):
         vh = self.value_head
-        return ops.HeadTailFn.apply(x, gptr, b, self.hidden_channels, mode, self.linear.weight, self.linear.bias,
+        lin_w, lin_b = self._lin_params()
+        return ops.HeadTailFn.apply(x, gptr, b, self.hidden_channels, mode, lin_w, lin_b,
                                     vh.layers[0].weight, vh.layers[0].bias, vh.layers[1].weight, vh.layers[1].bias)
 
-    def forward(self, x: Tensor, edge_index: Tensor, graph_indices, advantages_only=False, set_cache=False):
-        """Raw (pre-activation) ``advantages [N,1]`` (and ``value [B,1]``) like the reference head is NOT what
-        the fused kernel produces; DuellingTwoHeaded drives ``_tail`` directly.  Calling the head on its own
-        is supported only through DuellingTwoHeaded."""
-        raise NotImplementedError("HeadNetwork is evaluated through DuellingTwoHeaded.forward in this build")
+    def forward(self, x: Tensor, edge_index: Tensor, graph_indices, advantages_only=False, set_cache=False,
+                _graph: Optional[ops.GraphStructure] = None):
+        """GN0/models.py:368-384: raw (pre-activation) ``advantages [N,1]`` and ``value [B,1]`` from the body embedding
+        ``x [N,H]`` -- the head's SAGE layers on the layer-major kernels, then the head-tail kernel in its raw-output mode.
+        (DuellingTwoHeaded does not go through here: its fused kernels evaluate body, head and dueling combine at once.)"""
+        ops._require_cuda(x, "x")
+        n = x.shape[0]
+        gs = _graph if _graph is not None else ops.GraphStructure(edge_index, n)
+        hx = self.gnn(x, edge_index, set_cache=set_cache, _graph=gs)
+        gptr, b = ops.graph_ptr(graph_indices, None, n, x.device)
+        if advantages_only:
+            return self._tail(hx, gptr, b, 4).view(-1, 1)
+        value, adv = self._tail(hx, gptr, b, 3)
+        return adv.view(-1, 1), value.view(-1, 1)
 
 
 class DuellingTwoHeaded(torch.nn.Module):
@@ -309,7 +393,7 @@ class DuellingTwoHeaded(torch.nn.Module):
         ``gnn_hex_amd`` (env manager, ``Batch.from_data_list``) carries the side to move as ``x._hex_is_maker``.
         Without the hint the reference behaviour (assert + sync) is kept."""
         ops._require_cuda(x, "x")
-        hint = getattr(x, "_hex_is_maker", None)
+        hint, max_nodes = ops.hints_of(x)          # (None, None) when absent or stale (x edited in place since)
         if hint is None:
             assert torch.all(x[:, 2] == x[0, 2])
             is_maker = bool(x[0, 2] == 1)
@@ -318,7 +402,6 @@ class DuellingTwoHeaded(torch.nn.Module):
         n = x.shape[0]
         x2 = x[:, :2]
 
-        max_nodes = getattr(x, "_hex_max_nodes", None)
         gs = getattr(edge_index, "_hex_csr", None)          # CSR emitted by the env builder, if any
         # edge_index CSR-sorted once per batch; collated batches (edges grouped by graph) take the one-launch build
         grouped = (gs is None or gs.n != n) and getattr(edge_index, "_hex_grouped", False) \
@@ -343,6 +426,8 @@ class DuellingTwoHeaded(torch.nn.Module):
         if max_nodes is not None and ops.qnet_fused_supported(self.gnn.in_channels, h, max_nodes) \
                 and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels:
             params = self._fused_params(head)
+            if isinstance(head.linear, FactorizedNoisyLinear):      # effective weights are formed per forward
+                params = params[:-6] + list(head._lin_params()) + params[-4:]
             sink = self.activations_hook if torch.is_grad_enabled() else None
             outs = ops.QNetFusedFn.apply(x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs),
                                          len(head.gnn.convs), mode, sink, *params)
@@ -374,15 +459,16 @@ class DuellingTwoHeaded(torch.nn.Module):
         cache = self.__dict__.setdefault("_fused_cache", {})
         key = id(head)
         ent = cache.get(key)
+        lin0 = head.linear.weight_mu if isinstance(head.linear, FactorizedNoisyLinear) else head.linear.weight
         sig = (len(self.gnn.convs), len(head.gnn.convs), id(self.gnn.convs[0].lin_l.weight),
-               id(head.linear.weight), id(self.gnn.convs[-1].lin_r.weight))
+               id(lin0), id(self.gnn.convs[-1].lin_r.weight))
         if ent is None or ent[0] != sig:
             params = []
             for conv in list(self.gnn.convs) + list(head.gnn.convs):
                 params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
             vh = head.value_head
-            params += [head.linear.weight, head.linear.bias, vh.layers[0].weight, vh.layers[0].bias,
-                       vh.layers[1].weight, vh.layers[1].bias]
+            params += list(head._lin_params()) + [vh.layers[0].weight, vh.layers[0].bias,
+                                                   vh.layers[1].weight, vh.layers[1].bias]
             ent = (sig, params)
             cache[key] = ent
         return ent[1]

@@ -49,6 +49,7 @@ class ObsList:
             d = Data(x=self.x[n0:n1], edge_index=self.edge_local[:, e0:e1], backmap=self.backmap[n0:n1])
             d.x._hex_is_maker = self.is_maker
             d.x._hex_max_nodes = n1 - n0
+            d.x._hex_hint_version = d.x._version
             d._hex_src = (self, i)
             self._items[i] = d
         return d
@@ -70,6 +71,7 @@ class ObsList:
         b._num_graphs = len(self)
         b.x._hex_is_maker = self.is_maker
         b.x._hex_max_nodes = self.max_nodes
+        b.x._hex_hint_version = b.x._version
         b.edge_index._hex_csr = self.gs
         return b
 
@@ -93,13 +95,21 @@ class SnapObs(ObsList):
     everything the replay path needs (``snapshot()``, ``node_off`` / ``edge_off``, ``is_maker``); the ``Data`` views of
     an ``ObsList`` are not materialised."""
 
-    def __init__(self, snap, sizes: np.ndarray, is_maker: bool):
+    def __init__(self, snap, sizes: np.ndarray, is_maker: bool, owner=None):
+        self._owner = owner        # (DeviceRollout, run number): the snapshot is a view into that rollout's ring
         node_off = np.zeros(sizes.shape[0] + 1, dtype=np.int64)
         edge_off = np.zeros(sizes.shape[0] + 1, dtype=np.int64)
         np.cumsum(sizes[:, 0], out=node_off[1:])
         np.cumsum(sizes[:, 1], out=edge_off[1:])
         super().__init__(None, None, None, None, None, node_off.tolist(), edge_off.tolist(), None, is_maker,
                          int(sizes[:, 0].max()) if sizes.shape[0] else 0, snap)
+
+    def snapshot(self):
+        if self._owner is not None and self._owner[0]._run_no != self._owner[1]:
+            raise RuntimeError("stale rollout observation: DeviceRollout.run() has been called again and overwrote the "
+                               "snapshot ring this observation views; store a run's transitions (put_block) before the "
+                               "next run, or keep RolloutResult.detach() copies")
+        return super().snapshot()
 
     def __getitem__(self, i):
         raise TypeError("a rollout observation holds board snapshots only; re-observe it through GraphReplayBuffer")
@@ -116,6 +126,15 @@ class RolloutResult:
     def __init__(self, states, actions, vertices, rewards, dones, exploratories, infos):
         self.states, self.actions, self.vertices = states, actions, vertices
         self.rewards, self.dones, self.exploratories, self.infos = rewards, dones, exploratories, infos
+
+    def detach(self) -> "RolloutResult":
+        """Give the states their own copies of the board snapshots.  By default they VIEW the rollout's snapshot ring,
+        which the next ``run()`` overwrites (using such a state afterwards raises); a detached result stays valid."""
+        for st in self.states:
+            if st._owner is not None:
+                st._snap = tuple(t.clone() for t in st._snap)
+                st._owner = None
+        return self
 
 
 class DeviceRollout:
@@ -157,6 +176,7 @@ class DeviceRollout:
         self.alive = torch.zeros((T + 1, k, nv), dtype=torch.uint8, device=dev)
         self._mt = torch.zeros(k, dtype=torch.int32, device=dev)
         self._tm = torch.zeros(k, dtype=torch.int32, device=dev)
+        self._run_no = 0           # bumped by every run(): results of earlier runs view overwritten snapshots
         self._graph = None
         if graph:
             from .graphs import GraphedStep
@@ -196,6 +216,7 @@ class DeviceRollout:
             x = self.x.view(self.x.shape)       # fresh tensor object per step: the hints below differ per side
             x._hex_is_maker = maker
             x._hex_max_nodes = mgr._nv
+            x._hex_hint_version = x._version
             ei = self.edge_global.view(self.edge_global.shape)
             ei._hex_csr = self.gs
             with torch.no_grad():
@@ -222,6 +243,8 @@ class DeviceRollout:
         if mgr.global_onturn != self.start_side:
             raise RuntimeError("this rollout was built with %r to move" % self.start_side)
         sizes0 = mgr._sizes.copy()
+        self._run_no += 1
+        owner = (self, self._run_no)
         self._upload_offsets()
         if self._graph is not None:
             self._graph.replay()
@@ -240,7 +263,7 @@ class DeviceRollout:
         infos = [[{} for _ in range(k)] for _ in range(T)]
         now = time.perf_counter()
         maker = self.start_side == "m"
-        states = [SnapObs((self.adj[0], self.alive[0]), sizes0, maker)]
+        states = [SnapObs((self.adj[0], self.alive[0]), sizes0, maker, owner)]
         for t in range(T):
             mover_is_maker = maker
             for i in np.nonzero(dones[t])[0]:
@@ -255,7 +278,7 @@ class DeviceRollout:
                 rewards[t, i] = 1 if winner_is_maker == mover_is_maker else -1
                 mgr._creation_time[i] = now
             maker = not maker
-            states.append(SnapObs((self.adj[t + 1], self.alive[t + 1]), res[t, :, 2:4].astype(np.int64), maker))
+            states.append(SnapObs((self.adj[t + 1], self.alive[t + 1]), res[t, :, 2:4].astype(np.int64), maker, owner))
         mgr._sizes = res[-1, :, 2:4].astype(np.int64)
         mgr.last_obs = None
         return RolloutResult(states, ranks, verts, rewards, dones, expl, infos)
@@ -620,6 +643,7 @@ class Env_manager:
                                 sobs.__delattr__("backmap")
                                 sobs.x[:, 2] = 1.0 if maker_side else 0.0
                                 sobs.x._hex_is_maker = maker_side
+                                sobs.x._hex_hint_version = sobs.x._version
                                 transits.append((s_k, action[k], reward, sobs, True))
                                 break
                             if self.prune_exploratories and j > i and exploratories_history[j][k]:

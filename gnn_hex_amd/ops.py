@@ -31,6 +31,26 @@ def _require_cuda(t: torch.Tensor, what: str) -> None:
             "%s is on %s: gnn_hex_amd runs only on the MI355X HIP path (no CPU fallback)" % (what, t.device))
 
 
+def attach_hints(x: torch.Tensor, is_maker=None, max_nodes=None) -> torch.Tensor:
+    """Host-known metadata of a batch (side to move, largest graph) as attributes of its feature tensor, stamped with the
+    tensor's version counter: an in-place edit of ``x`` afterwards invalidates them (``hints_of`` then returns nothing and
+    the model falls back to the reference's device checks)."""
+    if is_maker is not None:
+        x._hex_is_maker = bool(is_maker)
+    if max_nodes is not None:
+        x._hex_max_nodes = int(max_nodes)
+    x._hex_hint_version = x._version
+    return x
+
+
+def hints_of(x: torch.Tensor):
+    """(is_maker, max_nodes) hints of ``x`` or (None, None) when absent or stale (x modified in place since)."""
+    ver = getattr(x, "_hex_hint_version", None)
+    if ver is not None and ver != x._version:
+        return None, None
+    return getattr(x, "_hex_is_maker", None), getattr(x, "_hex_max_nodes", None)
+
+
 def padded_width(hidden: int) -> int:
     hp = _lib.lib().hexgnn_padded_width(int(hidden))
     if hp < 0:
@@ -184,7 +204,7 @@ class SageStackFn(torch.autograd.Function):
     """y = relu(SAGE_L(... relu(SAGE_1(x)) ...)); CachifiedGNN.forward, GN0/models.py:261-294."""
 
     @staticmethod
-    def forward(ctx, x, gs: GraphStructure, c_in: int, hidden: int, num_layers: int, *params):
+    def forward(ctx, x, gs: GraphStructure, c_in: int, hidden: int, num_layers: int, flags: int, *params):
         L = _lib.lib()
         dev = x.device
         n = int(x.shape[0])
@@ -206,10 +226,11 @@ class SageStackFn(torch.autograd.Function):
         _lib.check(L.hexgnn_sage_stack_forward(
             n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
             xin.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), wpack.data_ptr(),
-            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), _stream()),
+            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), int(flags), _stream()),
             "hexgnn_sage_stack_forward")
         if need_bwd:
             ctx.gs = gs
+            ctx.flags = int(flags)
             ctx.dims = (n, c_in, hidden, num_layers, hp, x_stride)
             ctx.bufs = (xin, acts, saved, wpack)
             ctx.param_shapes = [p.shape for p in params]
@@ -233,18 +254,22 @@ class SageStackFn(torch.autograd.Function):
             gs.col_t.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(), x_stride, acts.data_ptr(),
             saved.data_ptr(), wpack.data_ptr(), dy.data_ptr(), dx.data_ptr() if dx is not None else None,
             _ptr_array(grads[0::3]), _ptr_array(grads[1::3]), _ptr_array(grads[2::3]), ws.data_ptr(), ws_bytes,
-            _stream()), "hexgnn_sage_stack_backward")
+            ctx.flags, _stream()), "hexgnn_sage_stack_backward")
         gx = _logical(dx, hidden) if dx is not None else None
-        return (gx, None, None, None, None) + tuple(grads)
+        return (gx, None, None, None, None, None) + tuple(grads)
 
 
-def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, convs) -> torch.Tensor:
-    """Run a stack of SAGEConv parameter holders (objects with lin_l.weight/bias, lin_r.weight)."""
+SAGE_LINEAR_LAST = 1      # HEXGNN_SAGE_LINEAR_LAST: no ReLU after the last layer of the stack
+
+
+def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, convs, linear_last: bool = False) -> torch.Tensor:
+    """Run a stack of SAGEConv parameter holders (objects with lin_l.weight/bias, lin_r.weight): ReLU after every layer
+    (CachifiedGNN.forward), except after the last one when ``linear_last`` (a bare SAGEConv.forward)."""
     _require_cuda(x, "x")
     params: List[torch.Tensor] = []
     for conv in convs:
         params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight]
-    out = SageStackFn.apply(x, gs, c_in, hidden, len(convs), *params)
+    out = SageStackFn.apply(x, gs, c_in, hidden, len(convs), SAGE_LINEAR_LAST if linear_last else 0, *params)
     out._hexgnn_hp = padded_width(hidden)
     return out
 
@@ -254,7 +279,8 @@ def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, conv
 # ------------------------------------------------------------------------------------------------
 
 class HeadTailFn(torch.autograd.Function):
-    """mode 0: Q [n]; mode 1: (V [b], A - mean(A) [n]); mode 2: 2*tanh(adv) [n].  GN0/models.py:374-384,567-584."""
+    """mode 0: Q [n]; mode 1: (V [b], A - mean(A) [n]); mode 2: 2*tanh(adv) [n]; mode 3: raw (value [b], advantages [n])
+    of HeadNetwork.forward; mode 4: raw advantages [n] only.  GN0/models.py:368-384,567-584."""
 
     @staticmethod
     def forward(ctx, h, gptr, b: int, hidden: int, mode: int, lin_w, lin_b, v0_w, v0_b, v1_w, v1_b):
@@ -266,7 +292,7 @@ class HeadTailFn(torch.autograd.Function):
         ps = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous()
               for p in (lin_w, lin_b, v0_w, v0_b, v1_w, v1_b)]
         q = torch.empty(n, dtype=torch.float32, device=dev)
-        out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+        out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode in (1, 3) else None
         saved = _bytes(L.hexgnn_head_saved_bytes(n, b, hidden), dev)
         _lib.check(L.hexgnn_head_forward(
             n, b, hidden, mode, gptr.data_ptr(), hpad.data_ptr(), ps[0].data_ptr(), ps[1].data_ptr(),
@@ -274,7 +300,7 @@ class HeadTailFn(torch.autograd.Function):
             out_v.data_ptr() if out_v is not None else None, saved.data_ptr(), _stream()), "hexgnn_head_forward")
         ctx.dims = (n, b, hidden, mode, hp)
         ctx.bufs = (hpad, gptr, saved, ps)
-        if mode == 1:
+        if mode in (1, 3):
             return out_v, q
         return q
 
@@ -284,7 +310,7 @@ class HeadTailFn(torch.autograd.Function):
         n, b, hidden, mode, hp = ctx.dims
         hpad, gptr, saved, ps = ctx.bufs
         dev = hpad.device
-        if mode == 1:
+        if mode in (1, 3):
             d_v, dq = gouts
             if d_v is None:
                 d_v = torch.zeros(b, dtype=torch.float32, device=dev)
@@ -304,7 +330,7 @@ class HeadTailFn(torch.autograd.Function):
             ps[4].data_ptr(), saved.data_ptr(), dq.data_ptr(), d_v.data_ptr() if d_v is not None else None,
             dh.data_ptr(), g[0].data_ptr(), g[1].data_ptr(), g[2].data_ptr(), g[3].data_ptr(), g[4].data_ptr(),
             g[5].data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "hexgnn_head_backward")
-        if mode == 2:   # value path unused: no gradient for the value head (reference: grads stay None)
+        if mode in (2, 4):   # value path unused: no gradient for the value head (reference: grads stay None)
             g[2] = g[3] = g[4] = g[5] = None
         return (_logical(dh, hidden), None, None, None, None) + tuple(g)
 

@@ -202,6 +202,7 @@ class GraphReplayBuffer:
         b.ptr = torch.from_numpy(node_off).to(dev, non_blocking=True)
         b._num_graphs = k
         b.x._hex_max_nodes = int(self.n_nodes[slots_host].max()) if k else 0
+        b.x._hex_hint_version = b.x._version
         b.edge_index._hex_csr = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
         return b
 
@@ -228,7 +229,9 @@ class GraphReplayBuffer:
         nxt = self._build_batch(idx + self.capacity, host + self.capacity)
         # all stored states of one buffer share the mover's side (maker / breaker buffers are separate)
         state.x._hex_is_maker = bool(self.side_host[int(host[0])]) if batch_size else True
+        state.x._hex_hint_version = state.x._version
         nxt.x._hex_is_maker = bool(self.side_host[int(host[0]) + self.capacity]) if batch_size else True
+        nxt.x._hex_hint_version = nxt.x._version
         return idx, w, state, nxt, self.action[idx], self.reward[idx], self.done[idx]
 
     def update_priorities(self, indices: torch.Tensor, td_errors: torch.Tensor) -> None:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HEXGNN_ABI_VERSION 1
+#define HEXGNN_ABI_VERSION 2
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
@@ -74,7 +74,10 @@ int hexgnn_graph_ptr(int n, int b, const int64_t* batch, int* gptr /*[b+1]*/, he
  *      after every layer.  Layer 0 maps c_in -> hidden, the rest hidden -> hidden.
  *      c_in <= 8 (raw features, row stride x_stride floats) or c_in == hidden (padded layout).
  *      wl/bl/wr: HOST arrays (num_layers entries) of device pointers to the torch parameters
- *      lin_l.weight [out,in], lin_l.bias [out], lin_r.weight [out,in]. ------------------------ */
+ *      lin_l.weight [out,in], lin_l.bias [out], lin_r.weight [out,in].
+ *      flags: HEXGNN_SAGE_LINEAR_LAST = no ReLU after the LAST layer of the stack; a 1-layer stack with it is a bare
+ *      SAGEConv.forward (torch_geometric SAGEConv as restated at GN0/torch_script_models.py:52-73). */
+#define HEXGNN_SAGE_LINEAR_LAST 1
 size_t hexgnn_sage_stack_pack_bytes(int c_in, int hidden, int num_layers);
 size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers);
 /* acts:  [num_layers][n][HP] outputs of every layer (post-ReLU); the last slab is the result.
@@ -85,7 +88,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers,
                               const int* rowptr, const int* col, const float* invdeg,
                               const float* x, int x_stride,
                               const float* const* wl, const float* const* bl, const float* const* wr,
-                              void* wpack, float* acts, void* saved, int need_backward,
+                              void* wpack, float* acts, void* saved, int need_backward, int flags,
                               hexgnn_stream_t stream);
 
 size_t hexgnn_sage_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers);
@@ -100,7 +103,8 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers,
                                const float* acts, const void* saved, const void* wpack,
                                const float* dy, float* dx,
                                float* const* d_wl, float* const* d_bl, float* const* d_wr,
-                               void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+                               void* workspace, size_t workspace_bytes, int flags /* as in the forward call */,
+                               hexgnn_stream_t stream);
 
 /* ---- head tail: HeadNetwork.forward after its gnn (GN0/models.py:374-384), MLP value head
  *      (GN0/models.py:36-82: Linear(4H,H/2) -> relu -> Linear(H/2,1)) and the dueling combine of
@@ -108,6 +112,9 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers,
  *      mode 0: q[n]   = tanh(v)[g] + 2tanh(a) - mean_g(2tanh(a))
  *      mode 1: out_v[b] = tanh(v), q[n] = 2tanh(a) - mean_g(2tanh(a))          (seperate=True)
  *      mode 2: q[n]   = 2tanh(a); pooling / value path skipped                  (advantages_only=True)
+ *      mode 3: q[n]   = a (raw advantage linear), out_v[b] = v (raw value MLP): HeadNetwork.forward itself,
+ *              GN0/models.py:368-384, before DuellingTwoHeaded's activations
+ *      mode 4: q[n]   = a only; pooling / value path skipped     (HeadNetwork.forward(advantages_only=True))
  *      Pooled order is [sum | max | min | mean] (value_aggr_types, GN0/models.py:940); max/min route
  *      their gradient to the FIRST row attaining the extremum (torch_scatter CPU kernel). -------- */
 size_t hexgnn_head_saved_bytes(int n, int b, int hidden);
@@ -115,10 +122,10 @@ int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, con
                         const float* lin_w /*[hidden]*/, const float* lin_b /*[1]*/,
                         const float* v0_w /*[hidden/2][4*hidden]*/, const float* v0_b /*[hidden/2]*/,
                         const float* v1_w /*[hidden/2]*/, const float* v1_b /*[1]*/,
-                        float* q /*[n]*/, float* out_v /*[b] (mode 1) or NULL*/,
+                        float* q /*[n]*/, float* out_v /*[b] (modes 1, 3) or NULL*/,
                         void* saved, hexgnn_stream_t stream);
 size_t hexgnn_head_backward_workspace_bytes(int n, int b, int hidden);
-/* dq: gradient of q [n]; d_out_v: gradient of out_v [b] (mode 1) or NULL.
+/* dq: gradient of q [n]; d_out_v: gradient of out_v [b] (modes 1, 3) or NULL.
  * dh: [n][HP] gradient w.r.t. h (padded layout, written).  Parameter gradients written. */
 int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, const float* h,
                          const float* lin_w, const float* v0_w, const float* v1_w,

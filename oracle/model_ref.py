@@ -14,6 +14,8 @@ on the reference's own call sites:
 * ``GraphSAGERef``          <- GN0/torch_script_models.py:96-144 (layer layout) and
                                GN0/models.py:144-164,261-294 (CachifiedGNN loop:
                                ReLU after EVERY layer because out_channels=None)
+* ``FactorizedNoisyLinearRef`` <- GN0/models.py:84-141 (--noisy_dqn=True: the heads'
+                               advantage linear, GN0/models.py:331-334)
 * ``HeadNetworkRef``        <- GN0/models.py:318-384
 * ``DuellingTwoHeadedRef``  <- GN0/models.py:477-590
 * ``get_pre_defined_ref``   <- GN0/models.py:892-947 (``modern_two_headed`` only)
@@ -152,11 +154,46 @@ class GraphSAGERef(torch.nn.Module):
         return x
 
 
+class FactorizedNoisyLinearRef(torch.nn.Module):
+    """GN0/models.py:84-141: y = (mu_w + sigma_w * eps_w) x + (mu_b + sigma_b * eps_b), factorised noise
+    eps_w = f(e_out) f(e_in)^T, eps_b = f(e_out), f(x) = sgn(x) sqrt(|x|)."""
+
+    def __init__(self, in_features: int, out_features: int, sigma_0: float) -> None:
+        super().__init__()
+        self.in_features, self.out_features, self.sigma_0 = in_features, out_features, sigma_0
+        self.weight_mu = torch.nn.Parameter(torch.empty(out_features, in_features))
+        self.weight_sigma = torch.nn.Parameter(torch.empty(out_features, in_features))
+        self.register_buffer("weight_epsilon", torch.empty(out_features, in_features))
+        self.bias_mu = torch.nn.Parameter(torch.empty(out_features))
+        self.bias_sigma = torch.nn.Parameter(torch.empty(out_features))
+        self.register_buffer("bias_epsilon", torch.empty(out_features))
+        with torch.no_grad():
+            scale = 1 / (in_features ** 0.5)
+            torch.nn.init.uniform_(self.weight_mu, -scale, scale)
+            torch.nn.init.uniform_(self.bias_mu, -scale, scale)
+            torch.nn.init.constant_(self.weight_sigma, sigma_0 * scale)
+            torch.nn.init.constant_(self.bias_sigma, sigma_0 * scale)
+        self.reset_noise()
+
+    @torch.no_grad()
+    def reset_noise(self) -> None:
+        def f(size):
+            noise = torch.randn(size)
+            return noise.sign().mul_(noise.abs().sqrt_())
+        e_in, e_out = f(self.in_features), f(self.out_features)
+        self.weight_epsilon.copy_(e_out.outer(e_in))
+        self.bias_epsilon.copy_(e_out)
+
+    def forward(self, input: Tensor) -> Tensor:
+        return F.linear(input, self.weight_mu + self.weight_sigma * self.weight_epsilon,
+                        self.bias_mu + self.bias_sigma * self.bias_epsilon)
+
+
 class HeadNetworkRef(torch.nn.Module):
-    """GN0/models.py:318-384 with noisy_dqn=False."""
+    """GN0/models.py:318-384."""
 
     def __init__(self, in_channels, hidden_channels, out_channels, value_head_type="linear",
-                 value_aggr_types=("mean",), num_layers=2, **_):
+                 value_aggr_types=("mean",), num_layers=2, noisy_dqn=False, noise_sigma=0, **_):
         super().__init__()
         self.gnn = GraphSAGERef(in_channels=in_channels, hidden_channels=hidden_channels, num_layers=num_layers)
         self.supports_cache = True
@@ -168,7 +205,10 @@ class HeadNetworkRef(torch.nn.Module):
             self.value_head = MLPRef(hidden_channels // 2, 1, hidden_channels * len(value_aggr_types), 1)
         self.out_channels = out_channels
         self.value_aggr_types = value_aggr_types
-        self.linear = torch.nn.Linear(hidden_channels, out_channels)
+        if noisy_dqn:
+            self.linear = FactorizedNoisyLinearRef(hidden_channels, out_channels, noise_sigma)
+        else:
+            self.linear = torch.nn.Linear(hidden_channels, out_channels)
 
     def forward(self, x, edge_index, graph_indices, advantages_only=False, set_cache=False):
         x = self.gnn(x, edge_index)
@@ -232,13 +272,14 @@ class DuellingTwoHeadedRef(torch.nn.Module):
 
 
 def get_pre_defined_ref(name: str, args: Optional[Namespace] = None) -> torch.nn.Module:
-    """GN0/models.py:892-947, ``modern_two_headed`` branch only (norm / noisy off)."""
+    """GN0/models.py:892-947, ``modern_two_headed`` branch only (norm off)."""
     if name != "modern_two_headed":
         raise NotImplementedError(name)
-    if getattr(args, "norm", False) or getattr(args, "noisy_dqn", False):
-        raise NotImplementedError("oracle covers --norm=False --noisy_dqn=False (README.md:5,7)")
+    if getattr(args, "norm", False):
+        raise NotImplementedError("oracle covers --norm=False (README.md:5,7)")
     return DuellingTwoHeadedRef(
         gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
                         cached_norm=False, norm=None, act="relu"),
         head_kwargs=dict(value_head_type="mlp", value_aggr_types=("sum", "max", "min", "mean"),
-                         num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2))
+                         num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2,
+                         noisy_dqn=getattr(args, "noisy_dqn", False), noise_sigma=getattr(args, "noisy_sigma0", 0.5)))

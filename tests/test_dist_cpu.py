@@ -73,6 +73,28 @@ def _worker(rank, world, port, q):
     sync.all_reduce()
     ok = ok and torch.allclose(flat, torch.full_like(flat, 1.5))
     ok = ok and all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(active, views))
+    # fourth step: the ranks disagree on the side (rank 0 maker head, rank 1 breaker head: equal element counts, so the
+    # plain bucket would silently mix the two heads) -- check=True must raise on every rank instead of reducing
+    checked = GradSync(model.parameters(), check=True)
+    for p in model.parameters():
+        p.grad = None
+    skip = "breaker_head" if rank == 0 else "maker_head"
+    for k, p in model.named_parameters():
+        if not k.startswith(skip):
+            p.grad = torch.ones(p.shape)
+    try:
+        checked.all_reduce()
+        ok = False
+    except RuntimeError as exc:
+        ok = ok and "different parameter sets" in str(exc)
+    # ... and passes when they agree
+    for p in model.parameters():
+        p.grad = None
+    for k, p in model.named_parameters():
+        if not k.startswith("breaker_head"):
+            p.grad = torch.full(p.shape, float(rank))
+    checked.all_reduce()
+    ok = ok and all(torch.allclose(p.grad, torch.full(p.shape, 0.5)) for p in model.parameters() if p.grad is not None)
     q.put((rank, bool(ok)))
     dist.barrier()
     dist.destroy_process_group()
@@ -107,3 +129,52 @@ def test_shard_range_and_edge_balance():
     loads = [sum(edges[i] for i in p) for p in parts]
     assert max(loads) - min(loads) <= max(edges)
     assert parts == balance_by_edges(edges, 8)                       # deterministic
+
+
+_CHILD = """
+import os, sys
+import torch, torch.distributed as dist
+dist.init_process_group("gloo")
+t = torch.tensor([float(dist.get_rank() + 1)])
+dist.all_reduce(t)
+if os.environ.get("FAIL_RANK") == os.environ["RANK"]:
+    sys.exit(7)
+if dist.get_rank() == 0:
+    print("sum=%d world=%s local=%s" % (int(t.item()), os.environ["WORLD_SIZE"], os.environ["LOCAL_RANK"]))
+dist.barrier()
+"""
+
+
+@pytest.mark.timeout(180)
+def test_launch_ranks_brings_up_its_own_world(tmp_path, capfd):
+    """gnn_hex_amd.dist.launch_ranks is what `bench.py --gpus N` uses when no launcher set WORLD_SIZE: N fresh child
+    processes with the rendezvous environment, rank 0's stdout passed through, a failing rank's code returned."""
+    import sys
+    from gnn_hex_amd.dist import launch_ranks
+    script = tmp_path / "child.py"
+    script.write_text(_CHILD)
+    assert launch_ranks([sys.executable, str(script)], 3, timeout_s=150) == 0
+    assert "sum=6 world=3 local=0" in capfd.readouterr().out
+    os.environ["FAIL_RANK"] = "1"
+    try:
+        assert launch_ranks([sys.executable, str(script)], 2, timeout_s=150) == 7
+    finally:
+        del os.environ["FAIL_RANK"]
+
+
+def test_bench_refuses_mismatched_world(monkeypatch):
+    """bench.py must never print a line whose n_gpus differs from --gpus: under a launcher with the wrong WORLD_SIZE it
+    exits, and without GPUs for the requested ranks it says so instead of silently running one rank."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=2 but --gpus=4" in r.stderr
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    import torch
+    if torch.cuda.device_count() < 8:
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8"], env=env, capture_output=True,
+                           text=True, timeout=120)
+        assert r.returncode != 0 and "only" in r.stderr and "GPU(s) visible" in r.stderr and r.stdout.strip() == ""

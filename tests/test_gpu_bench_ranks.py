@@ -1,0 +1,30 @@
+"""bench.py brings up its own ranks: `python bench.py --gpus 2` (no external launcher) on ONE GPU with the gloo
+backend as the rehearsal of the RCCL path -- the JSON line must say n_gpus 2, carry the whole-job value of both ranks,
+and both ranks must end with identical parameters after an update from the all-reduced gradients."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("data", ["D0", "D1"])
+def test_bench_two_ranks_gloo_rehearsal(data):
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "S256",
+           "--data", data, "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-split"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["config"]["global_batch"] == 512
+    assert out["replicas_identical"] is True
+    assert out["scaling"] == "weak" and out["value"] > 0
+    assert abs(out["value"] - 512 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+    assert out["config"]["collective"]["backend"].startswith("gloo")

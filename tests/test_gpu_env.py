@@ -270,3 +270,25 @@ def test_device_rollout_feeds_replay():
     q = hip(s.x, s.edge_index, s.batch, s.ptr)
     assert q.shape[0] == s.x.shape[0] and torch.isfinite(q).all()
     assert int(act.max()) < int((s.ptr[1:] - s.ptr[:-1]).max())
+
+
+def test_rollout_result_goes_stale_unless_detached():
+    """RolloutResult.states view the rollout's snapshot ring: after the next run() they must refuse to be used (they would
+    silently describe other boards); detach() gives them their own copies."""
+    import torch
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
+    from helpers import make_pair
+    hip, _ = make_pair(3, 35, seed=4)
+    mgr = Env_manager(8, 5, gamma=0.9)
+    mgr.reset()
+    ro = DeviceRollout(mgr, hip, steps=4, eps=0.5, graph=False)
+    first = ro.run()
+    kept = [tuple(t.clone() for t in s.snapshot()) for s in first.states]
+    second = ro.run().detach()
+    with pytest.raises(RuntimeError, match="stale rollout observation"):
+        first.states[1].snapshot()
+    copies = [tuple(t.clone() for t in s.snapshot()) for s in second.states]
+    ro.run()
+    for s, c in zip(second.states, copies):                      # detached: unaffected by the third run
+        assert all(torch.equal(a, b) for a, b in zip(s.snapshot(), c))
+    assert any(not torch.equal(k[0], c[0]) for k, c in zip(kept, copies))

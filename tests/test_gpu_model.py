@@ -135,6 +135,38 @@ def test_grouped_csr_build_edge_cases():
         bad.check()
 
 
+def test_grouped_csr_build_graph_of_exactly_2048_nodes():
+    """The one-launch build takes graphs up to 2048 nodes; at exactly 2048 the last row's end lies past the scanned range
+    (regression: it was read from uninitialised LDS).  2049 nodes must raise status bit 8."""
+    from gnn_hex_amd import ops
+    rng = np.random.default_rng(9)
+    for n0 in (2047, 2048):
+        sizes = [n0, 5]
+        off, eis = 0, []
+        for n in sizes:
+            m = 6 * n
+            s, d = rng.integers(0, n, m), rng.integers(0, n, m)
+            s[:4] = n - 1                                   # make sure the last row has out- and in-edges
+            d[4:8] = n - 1
+            eis.append(np.stack([s, d]) + off)
+            off += n
+        ei = torch.from_numpy(np.concatenate(eis, 1).astype(np.int64)).cuda()
+        gptr = torch.tensor([0, sizes[0], off], dtype=torch.int32, device="cuda")
+        gs = ops.GraphStructure(ei, off)
+        gg = ops.GraphStructure(ei, off, gptr, 2)
+        torch.cuda.synchronize()
+        gg.check()
+        e = ei.shape[1]
+        for name in ("rowptr", "rowptr_t", "invdeg"):
+            assert torch.equal(getattr(gg, name), getattr(gs, name)), (n0, name)
+        assert torch.equal(gg.col[:e], gs.col[:e]) and torch.equal(gg.col_t[:e], gs.col_t[:e])
+    ei = torch.tensor([[0, 2048], [2048, 0]], dtype=torch.int64, device="cuda")
+    big = ops.GraphStructure(ei, 2049, torch.tensor([0, 2049], dtype=torch.int32, device="cuda"), 1)
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        big.check()
+
+
 @pytest.mark.parametrize("maker", [True, False])
 def test_gnn_s_hex7_start_positions(maker):
     hip, ref = make_pair(10, 35)
@@ -220,6 +252,24 @@ def test_mixed_side_batch_asserts_like_reference():
     x[0, 2] = 0.0
     with pytest.raises(AssertionError):
         hip(x.cuda(), ei.cuda(), batch.cuda(), ptr.cuda())
+
+
+def test_stale_hints_are_dropped_after_in_place_edit():
+    """Host-side hints (side to move, largest graph) are stamped with the tensor's version: editing x in place afterwards
+    must make the model fall back to the reference's own device check instead of trusting the stale side."""
+    from gnn_hex_amd import ops
+    hip, ref = make_pair(3, 16, seed=8)
+    x, ei, batch, ptr = batch_tensors("D0", [5, 7], maker=True)
+    xd = ops.attach_hints(x.cuda(), is_maker=True, max_nodes=51)
+    assert ops.hints_of(xd) == (True, 51)
+    xd[:, 2] = 0.0                                   # now the breaker is to move; the hint says maker
+    assert ops.hints_of(xd) == (None, None)
+    x2 = x.clone()
+    x2[:, 2] = 0.0
+    with torch.no_grad():
+        q = hip(xd, ei.cuda(), batch.cuda(), ptr.cuda())
+        q_ref = ref(x2, ei, batch, ptr)               # breaker head
+    assert (q.cpu() - q_ref).abs().max() < TOL
 
 
 def test_final_conv_acts_and_hook():

@@ -51,6 +51,34 @@ def test_per_trees_and_sampling_match_oracle():
         assert np.allclose(ow.cpu().numpy(), rw, rtol=1e-6, atol=0)
 
 
+def test_per_update_duplicates_last_wins_and_large_lists():
+    """PER samples with replacement, so update_priorities sees duplicated slots: the last occurrence must win in BOTH
+    trees (oracle: sequential loop), deterministically, also across the 2048-entry launch chunks of a long list."""
+    from gnn_hex_amd import _lib, ops
+    from oracle.replay_ref import SegmentTreePER
+    L = _lib.lib()
+    cap = 4096
+    rng = np.random.default_rng(7)
+    for k in (300, 2048, 5000):
+        st = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+        mt = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+        _lib.check(L.hexgnn_per_init(cap, st.data_ptr(), mt.data_ptr(), ops._stream()))
+        ref = SegmentTreePER(cap)
+        idx = rng.integers(0, 700, k).astype(np.int32)          # heavy duplication
+        idx[-1] = idx[0]                                         # a duplicate spanning the whole list
+        pa = rng.random(k) + 1e-3
+        ref.update(idx, pa)
+        di, dp = torch.from_numpy(idx).cuda(), torch.from_numpy(pa).cuda()
+        for _ in range(3):                                       # repeated: no run-to-run variation
+            _lib.check(L.hexgnn_per_update(cap, k, di.data_ptr(), dp.data_ptr(), st.data_ptr(), mt.data_ptr(), ops._stream()))
+            torch.cuda.synchronize()
+            assert np.array_equal(st.cpu().numpy()[1:], ref.sum[1:])
+            fin = np.isfinite(ref.min)
+            assert np.array_equal(mt.cpu().numpy()[fin], ref.min[fin])
+            leaves = np.unique(idx)
+            assert np.array_equal(st.cpu().numpy()[cap + leaves], mt.cpu().numpy()[cap + leaves])
+
+
 def _play(mgr, steps, rng):
     obs0 = mgr.reset()
     states, actions, rewards, dones, expl = [], [], [], [], []

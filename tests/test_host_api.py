@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), "libhexgnn.so does not export %s" % name
     assert set(declared) == set(_lib.exported_symbols()), "ctypes signature table out of sync with the header"
-    assert L.hexgnn_abi_version() == 1
+    assert L.hexgnn_abi_version() == _lib.ABI_VERSION == 2
     assert L.hexgnn_padded_width(110) == 112 and L.hexgnn_padded_width(35) == 48 and L.hexgnn_padded_width(129) < 0
     assert L.hexgnn_strerror(-3).decode() == "workspace too small"
     assert L.hexgnn_qnet_supported(2, 110, 123) == 1 and L.hexgnn_qnet_supported(2, 110, 146) == 0
@@ -69,10 +69,29 @@ def test_unsupported_configurations_fail_loudly():
     args.norm = True
     with pytest.raises(NotImplementedError):
         get_pre_defined("modern_two_headed", args)
-    args = model_args(3, 8)
+
+
+def test_noisy_dqn_module_tree_and_state_dict_keys():
+    """--noisy_dqn=True: the heads' advantage linear is a FactorizedNoisyLinear with the reference's parameter / buffer
+    names (GN0/models.py:84-141), initialised as there (sigma = sigma_0 / sqrt(in), factorised epsilon)."""
+    from gnn_hex_amd.models import FactorizedNoisyLinear, get_pre_defined
+    args = model_args(3, 16)
     args.noisy_dqn = True
-    with pytest.raises(NotImplementedError):
-        get_pre_defined("modern_two_headed", args)
+    torch.manual_seed(0)
+    m = get_pre_defined("modern_two_headed", args)
+    for head in (m.maker_head, m.breaker_head):
+        lin = head.linear
+        assert isinstance(lin, FactorizedNoisyLinear)
+        assert [k for k, _ in lin.named_parameters()] == ["weight_mu", "weight_sigma", "bias_mu", "bias_sigma"]
+        assert [k for k, _ in lin.named_buffers()] == ["weight_epsilon", "bias_epsilon"]
+        assert torch.allclose(lin.weight_sigma, torch.full((1, 16), 0.5 / 4.0)) and lin.weight_mu.abs().max() <= 0.25
+        assert torch.allclose(lin.weight_epsilon, lin.bias_epsilon.outer(lin.weight_epsilon[0] / lin.bias_epsilon[0]))
+        w, b = lin.effective()
+        assert torch.equal(w, lin.weight_mu + lin.weight_sigma * lin.weight_epsilon) and b.shape == (1,)
+        lin.disable_noise()
+        assert torch.equal(lin.effective()[0], lin.weight_mu)
+    assert sum(p.numel() for p in m.parameters()) == sum(
+        p.numel() for p in get_pre_defined("modern_two_headed", model_args(3, 16)).parameters()) + 2 * (16 + 1)
 
 
 def test_cpu_tensors_raise_not_fall_back():
