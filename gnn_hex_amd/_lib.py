@@ -48,6 +48,8 @@ _SIGS = {
     "hexgnn_qnet_backward_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_backward": (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
+    "hexgnn_qnet_backward_staged": (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp,
+                                         vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, ci, vp]),
     "hexgnn_env_create": (ci, [ci, ci, vp]),
     "hexgnn_env_destroy": (None, [vp]),
     "hexgnn_env_num_vertices": (ci, [vp]),

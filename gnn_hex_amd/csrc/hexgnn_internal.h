@@ -6,6 +6,7 @@
 namespace hexgnn {
 
 constexpr int kMaxLayers = 64;
+constexpr int kDwMaxSlices = 64;   // row slices per layer of the weight-gradient GEMM (workspace is sized for this many)
 
 struct StackPlan {
     int hp, nt, L, c_in;
@@ -35,7 +36,9 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
                         int x_stride, const float* acts, const char* saved, const float* G, float* const* d_wl,
                         float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st,
                         int math = 0, const unsigned* xmax = nullptr, const unsigned* gmax = nullptr,
-                        bool hidden_only_no_reduce = false);
+                        bool hidden_only_no_reduce = false, int layer_lo = -1, int layer_hi = -1);
+// layer_lo / layer_hi (>= 0): only the hidden-input layers [layer_lo, layer_hi) -- staged backward; `part` then is the
+// stage's own slab region and the slice count follows the stage's layer count (dw_slices_for(n, layer_hi - layer_lo, math))
 // hidden_only_no_reduce: leave the slice slabs in `part` and skip the raw first layer (the fused path reduces everything in
 // one launch and gets the first layer's per-graph partials from its backward kernel).
 // math 1: f16x3 split with per-layer power-of-two scales from xmax[l] = max |[agg_l | x_l]|, gmax[l] = max |G_l| (bit patterns)

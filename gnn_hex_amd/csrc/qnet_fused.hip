@@ -164,7 +164,7 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     const size_t slab = align_up(sizeof(float) * (size_t)n * q->sp.hp, 256);
     size_t off = 0;
     q->ws_g_off = off; off += slab * L;
-    q->ws_part_off = off; off += align_up(sizeof(float) * (size_t)L * q->bp.S * q->sp.hp * (2 * q->sp.hp + 1), 256);
+    q->ws_part_off = off; off += align_up(sizeof(float) * (size_t)L * kDwMaxSlices * q->sp.hp * (2 * q->sp.hp + 1), 256);
     q->ws_part0_off = off; off += align_up(sizeof(float) * (size_t)q->bp.S0 * q->sp.hp * 17, 256);
     q->ws_head_off = off; off += q->hw.total;
     q->ws_first_off = align_up(off, 256); off = q->ws_first_off + sizeof(float) * (size_t)(b > 0 ? b : 1) * 17 * q->sp.hp;
@@ -240,17 +240,20 @@ size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, 
     return q.ws_total;
 }
 
-int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
-                         const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
-                         const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
-                         const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
-                         const float* d_out_v, float* d_embeds, float* const* d_wl, float* const* d_bl,
-                         float* const* d_wr, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b,
-                         float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
-                         hexgnn_stream_t stream_) {
+int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+                                const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                                const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
+                                const float* d_out_v, float* d_embeds, float* const* d_wl, float* const* d_bl,
+                                float* const* d_wr, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b,
+                                float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
+                                int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 0 || b < 0 || mode < 0 || mode > 2 || math < 0 || math > 1 || body_layers < 1 || body_layers > total_layers)
         return HEXGNN_EINVAL;
+    if (stages <= 0 || (stages & ~(HEXGNN_QBWD_DATA | HEXGNN_QBWD_SMALL | HEXGNN_QBWD_HIDDEN))) return HEXGNN_EINVAL;
+    if ((stages & HEXGNN_QBWD_HIDDEN) && (layer_lo < 1 || layer_hi < layer_lo || layer_hi > total_layers)) return HEXGNN_EINVAL;
+    const bool st_data = stages & HEXGNN_QBWD_DATA, st_small = stages & HEXGNN_QBWD_SMALL, st_hidden = stages & HEXGNN_QBWD_HIDDEN;
     QPlan qp;
     int rc = make_qplan(n, b, c_in, hidden, total_layers, &qp);
     if (rc != HEXGNN_OK) return rc;
@@ -288,10 +291,12 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     // repeated on the same saved state only re-maxes identical values
     a.gmax = math == 1 ? (unsigned*)(const_cast<char*>(sv) + qp.xmax_off) + kMaxLayers : nullptr;
     if (b > 0 && n > 0) {
-        KernelTimer kt(HEXGNN_K_QNET_BWD, st);
-        rc = launch_qbwd_math(qp.sp.nt, math, a, st);
-        if (rc != HEXGNN_OK) return rc;
-    } else {
+        if (st_data) {
+            KernelTimer kt(HEXGNN_K_QNET_BWD, st);
+            rc = launch_qbwd_math(qp.sp.nt, math, a, st);
+            if (rc != HEXGNN_OK) return rc;
+        }
+    } else if (st_data) {
         for (int l = 0; l < total_layers; ++l) {
             const int in = (l == 0) ? c_in : hidden;
             (void)hipMemsetAsync(d_wl[l], 0, sizeof(float) * (size_t)hidden * in, st);
@@ -303,25 +308,33 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
         (void)hipMemsetAsync(a.dvr, 0, sizeof(float) * (size_t)(b > 0 ? b : 1), st);
     }
     if (n > 0 && b > 0) {
-        rc = launch_weight_grads(n, c_in, hidden, qp.sp, qp.bp, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part,
-                                 part0, st, math, (const unsigned*)(sv + qp.xmax_off), a.gmax, /*hidden_only_no_reduce=*/true);
-        if (rc != HEXGNN_OK) return rc;
+        // hidden layers [lo, hi) of this call: weight-gradient GEMM into the stage's own slab region, then ONE reduce launch
+        // whose block roles cover those slabs (R0) and -- with HEXGNN_QBWD_SMALL -- the per-graph partials (R1..R3)
+        const int lo = st_hidden ? layer_lo : 1, hi = st_hidden ? layer_hi : 1;
+        const int nh = hi - lo;
+        const size_t slab_sz = (size_t)qp.sp.hp * (2 * qp.sp.hp + 1);
+        float* spart = part + (size_t)(lo - 1) * kDwMaxSlices * slab_sz;
+        if (nh > 0) {
+            rc = launch_weight_grads(n, c_in, hidden, qp.sp, qp.bp, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, spart,
+                                     part0, st, math, (const unsigned*)(sv + qp.xmax_off), a.gmax,
+                                     /*hidden_only_no_reduce=*/true, lo, hi);
+            if (rc != HEXGNN_OK) return rc;
+        }
         GradReduceArgs r;
-        const int nh = total_layers - 1;
-        for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[i + 1]; r.dbl[i] = d_bl[i + 1]; r.dwr[i] = d_wr[i + 1]; }
-        r.part = part; r.S = dw_slices_for(n, nh, math); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
+        for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[lo + i]; r.dbl[i] = d_bl[lo + i]; r.dwr[i] = d_wr[lo + i]; }
+        r.part = spart; r.S = dw_slices_for(n, nh, math); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
         r.blk_per_layer = (qp.sp.hp * (2 * qp.sp.hp + 1) / 4 + 255) / 256;      // one thread per float4 of a slab
         r.first_part = a.first_part; r.b = b; r.c_in = c_in; r.dwl0 = d_wl[0]; r.dbl0 = d_bl[0]; r.dwr0 = d_wr[0];
         r.lin_part = a.lin_part; r.d_lin_w = d_lin_w; r.d_lin_b = d_lin_b;
         r.dz = a.dz; r.dvr = a.dvr; r.pooled = (const float*)(hsv + qp.hs.pooled_off); r.z = (const float*)(hsv + qp.hs.z_off);
         r.d_v0_w = d_v0_w; r.d_v0_b = d_v0_b; r.d_v1_w = d_v1_w; r.d_v1_b = d_v1_b;
         r.n0 = nh * r.blk_per_layer;
-        r.n1 = (hidden * (2 * c_in + 1) + 3) / 4;
-        r.n2 = (hidden + 1 + 3) / 4;
+        r.n1 = st_small ? (hidden * (2 * c_in + 1) + 3) / 4 : 0;
+        r.n2 = st_small ? (hidden + 1 + 3) / 4 : 0;
         r.nbx3 = (4 * hidden + 63) / 64;
-        r.n3 = (mode != 2 && hidden / 2 > 0) ? r.nbx3 * (hidden / 2) : 0;
-        qnet_grad_reduce_kernel<<<r.n0 + r.n1 + r.n2 + r.n3, 256, 0, st>>>(r);
-    } else {
+        r.n3 = (st_small && mode != 2 && hidden / 2 > 0) ? r.nbx3 * (hidden / 2) : 0;
+        if (r.n0 + r.n1 + r.n2 + r.n3 > 0) qnet_grad_reduce_kernel<<<r.n0 + r.n1 + r.n2 + r.n3, 256, 0, st>>>(r);
+    } else if (st_small) {
         launch_head_param_grads(b, hidden, mode, a.dz, a.dvr, (const float*)(hsv + qp.hs.pooled_off),
                                 (const float*)(hsv + qp.hs.z_off), a.lin_part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w,
                                 d_v1_b, st);
@@ -329,6 +342,20 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
     return check_launch();
 }
 
+int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+                         const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                         const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                         const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
+                         const float* d_out_v, float* d_embeds, float* const* d_wl, float* const* d_bl,
+                         float* const* d_wr, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b,
+                         float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
+                         hexgnn_stream_t stream_) {
+    return hexgnn_qnet_backward_staged(n, b, c_in, hidden, total_layers, body_layers, mode, math, gptr, rowptr_t, col_t,
+                                       invdeg, x, x_stride, acts, saved, wpack, lin_w, v0_w, v1_w, dq, d_out_v, d_embeds,
+                                       d_wl, d_bl, d_wr, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b, workspace,
+                                       workspace_bytes, status, HEXGNN_QBWD_DATA | HEXGNN_QBWD_SMALL | HEXGNN_QBWD_HIDDEN,
+                                       1, total_layers, stream_);
+}
 
 #ifdef HEXGNN_STAMPS
 // profiling builds only: copies the s_memtime stamps of the exact-fp32 fused kernels to `out` (host pointer)

@@ -859,7 +859,7 @@ static int dw_slices_fp32(int n, int hidden_layers) {
     int s = rounds * kSlots / nh;
     if (s > n / 256) s = n / 256;
     if (s < base) s = base;
-    if (s > 64) s = 64;
+    if (s > kDwMaxSlices) s = kDwMaxSlices;
     return s;
 }
 int dw_slices_for(int n, int hidden_layers, int math) {
@@ -883,7 +883,7 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { b->pair_off[i][j] = off; off += slab; }
     b->S = dw_slices_fp32(n, p.L - (p.small_first ? 1 : 0));
     b->rps = dw_rows_per_slice(n, b->S);
-    b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * b->S * p.hp * (2 * p.hp + 1), 256);
+    b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * kDwMaxSlices * p.hp * (2 * p.hp + 1), 256);
     b->rps0 = 128;
     b->S0 = (n + b->rps0 - 1) / b->rps0; if (b->S0 < 1) b->S0 = 1;
     b->part0_off = off; off += align_up(sizeof(float) * (size_t)b->S0 * p.hp * 17, 256);
@@ -920,10 +920,12 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
 int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const BwdPlan& b, const float* x,
                         int x_stride, const float* acts, const char* sv, const float* G, float* const* d_wl,
                         float* const* d_bl, float* const* d_wr, float* part, float* part0, hipStream_t st,
-                        int math, const unsigned* xmax, const unsigned* gmax, bool hidden_only_no_reduce) {
+                        int math, const unsigned* xmax, const unsigned* gmax, bool hidden_only_no_reduce,
+                        int layer_lo, int layer_hi) {
     const size_t slab = (size_t)n * p.hp;
-    const int first_hidden = p.small_first ? 1 : 0;
-    const int nh = p.L - first_hidden;
+    const int lo = layer_lo < 0 ? (p.small_first ? 1 : 0) : layer_lo;
+    const int first_hidden = lo;                    // first layer of this launch (hidden-input layers only)
+    const int nh = (layer_hi < 0 ? p.L : layer_hi) - lo;
     if (nh > 0) {
         DwArgs da;
         DwReduceArgs ra;
@@ -950,7 +952,7 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
         const int tot = hidden * (2 * hidden + 1);
         if (!hidden_only_no_reduce) sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
     }
-    if (p.small_first && !hidden_only_no_reduce) {
+    if (p.small_first && !hidden_only_no_reduce && layer_lo < 0) {
         sage_first_dw_kernel<<<b.S0, 256, 0, st>>>(n, c_in, p.hp, b.rps0, G, (const float*)(sv + p.agg_off[0]), x,
                                                    x_stride, part0);
         const int tot = hidden * (2 * c_in + 1);

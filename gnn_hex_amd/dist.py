@@ -32,6 +32,7 @@ class GradSync:
         self.check = check
         self._flat: Optional[torch.Tensor] = None
         self._key = None
+        self._segments = []          # (data_ptr, numel, work) of the segments reduced from inside the backward
 
     def _bucket(self, active: List[torch.nn.Parameter]) -> torch.Tensor:
         key = tuple(id(p) for p in active)
@@ -61,6 +62,46 @@ class GradSync:
             off += g.numel()
         return torch.empty(0, dtype=torch.float32, device=g0.device).set_(st, start, (off - start,))
 
+    # ---- overlap with the backward -----------------------------------------------------------
+    def enable_overlap(self, enabled: bool = True) -> None:
+        """Start the all-reduce of a gradient segment from INSIDE the fused backward, as soon as that segment's kernels
+        are enqueued (gnn_hex_amd.ops.set_grad_stage_hook): the upper layers' + head's half of the flat buffer travels
+        over xGMI while the lower layers' weight-gradient GEMM still computes; ``all_reduce()`` then only waits.  With
+        RCCL the collective runs on the process group's own stream (async work, 1/world folded in as ReduceOp.AVG); the
+        gloo rehearsal backend reduces the segment synchronously through the host (same results, no overlap)."""
+        from . import ops
+        ops.set_grad_stage_hook(self._on_segment if enabled else None)
+
+    def _on_segment(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        world = dist.get_world_size(self.group) if dist.is_initialized() else 1
+        if world == 1 or hi <= lo:
+            return
+        seg = flat[lo:hi]
+        work = None
+        if flat.is_cuda and dist.get_backend(self.group) != "gloo":
+            op = dist.ReduceOp.AVG if self.average else dist.ReduceOp.SUM
+            work = dist.all_reduce(seg, op=op, group=self.group, async_op=True)
+        else:
+            self._reduce(seg, world)
+        self._segments.append((seg.data_ptr(), seg.numel(), work))
+
+    def _finish_segments(self, active: List[torch.nn.Parameter]) -> Optional[int]:
+        """Wait for the segments reduced during the backward; returns their element count if they are exactly this
+        step's gradients (one contiguous flat buffer), else None (the caller then reduces the remaining way)."""
+        segs, self._segments = self._segments, []
+        if not segs:
+            return None
+        for _, _, work in segs:
+            if work is not None:
+                work.wait()               # the current stream waits for the collective's stream
+        flat = self._adopt_flat(active)
+        covered = sum(n for _, n, _ in segs)
+        lo = min(p for p, _, _ in segs)
+        if flat is None or flat.data_ptr() != lo or flat.numel() != covered:
+            raise RuntimeError("GradSync: gradient segments were reduced during the backward, but they are not this step's "
+                               "gradient buffer (more than one backward per all_reduce()?)")
+        return covered
+
     def all_reduce(self) -> int:
         """Sum (or average) gradients over the process group in place.  Returns the bucket size in elements."""
         active = [p for p in self.params if p.grad is not None]
@@ -68,9 +109,13 @@ class GradSync:
             return 0
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world == 1:
+            self._segments = []
             return sum(p.numel() for p in active)
         if self.check:
             self._check_same_set(active, world)
+        done = self._finish_segments(active)
+        if done is not None:
+            return done
         flat = self._adopt_flat(active)
         if flat is not None:            # zero-copy: one collective on the buffer the backward wrote
             self._reduce(flat, world)

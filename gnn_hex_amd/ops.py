@@ -361,6 +361,18 @@ def set_fused(enabled: bool) -> None:
     _FUSED_ENABLED = bool(enabled)
 
 
+_GRAD_STAGE_HOOK = None
+
+
+def set_grad_stage_hook(fn) -> None:
+    """``fn(flat, lo, hi)`` is called INSIDE the fused backward as soon as the gradient elements ``flat[lo:hi]`` are final
+    (their kernels are enqueued on the current stream) while the weight-gradient GEMM of the remaining layers is still
+    to be enqueued: ``gnn_hex_amd.dist.GradSync.enable_overlap`` starts that segment's all-reduce there.
+    None switches the staging off (one backward call, one reduce launch)."""
+    global _GRAD_STAGE_HOOK
+    _GRAD_STAGE_HOOK = fn
+
+
 def qnet_fused_supported(c_in: int, hidden: int, max_nodes: int) -> bool:
     return _FUSED_ENABLED and bool(_lib.lib().hexgnn_qnet_supported(int(c_in), int(hidden), int(max_nodes)))
 
@@ -451,13 +463,24 @@ class QNetFusedFn(torch.autograd.Function):
         d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if ctx.grad_sink is not None else None
         ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
         ws = _bytes(ws_bytes, dev)
-        _lib.check(L.hexgnn_qnet_backward(
-            n, b, c_in, hidden, tot, body_layers, mode, ctx.math, gptr.data_ptr(), gs.rowptr_t.data_ptr(),
-            gs.col_t.data_ptr(), gs.invdeg.data_ptr(), x.data_ptr(), x_stride, acts.data_ptr(), saved.data_ptr(),
-            wpack.data_ptr(), tail[0].data_ptr(), tail[2].data_ptr(), tail[4].data_ptr(), dq.data_ptr(),
-            d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
-            vp_arr(*cp[0::3]), vp_arr(*cp[1::3]), vp_arr(*cp[2::3]), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5],
-            ws.data_ptr(), ws_bytes, status.data_ptr(), _stream()), "hexgnn_qnet_backward")
+        common = (n, b, c_in, hidden, tot, body_layers, mode, ctx.math, gptr.data_ptr(), gs.rowptr_t.data_ptr(),
+                  gs.col_t.data_ptr(), gs.invdeg.data_ptr(), x.data_ptr(), x_stride, acts.data_ptr(), saved.data_ptr(),
+                  wpack.data_ptr(), tail[0].data_ptr(), tail[2].data_ptr(), tail[4].data_ptr(), dq.data_ptr(),
+                  d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
+                  vp_arr(*cp[0::3]), vp_arr(*cp[1::3]), vp_arr(*cp[2::3]), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5],
+                  ws.data_ptr(), ws_bytes, status.data_ptr())
+        hook = _GRAD_STAGE_HOOK
+        if hook is None or tot < 3 or mode == 2:
+            _lib.check(L.hexgnn_qnet_backward(*common, _stream()), "hexgnn_qnet_backward")
+        else:
+            # two stages: the upper half of the hidden layers + everything small first -- with the head tail they are the
+            # TAIL of the flat buffer, handed to the hook (all-reduce on the collective's own stream) while the lower
+            # half's weight-gradient GEMM is enqueued behind them; then the head of the buffer
+            mid = 1 + tot // 2
+            _lib.check(L.hexgnn_qnet_backward_staged(*common, 1 | 2 | 4, mid, tot, _stream()), "hexgnn_qnet_backward_staged")
+            hook(flat, offs[3 * mid], total)
+            _lib.check(L.hexgnn_qnet_backward_staged(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_staged")
+            hook(flat, 0, offs[3 * mid])
         cg, tg = grads[:3 * tot], grads[3 * tot:]
         if ctx.grad_sink is not None:
             ctx.grad_sink(d_emb[:, :hidden])

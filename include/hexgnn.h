@@ -173,6 +173,27 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
                          float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
                          void* workspace, size_t workspace_bytes, int* status, hexgnn_stream_t stream);
 
+/* The same backward in stages, so that the gradient all-reduce of the layers that are finished can run (RCCL, its own
+ * stream) while the weight-gradient GEMM of the remaining layers still computes (the reference has no
+ * collective, README.md:53).  stages: bit set of
+ *   HEXGNN_QBWD_DATA    the data chain (G of every layer, per-graph partials); must come first
+ *   HEXGNN_QBWD_SMALL   per-graph partials -> gradients of the raw first layer, the advantage linear and the value MLP
+ *   HEXGNN_QBWD_HIDDEN  weight-gradient GEMM + slice reduce of the hidden-input layers [layer_lo, layer_hi), 1 <= lo <= hi <= total_layers
+ * Every call takes the full argument list of hexgnn_qnet_backward (same workspace); the stages of one step may be issued in
+ * any number of calls, each layer range once.  hexgnn_qnet_backward == all three stages over [1, total_layers). */
+#define HEXGNN_QBWD_DATA 1
+#define HEXGNN_QBWD_SMALL 2
+#define HEXGNN_QBWD_HIDDEN 4
+int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+                                const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                                const float* lin_w, const float* v0_w, const float* v1_w,
+                                const float* dq, const float* d_out_v, float* d_embeds,
+                                float* const* d_wl, float* const* d_bl, float* const* d_wr,
+                                float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
+                                void* workspace, size_t workspace_bytes, int* status,
+                                int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream);
+
 /* ---- batched board-graph builder: num_envs lock-stepped Hex / Shannon node-switching games on the device.
  *      Replaces Hex_game / Node_switching_game (graph_game/graph_tools_games.py:20-29,
  *      graph_game/shannon_node_switching_game.py:80-205, graph_game/hex_board_game.py:214-233) as driven by

@@ -1,7 +1,8 @@
 """Curriculum growth and checkpoints ON THE DEVICE: after ``grow_depth`` / ``grow_width``
 (GN0/models.py:166-238,336-360,494-508) the HIP path must (a) still compute the function it computed before -- identity
-layers and zero-padded widening preserve the network's output, the property the reference's curriculum relies on -- and
-(b) agree with an oracle network BUILT at the grown shape and loaded with the grown state dict: Q and every gradient at
+layers preserve Q, zero-padded widening preserves the advantage stream (the value MLP is widened by a plain block copy,
+GN0/models.py:51-73, which moves the [sum|max|min|mean] segments of its input: the reference's value output changes
+there, and the mirror reproduces exactly that) -- and (b) agree with an oracle network BUILT at the grown shape and loaded with the grown state dict: Q and every gradient at
 1e-4, on the fused (both arithmetic modes) and the layer-major kernels.  A checkpoint in the reference's format
 ({"state_dict", "args"}) written from the grown model loads into a fresh mirror and runs."""
 import pytest
@@ -54,6 +55,11 @@ def _parity(hip, ref, data):
     return q
 
 
+def _adv(hip, data):
+    with torch.no_grad():
+        return hip(*[t.cuda() for t in data[:4]], advantages_only=True)
+
+
 def _data(sizes, maker):
     x, ei, batch, ptr = batch_tensors("D1", sizes, maker=maker)
     sel, tgt = sel_and_targets(ptr)
@@ -65,6 +71,7 @@ def test_grow_depth_then_width_on_device(maker):
     hip, ref = make_pair(4, 35, seed=41)
     data = _data([7, 5, 11, 7, 9, 6], maker)
     q0 = _parity(hip, ref, data)
+    a0 = _adv(hip, data)
     # depth: + 2 identity layers (lin_l = 0, lin_r = I) -> same function, deeper network
     hip.grow_depth(2)
     assert len(hip.gnn.convs) == 6
@@ -73,12 +80,12 @@ def test_grow_depth_then_width_on_device(maker):
     # width 35 -> 48: old weights in the top-left blocks, new input columns zero -> same function, wider network
     hip.grow_width(48)
     assert hip.gnn.hidden_channels == 48 and hip.maker_head.linear.weight.shape == (1, 48)
-    q2 = _parity(hip, _oracle_like(hip, 6, 48), data)
-    assert (q2 - q0).abs().max().item() < 1e-5
+    _parity(hip, _oracle_like(hip, 6, 48), data)
+    assert (_adv(hip, data) - a0).abs().max().item() < 1e-5
     # width 48 -> 128: beyond the fused kernels' 112 columns, the layer-major kernels take over on every path
     hip.grow_width(128)
     q3 = _parity(hip, _oracle_like(hip, 6, 128), data)
-    assert (q3 - q0).abs().max().item() < 1e-5
+    assert (_adv(hip, data) - a0).abs().max().item() < 1e-5
     # training continues on the grown network: one SGD step moves the output, parity still holds afterwards
     ref3 = _oracle_like(hip, 6, 128)
     for m in (hip, ref3):
@@ -95,10 +102,11 @@ def test_gnn_l_grow_width_110_to_128():
     """The BASELINE GNN-L shape growing past the fused kernels' width (hidden 110 -> 128)."""
     hip, ref = make_pair(15, 110, seed=42)
     data = _data([11, 11, 7, 11], True)
-    q0 = _parity(hip, ref, data)
+    _parity(hip, ref, data)
+    a0 = _adv(hip, data)
     hip.grow_width(128)
-    q1 = _parity(hip, _oracle_like(hip, 15, 128), data)
-    assert (q1 - q0).abs().max().item() < 1e-5
+    _parity(hip, _oracle_like(hip, 15, 128), data)
+    assert (_adv(hip, data) - a0).abs().max().item() < 1e-5
 
 
 def test_checkpoint_of_a_grown_model_loads_and_runs(tmp_path):
