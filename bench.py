@@ -73,6 +73,13 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="capture each step (maker batch / breaker batch) into a HIP graph and replay it; the gradient "
                          "all-reduce stays outside the graph")
+    ap.add_argument("--preheat-ms", type=float, default=150.0,
+                    help="untimed device preheat before the W warm-up steps: the step is repeated until this much wall time "
+                         "has passed, so that the clocks, the caching allocator and the TLBs are in their steady state when "
+                         "the K timed steps start (a cold start runs its first 20 steps ~5 %% slower); 0 disables it")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: one all-reduce after the backward instead of the staged backward whose first gradient "
+                         "segment is reduced while the rest of the weight-gradient GEMM computes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the informational split-precision timing (clean profiles)")
     args = ap.parse_args()
@@ -115,6 +122,9 @@ def main():
     B = args.batch
     hip, ref = make_pair(num_layers, hidden, seed=0, device=dev)   # identical replicas on every rank
     sync = GradSync(hip.parameters())
+    overlap = world > 1 and not args.no_overlap and not args.graph
+    if overlap:
+        sync.enable_overlap()
 
     # two resident batches (maker to move / breaker to move), alternated per step; each rank draws its own
     # graphs for D1 (seed offset by rank), D0 is the same start position everywhere.
@@ -186,7 +196,22 @@ def main():
         if rank == 0:
             print("[bench] " + msg, file=sys.stderr, flush=True)
 
-    note("setup done (%s, %d ranks); warm-up" % (label, world))
+    note("setup done (%s, %d ranks); preheat + warm-up" % (label, world))
+    preheat_steps = 0
+    if args.preheat_ms > 0:
+        # same number of steps on every rank (collectives inside): chunks of 16 steps until rank 0's clock says stop
+        t_pre = time.perf_counter()
+        while True:
+            for i in range(16):
+                step(i)
+            preheat_steps += 16
+            torch.cuda.synchronize()
+            go = torch.tensor([1.0 if (time.perf_counter() - t_pre) * 1e3 < args.preheat_ms else 0.0])
+            if world > 1:
+                go = go.to(dev) if args.backend == "nccl" else go
+                dist.broadcast(go, 0)
+            if float(go.item()) == 0.0 or preheat_steps >= 4096:
+                break
     for i in range(args.warmup):
         step(i)
     barrier()
@@ -220,6 +245,7 @@ def main():
         replicas_identical = all(torch.equal(g, gathered[0]) for g in gathered)
         if not replicas_identical:
             raise SystemExit("rank %d: parameter replicas diverged after the gradient all-reduce: %s" % (rank, gathered))
+        sync.enable_overlap(False)       # the rank-0-only passes below must not start collectives
 
     out = None
     if rank == 0:
@@ -303,7 +329,8 @@ def main():
 
         out = {
             "metric": "board-graphs/sec fwd+bwd", "value": value, "unit": "graphs/s", "n_gpus": world,
-            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "steps": args.steps, "warmup": args.warmup, "preheat_steps": preheat_steps, "ms_per_step": ms_per_step,
+            "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.math == "fp32" else "f32 operands split into scaled f16 hi+lo (f16x3 MFMA, 22-bit products), f32 accumulate",
             "data": "synthetic",
@@ -316,6 +343,7 @@ def main():
         if world > 1:
             out["replicas_identical"] = replicas_identical
             out["config"]["collective"] = {"backend": "rccl" if args.backend == "nccl" else "gloo (rehearsal)",
+                                           "overlapped_with_backward": overlap,
                                            "bucket_bytes": 4 * sum(p.numel() for p in plist if p.grad is not None)}
         print(json.dumps(out))
     if world > 1:

@@ -363,13 +363,18 @@ __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const in
         __syncthreads();
         for (int j = threadIdx.x; j < kk; j += 256) {
             const int i = s_i[j];
-            if (i < 0) continue;
+            if (i < 0) continue;                       // not in this workgroup's range (most entries)
+            // one pass over the chunk without early exits (independent LDS reads pipeline; a dependent early-exit loop
+            // cost 20 us here): is an earlier entry naming the same node? sum of the later ones, in list order
             bool first = true;
-            for (int q = 0; q < j && first; ++q) first = s_i[q] != i;
-            if (!first) continue;
             float acc = s_g[j];
-            for (int q = j + 1; q < kk; ++q) if (s_i[q] == i) acc += s_g[q];
-            dq[i] += acc;          // only this thread touches dq[i] in this chunk; chunks are separated by the barrier
+#pragma unroll 8
+            for (int q = 0; q < kk; ++q) {
+                const bool same = s_i[q] == i;
+                first = first && !(same && q < j);
+                acc += (same && q > j) ? s_g[q] : 0.f;
+            }
+            if (first) dq[i] += acc;   // only this thread touches dq[i] in this chunk; chunks are separated by the barrier
         }
     }
 }

@@ -29,8 +29,9 @@ __global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const 
     for (int i = threadIdx.x; i < k; i += 1024) {
         const int slot = in_lds ? s_idx[i] : idx[i];
         if (slot < 0 || slot >= cap) continue;               // out-of-range slots are ignored
-        bool last = true;
-        for (int j = i + 1; j < k && last; ++j) last = (in_lds ? s_idx[j] : idx[j]) != slot;
+        bool last = true;           // no early exit: independent LDS reads pipeline, a dependent exit test serialises them
+#pragma unroll 8
+        for (int j = i + 1; j < k; ++j) last = last && (in_lds ? s_idx[j] : idx[j]) != slot;
         if (!last) continue;
         const int leaf = cap + slot;
         sum_tree[leaf] = prio_alpha[i];
