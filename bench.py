@@ -70,9 +70,14 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="collective backend for N > 1 (nccl = RCCL over xGMI; gloo only to rehearse the multi-rank path "
                          "on a box with fewer GPUs than ranks)")
-    ap.add_argument("--graph", action="store_true",
-                    help="capture each step (maker batch / breaker batch) into a HIP graph and replay it; the gradient "
-                         "all-reduce stays outside the graph")
+    ap.add_argument("--graph", dest="graph", action="store_true", default=None,
+                    help="capture each step (maker batch / breaker batch) into a HIP graph and replay it (gnn_hex_amd.graphs."
+                         "GraphedStep: every kernel of the step still runs per replay); the gradient all-reduce stays "
+                         "outside the graph.  Default for --mode train: the step is a fixed sequence of ~10 launches, and "
+                         "replaying it removes the host from the loop (GNN-S is host-bound in eager mode)")
+    ap.add_argument("--eager", dest="graph", action="store_false",
+                    help="issue every step through Python / torch.autograd (what an unmodified train.py does); with N > 1 "
+                         "this also overlaps the all-reduce with the backward")
     ap.add_argument("--preheat-ms", type=float, default=150.0,
                     help="untimed device preheat before the W warm-up steps: the step is repeated until this much wall time "
                          "has passed, so that the clocks, the caching allocator and the TLBs are in their steady state when "
@@ -83,6 +88,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-split", action="store_true", help="skip the informational split-precision timing (clean profiles)")
     args = ap.parse_args()
+    if args.graph is None:
+        args.graph = args.mode == "train"
 
     ndev = torch.cuda.device_count()       # does not initialise HIP
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -41,6 +41,9 @@ _SIGS = {
     "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, sz, vp]),
+    "hexgnn_graph_layernorm_workspace_bytes": (sz, [ci]),
+    "hexgnn_graph_layernorm_forward": (ci, [ci, ci, vp, vp, vp, C.c_float, ci, vp, vp, vp, sz, vp]),
+    "hexgnn_graph_layernorm_backward": (ci, [ci, ci, vp, vp, vp, vp, vp, C.c_float, ci, vp, vp, vp, vp, sz, vp]),
     "hexgnn_qnet_supported": (ci, [ci, ci, ci]),
     "hexgnn_qnet_saved_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_forward": (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,

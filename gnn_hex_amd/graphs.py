@@ -20,8 +20,9 @@ as the capture ends, which also returns its saved buffers to the graph's pool).
 ROCm 7.2 runtime bug: with the default AQL packet capture of hipGraphExec, eager kernel launches between the replays
 of two instantiated graphs corrupt the second graph's kernel arguments (garbage pointers -> GPU memory fault; found
 with tests/test_gpu_model.py::test_graphed_step_replays_bit_identical_gradients).  Export
-``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` BEFORE the HIP runtime initialises (``bench.py`` and ``tests/conftest.py`` do;
-``GraphedStep`` refuses to run without it).
+``DEBUG_CLR_GRAPH_PACKET_CAPTURE=0`` BEFORE the HIP runtime initialises: ``import gnn_hex_amd`` does (HIP starts lazily at
+the first device call, so importing the package before touching the GPU is enough); ``GraphedStep`` refuses to run when
+HIP was already up without it.
 """
 from __future__ import annotations
 
@@ -43,9 +44,11 @@ def _detach(out):
 class GraphedStep:
     def __init__(self, fn: Callable[[], object], params: Optional[Iterable[torch.nn.Parameter]] = None,
                  warmup: int = 3, pool=None):
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+        import gnn_hex_amd
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0" or not gnn_hex_amd._graph_env_ok:
             raise RuntimeError("GraphedStep needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 in the environment before the HIP "
-                               "runtime starts (ROCm 7.2 hipGraph packet-capture bug, see gnn_hex_amd/graphs.py)")
+                               "runtime starts (ROCm 7.2 hipGraph packet-capture bug, see gnn_hex_amd/graphs.py): "
+                               "`import gnn_hex_amd` sets it, but here HIP was already initialised without it")
         self.params: List[torch.nn.Parameter] = list(params) if params is not None else []
         gc.collect()            # unreachable autograd graphs (and their cached AccumulateGrad nodes) go now
         side = torch.cuda.Stream()

@@ -10,12 +10,15 @@ of libhexgnn.so (gnn_hex_amd/ops.py).  CUDA(HIP) tensors only -- there is no CPU
 ``--noisy_dqn=True`` (FactorizedNoisyLinear as the heads' advantage linear, GN0/models.py:84-141,331-334) is
 supported on every kernel path: the effective weight ``mu + sigma * eps`` is formed per forward and handed to the
 kernels like a plain Linear; autograd carries the kernel's gradient back to ``mu`` and ``sigma``.
-Out of scope here (raise NotImplementedError): ``--norm=True`` (torch_geometric LayerNorm in its whole-batch
-"graph" mode / CachedGraphNorm) and the other model families of the reference factory; all BASELINE configs run
-``--norm=False --noisy_dqn=False`` (README.md:5,7).
+``--norm=True`` (torch_geometric LayerNorm, which the model calls in its whole-batch "graph" form, GN0/models.py:286-287,
+550-551,935,945) runs on the layer-major kernels: one SAGE layer without ReLU, then the ``hexgnn_graph_layernorm`` kernels
+with the ReLU fused; a batch-global statistic rules the per-graph fused kernels out.
+Out of scope here (raise NotImplementedError): CachedGraphNorm (``cached_norm=True``, never set by this factory) and the
+other model families of the reference factory; all BASELINE configs run ``--norm=False --noisy_dqn=False`` (README.md:5,7).
 """
 from __future__ import annotations
 
+import copy
 from argparse import Namespace
 from math import sqrt
 from typing import Optional, Tuple, Union
@@ -122,6 +125,35 @@ class FactorizedNoisyLinear(torch.nn.Module):
         return torch.nn.functional.linear(input, w, b)
 
 
+class LayerNorm(torch.nn.Module):
+    """torch_geometric.nn.norm.LayerNorm (pyg 2.2.0; imported at GN0/models.py:8, built at 935,945 for --norm=True) in the
+    one call form the model uses: mode "graph" and NO batch vector (GN0/models.py:286-287,550-551), i.e. normalisation
+    over all nodes and channels of the whole batch, ``(x - mean) / (std + eps) * weight + bias``.  Evaluated by the
+    ``hexgnn_graph_layernorm_*`` kernels; ``_relu`` fuses the activation CachifiedGNN applies after the norm."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5, affine: bool = True, mode: str = "graph"):
+        super().__init__()
+        if mode != "graph" or not affine:
+            raise NotImplementedError("LayerNorm: the model uses mode='graph', affine=True")
+        self.in_channels = in_channels
+        self.eps = eps
+        self.mode = mode
+        self.weight = torch.nn.Parameter(torch.ones(in_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(in_channels))
+
+    def reset_parameters(self):
+        torch.nn.init.ones_(self.weight)
+        torch.nn.init.zeros_(self.bias)
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, _relu: bool = False) -> Tensor:
+        if batch is not None:
+            raise NotImplementedError("LayerNorm with a batch vector is not on the model's path (GN0/models.py:287)")
+        return ops.graph_layernorm(x, self.weight, self.bias, self.eps, _relu)
+
+    def __repr__(self):
+        return "%s(%d, mode=%s)" % (self.__class__.__name__, self.in_channels, self.mode)
+
+
 class SAGEConv(torch.nn.Module):
     """Parameter holder for pyg SAGEConv(aggr='mean', root_weight=True, bias=True): ``lin_l`` (with bias)
     acts on the neighbour mean, ``lin_r`` (no bias) on the root (GN0/torch_script_models.py:52-73)."""
@@ -154,8 +186,8 @@ class GraphSAGE(torch.nn.Module):
     def __init__(self, in_channels: int, hidden_channels: int, num_layers: int, out_channels: Optional[int] = None,
                  dropout: float = 0.0, act="relu", norm=None, jk=None, **kwargs):
         super().__init__()
-        if norm is not None:
-            raise NotImplementedError("--norm=True is outside the accelerated hot path (README.md:5,7 use --norm=False)")
+        if norm is not None and not isinstance(norm, LayerNorm):
+            raise NotImplementedError("only norm=None or the LayerNorm of --norm=True (GN0/models.py:935,945)")
         if act != "relu" or jk is not None or dropout != 0.0:
             raise NotImplementedError("only act='relu', jk=None, dropout=0 (the modern_two_headed configuration)")
         self.in_channels = in_channels
@@ -176,6 +208,10 @@ class GraphSAGE(torch.nn.Module):
             c = hidden_channels
         self.convs.append(self.init_conv(c, self.out_channels, **kwargs))
         self.norms = None
+        if norm is not None:        # BasicGNN: one norm per hidden layer (CachifiedGNN adds the one of the last layer)
+            self.norms = ModuleList()
+            for _ in range(num_layers - 1):
+                self.norms.append(copy.deepcopy(norm))
 
     def init_conv(self, in_channels: int, out_channels: int, **kwargs) -> SAGEConv:
         return SAGEConv(in_channels, out_channels, **kwargs)
@@ -204,10 +240,16 @@ def cachify_gnn(gnn):
             self.has_cache = False
             if self.has_output:
                 raise NotImplementedError("out_channels != None (linear last layer) is not on the hot path")
+            if cached_norm:
+                raise NotImplementedError("cached_norm=True (CachedGraphNorm) is not used by modern_two_headed")
+            if self.norms is not None:      # final norm after the last hidden layer (GN0/models.py:158-162)
+                self.norms.append(copy.deepcopy(self.norms[0] if len(self.norms) > 0 else kwargs["norm"]))
 
         def grow_depth(self, additional_layers):
             """GN0/models.py:166-185: append identity layers (lin_l = 0, lin_r = I)."""
             assert not self.has_output
+            if self.norms is not None:
+                raise NotImplementedError("grow_depth with --norm=True")
             self.num_layers += additional_layers
             device = self.convs[0].lin_l.weight.device
             for _ in range(additional_layers):
@@ -221,6 +263,8 @@ def cachify_gnn(gnn):
         def grow_width(self, new_width, new_in_channels=None):
             """GN0/models.py:187-238: widen every layer, old weights in the top-left block, new input
             columns zero, new output rows freshly initialised."""
+            if self.norms is not None:
+                raise NotImplementedError("grow_width with --norm=True")
             device = self.convs[0].lin_l.weight.device
             old_convs = self.convs
             old_in_channels = self.in_channels
@@ -254,6 +298,7 @@ def cachify_gnn(gnn):
         def export_norm_cache(self):
             if self.norms is None:
                 return
+            assert self.has_cache       # as the reference: only a cached norm (never built here) ever sets it
             raise NotImplementedError
 
         def import_norm_cache(self, mean_cache, var_cache):
@@ -263,9 +308,16 @@ def cachify_gnn(gnn):
 
         def forward(self, x: Tensor, edge_index, *, edge_weight=None, edge_attr=None, set_cache: bool = False,
                     _graph: Optional[ops.GraphStructure] = None) -> Tensor:
-            """conv -> relu for every layer (GN0/models.py:261-294 with has_output False, norms None)."""
+            """conv -> [norm] -> relu for every layer (GN0/models.py:261-294 with has_output False)."""
             gs = _graph if _graph is not None else ops.GraphStructure(edge_index, x.shape[0])
-            return ops.sage_stack(x, gs, self.in_channels, self.hidden_channels, self.convs)
+            if self.norms is None:
+                return ops.sage_stack(x, gs, self.in_channels, self.hidden_channels, self.convs)
+            # --norm=True: the whole-batch statistics sit between a layer's contraction and its activation, so the stack
+            # runs layer by layer: SAGE layer without ReLU, then LayerNorm with the ReLU fused
+            for conv, norm in zip(self.convs, self.norms):
+                x = conv(x, edge_index, _graph=gs)
+                x = norm(x, _relu=True)
+            return x
 
     return CachifiedGNN
 
@@ -346,8 +398,9 @@ class DuellingTwoHeaded(torch.nn.Module):
         super().__init__()
         self.gnn = GNN(**gnn_kwargs)
         if "norm" in gnn_kwargs and gnn_kwargs["norm"]:
-            raise NotImplementedError("--norm=True is outside the accelerated hot path")
-        self.after_embed_norm = None
+            self.after_embed_norm = copy.deepcopy(gnn_kwargs["norm"])
+        else:
+            self.after_embed_norm = None
         self.supports_cache = hasattr(self.gnn, "supports_cache") and self.gnn.supports_cache
         self.value_activation = Tanh()
         self.advantage_activation = Tanh()
@@ -424,7 +477,7 @@ class DuellingTwoHeaded(torch.nn.Module):
             max_nodes = int((gptr[1:] - gptr[:-1]).max()) if b > 0 else 0     # host sync (no size hint given)
         h = self.gnn.hidden_channels
         if max_nodes is not None and ops.qnet_fused_supported(self.gnn.in_channels, h, max_nodes) \
-                and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels:
+                and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels and self.gnn.norms is None:
             params = self._fused_params(head)
             if isinstance(head.linear, FactorizedNoisyLinear):      # effective weights are formed per forward
                 params = params[:-6] + list(head._lin_params()) + params[-4:]
@@ -440,6 +493,8 @@ class DuellingTwoHeaded(torch.nn.Module):
 
         # general layer-major path (any graph size, hidden <= 128)
         embeds = self.gnn(x2, edge_index, set_cache=set_cache, _graph=gs)
+        if self.after_embed_norm is not None:
+            embeds = self.after_embed_norm(embeds)
         # values only (as the fused path): keeping the differentiable tensor on the module would keep the whole autograd
         # graph -- and its per-parameter AccumulateGrad nodes -- alive across steps (see gnn_hex_amd/graphs.py)
         self.final_conv_acts = embeds.detach()
@@ -486,16 +541,15 @@ class DuellingTwoHeaded(torch.nn.Module):
 def get_pre_defined(name, args: Optional[Namespace] = None) -> torch.nn.Module:
     """GN0/models.py:892-980.  Only ``modern_two_headed`` (the RainbowDQN GNN of README.md:5,7) is built."""
     if name == "modern_two_headed":
-        if getattr(args, "norm", False):
-            raise NotImplementedError("--norm=True is outside the accelerated hot path")
+        use_norm = bool(getattr(args, "norm", False))
         return DuellingTwoHeaded(
             cachify_gnn(GraphSAGE), HeadNetwork,
             gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
-                            cached_norm=False, norm=None, act="relu"),
+                            cached_norm=False, norm=LayerNorm(args.hidden_channels) if use_norm else None, act="relu"),
             head_kwargs=dict(GNN=cachify_gnn(GraphSAGE), value_head_type="mlp",
                              value_aggr_types=("sum", "max", "min", "mean"),
                              num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2,
                              noisy_dqn=args.noisy_dqn, noise_sigma=args.noisy_sigma0, cached_norm=False,
-                             norm=None, act="relu"))
+                             norm=LayerNorm(args.hidden_channels) if use_norm else None, act="relu"))
     raise NotImplementedError(
         "%r: only 'modern_two_headed' is part of the MI355X hot path (SURVEY.md section 8)" % (name,))

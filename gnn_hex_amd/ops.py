@@ -274,6 +274,55 @@ def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, conv
     return out
 
 
+class GraphLayerNormFn(torch.autograd.Function):
+    """torch_geometric LayerNorm(mode="graph") without a batch vector: normalise over ALL nodes and channels of the batch,
+    affine, optional fused ReLU (GN0/models.py:286-289 norm -> act).  C ABI ``hexgnn_graph_layernorm_*``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps: float, relu: bool):
+        L = _lib.lib()
+        hidden = int(x.shape[1])
+        hp = padded_width(hidden)
+        n = int(x.shape[0])
+        xp = as_padded(x, hidden, trust_pads=False)
+        w = weight if (weight.is_contiguous() and weight.dtype == torch.float32) else weight.float().contiguous()
+        b = bias if (bias.is_contiguous() and bias.dtype == torch.float32) else bias.float().contiguous()
+        y = torch.empty((n, hp), dtype=torch.float32, device=x.device)
+        stats = torch.empty(2, dtype=torch.float32, device=x.device)
+        ws_bytes = L.hexgnn_graph_layernorm_workspace_bytes(hidden)
+        ws = _bytes(ws_bytes, x.device)
+        _lib.check(L.hexgnn_graph_layernorm_forward(n, hidden, xp.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps),
+                                                    int(relu), y.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                    _stream()), "hexgnn_graph_layernorm_forward")
+        ctx.dims = (n, hidden, hp, float(eps), bool(relu))
+        ctx.bufs = (xp, y, w, stats)
+        return _logical(y, hidden)
+
+    @staticmethod
+    def backward(ctx, dy):
+        L = _lib.lib()
+        n, hidden, hp, eps, relu = ctx.dims
+        xp, y, w, stats = ctx.bufs
+        dyp = as_padded(dy, hidden, trust_pads=True)
+        dx = torch.empty((n, hp), dtype=torch.float32, device=xp.device)
+        dw = torch.empty(hidden, dtype=torch.float32, device=xp.device)
+        db = torch.empty(hidden, dtype=torch.float32, device=xp.device)
+        ws_bytes = L.hexgnn_graph_layernorm_workspace_bytes(hidden)
+        ws = _bytes(ws_bytes, xp.device)
+        _lib.check(L.hexgnn_graph_layernorm_backward(n, hidden, xp.data_ptr(), y.data_ptr(), w.data_ptr(), stats.data_ptr(),
+                                                     dyp.data_ptr(), eps, int(relu), dx.data_ptr(), dw.data_ptr(),
+                                                     db.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                   "hexgnn_graph_layernorm_backward")
+        return _logical(dx, hidden), dw, db, None, None
+
+
+def graph_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, relu: bool = False):
+    _require_cuda(x, "x")
+    out = GraphLayerNormFn.apply(x, weight, bias, eps, relu)
+    out._hexgnn_hp = padded_width(int(x.shape[1]))
+    return out
+
+
 # ------------------------------------------------------------------------------------------------
 # head tail (advantage linear + pooling + value MLP + dueling combine)
 # ------------------------------------------------------------------------------------------------

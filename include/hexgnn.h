@@ -134,6 +134,21 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
                          float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
                          void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
 
+/* ---- whole-batch LayerNorm (--norm=True): torch_geometric 2.2.0 LayerNorm(hidden, mode="graph") as
+ *      CachifiedGNN.forward / DuellingTwoHeaded.forward call it, WITHOUT a batch vector (GN0/models.py:8,286-287,550-551,
+ *      935,945): mean and biased std over ALL n x hidden elements, y = (x - mean) / (std + eps) * weight + bias, then the
+ *      activation CachifiedGNN applies after the norm (relu != 0).  x / y / dy / dx: padded layout [n][HP]; stats [2]
+ *      receives (mean, 1/(std+eps)) for the backward call.  Deterministic (fp64 block partials, fixed order). ---- */
+size_t hexgnn_graph_layernorm_workspace_bytes(int hidden);
+int hexgnn_graph_layernorm_forward(int n, int hidden, const float* x, const float* weight /*[hidden]*/,
+                                   const float* bias /*[hidden]*/, float eps, int relu, float* y, float* stats /*[2]*/,
+                                   void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+/* y: the forward output (only read when relu != 0, for the mask); d_weight / d_bias [hidden] are written. */
+int hexgnn_graph_layernorm_backward(int n, int hidden, const float* x, const float* y, const float* weight,
+                                    const float* stats, const float* dy, float eps, int relu, float* dx,
+                                    float* d_weight, float* d_bias, void* workspace, size_t workspace_bytes,
+                                    hexgnn_stream_t stream);
+
 /* ---- fused per-graph path: the WHOLE network (raw first layer, all body + head SAGE layers, head tail) in one
  *      launch per direction, one workgroup per graph with the node features resident in LDS.  Usable when
  *      hexgnn_qnet_supported(): hidden <= 112, c_in <= 8, every graph <= 128 nodes (status |= 2 and the graph is

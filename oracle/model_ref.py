@@ -14,6 +14,10 @@ on the reference's own call sites:
 * ``GraphSAGERef``          <- GN0/torch_script_models.py:96-144 (layer layout) and
                                GN0/models.py:144-164,261-294 (CachifiedGNN loop:
                                ReLU after EVERY layer because out_channels=None)
+* ``LayerNormRef``          <- torch_geometric 2.2.0 ``nn.norm.LayerNorm`` (--norm=True,
+                               GN0/models.py:8,935,945), mode "graph", called WITHOUT a batch
+                               vector (GN0/models.py:286-287,550-551): statistics over all
+                               nodes and channels of the batch, eps added to the std
 * ``FactorizedNoisyLinearRef`` <- GN0/models.py:84-141 (--noisy_dqn=True: the heads'
                                advantage linear, GN0/models.py:331-334)
 * ``HeadNetworkRef``        <- GN0/models.py:318-384
@@ -119,6 +123,22 @@ class SAGEConvRef(torch.nn.Module):
         return out
 
 
+class LayerNormRef(torch.nn.Module):
+    """pyg 2.2.0 LayerNorm(in_channels, eps=1e-5, affine=True, mode="graph").forward(x, batch=None):
+    ``x = x - x.mean(); out = x / (x.std(unbiased=False) + eps); out = out * weight + bias``."""
+
+    def __init__(self, in_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = torch.nn.Parameter(torch.ones(in_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(in_channels))
+
+    def forward(self, x: Tensor) -> Tensor:
+        x = x - x.mean()
+        out = x / (x.std(unbiased=False) + self.eps)
+        return out * self.weight + self.bias
+
+
 class GraphSAGERef(torch.nn.Module):
     """BasicGNN layout (torch_script_models.py:118-144) + CachifiedGNN loop (models.py:261-294)."""
 
@@ -127,8 +147,6 @@ class GraphSAGERef(torch.nn.Module):
     def __init__(self, in_channels: int, hidden_channels: int, num_layers: int,
                  out_channels: Optional[int] = None, norm=None, act="relu", cached_norm=False, **_):
         super().__init__()
-        if norm is not None:
-            raise NotImplementedError("oracle covers norm=None only (all BASELINE configs use --norm=False)")
         self.in_channels = in_channels
         self.hidden_channels = hidden_channels
         self.num_layers = num_layers
@@ -144,12 +162,18 @@ class GraphSAGERef(torch.nn.Module):
             c = hidden_channels
         self.convs.append(SAGEConvRef(c, self.out_channels))
         self.norms = None
+        if norm is not None:     # BasicGNN: num_layers - 1 norms; CachifiedGNN appends the last one (GN0/models.py:158-162)
+            self.norms = torch.nn.ModuleList(LayerNormRef(hidden_channels) for _ in range(num_layers - 1))
+            if not self.has_output:
+                self.norms.append(LayerNormRef(hidden_channels))
 
     def forward(self, x: Tensor, edge_index: Tensor, set_cache: bool = False) -> Tensor:
         for i in range(self.num_layers):
             x = self.convs[i](x, edge_index)
             if i == self.num_layers - 1 and self.has_output:
                 break
+            if self.norms is not None:          # act_first is False: norm, then activation (GN0/models.py:284-291)
+                x = self.norms[i](x)
             x = F.relu(x)
         return x
 
@@ -193,9 +217,10 @@ class HeadNetworkRef(torch.nn.Module):
     """GN0/models.py:318-384."""
 
     def __init__(self, in_channels, hidden_channels, out_channels, value_head_type="linear",
-                 value_aggr_types=("mean",), num_layers=2, noisy_dqn=False, noise_sigma=0, **_):
+                 value_aggr_types=("mean",), num_layers=2, noisy_dqn=False, noise_sigma=0, norm=None, **_):
         super().__init__()
-        self.gnn = GraphSAGERef(in_channels=in_channels, hidden_channels=hidden_channels, num_layers=num_layers)
+        self.gnn = GraphSAGERef(in_channels=in_channels, hidden_channels=hidden_channels, num_layers=num_layers,
+                                norm=norm)
         self.supports_cache = True
         self.value_head_type = value_head_type
         self.hidden_channels = hidden_channels
@@ -227,7 +252,7 @@ class DuellingTwoHeadedRef(torch.nn.Module):
     def __init__(self, gnn_kwargs, head_kwargs):
         super().__init__()
         self.gnn = GraphSAGERef(**gnn_kwargs)
-        self.after_embed_norm = None
+        self.after_embed_norm = LayerNormRef(gnn_kwargs["hidden_channels"]) if gnn_kwargs.get("norm") else None
         self.supports_cache = True
         self.value_activation = torch.nn.Tanh()
         self.advantage_activation = torch.nn.Tanh()
@@ -249,6 +274,8 @@ class DuellingTwoHeadedRef(torch.nn.Module):
         if graph_indices is None:
             graph_indices = x.new_zeros(x.size(0), dtype=torch.long)
         embeds = self.gnn(x, edge_index)
+        if self.after_embed_norm is not None:
+            embeds = self.after_embed_norm(embeds)
         self.final_conv_acts = embeds
         if embeds.requires_grad:
             embeds.register_hook(self.activations_hook)
@@ -272,14 +299,14 @@ class DuellingTwoHeadedRef(torch.nn.Module):
 
 
 def get_pre_defined_ref(name: str, args: Optional[Namespace] = None) -> torch.nn.Module:
-    """GN0/models.py:892-947, ``modern_two_headed`` branch only (norm off)."""
+    """GN0/models.py:892-947, ``modern_two_headed`` branch only."""
     if name != "modern_two_headed":
         raise NotImplementedError(name)
-    if getattr(args, "norm", False):
-        raise NotImplementedError("oracle covers --norm=False (README.md:5,7)")
+    norm = True if getattr(args, "norm", False) else None
     return DuellingTwoHeadedRef(
         gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
-                        cached_norm=False, norm=None, act="relu"),
+                        cached_norm=False, norm=norm, act="relu"),
         head_kwargs=dict(value_head_type="mlp", value_aggr_types=("sum", "max", "min", "mean"),
                          num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2,
-                         noisy_dqn=getattr(args, "noisy_dqn", False), noise_sigma=getattr(args, "noisy_sigma0", 0.5)))
+                         noisy_dqn=getattr(args, "noisy_dqn", False), noise_sigma=getattr(args, "noisy_sigma0", 0.5),
+                         norm=norm))

@@ -65,10 +65,25 @@ def test_unsupported_configurations_fail_loudly():
     from gnn_hex_amd.models import get_pre_defined
     with pytest.raises(NotImplementedError):
         get_pre_defined("two_headed", model_args(3, 8))
-    args = model_args(3, 8)
-    args.norm = True
     with pytest.raises(NotImplementedError):
-        get_pre_defined("modern_two_headed", args)
+        get_pre_defined("pna_two_headed", model_args(3, 8))
+
+
+def test_norm_module_tree_and_state_dict_keys():
+    """--norm=True: one LayerNorm per body layer (BasicGNN's num_layers - 1 plus CachifiedGNN's final one,
+    GN0/models.py:158-162), after_embed_norm (482-483), two per head; keys and order as the oracle's restatement."""
+    from gnn_hex_amd.models import LayerNorm, get_pre_defined
+    from oracle.model_ref import get_pre_defined_ref
+    args = model_args(4, 16)
+    args.norm = True
+    m, r = get_pre_defined("modern_two_headed", args), get_pre_defined_ref("modern_two_headed", args)
+    assert list(m.state_dict().keys()) == list(r.state_dict().keys())
+    assert len(m.gnn.norms) == 4 and len(m.maker_head.gnn.norms) == 2 and isinstance(m.after_embed_norm, LayerNorm)
+    assert m.gnn.norms[0] is not m.gnn.norms[1] and m.gnn.norms[0].weight is not m.after_embed_norm.weight
+    assert torch.equal(m.gnn.norms[3].weight, torch.ones(16)) and m.gnn.norms[3].eps == 1e-5
+    with pytest.raises(AssertionError):
+        m.export_norm_cache()              # as the reference: no cache was ever set
+    m.import_norm_cache(None, None, None)  # cached_norm=False: a no-op
 
 
 def test_noisy_dqn_module_tree_and_state_dict_keys():
