@@ -325,7 +325,8 @@ int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int6
         (n > 0 && !invdeg))
         return HEXGNN_EINVAL;
     if (e > 0 && (!src || !dst || !col || !col_t)) return HEXGNN_EINVAL;
-    (void)hipMemsetAsync(status, 0, sizeof(int), stream);
+    // status is OR-ed into and NOT cleared here (a memset launch per batch for a word that stays zero unless the caller's
+    // data is broken): the caller hands a word it zeroed, e.g. one long-lived sticky error word per device
     KernelTimer kt(HEXGNN_K_CSR, stream);
     if (b > 0) {
         csr_grouped_kernel<<<b, 256, 0, stream>>>(n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t,

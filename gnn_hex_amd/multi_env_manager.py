@@ -607,50 +607,36 @@ class Env_manager:
                 b.start_obs = start_obs
         return blocks[0], blocks[1]
 
-    # ---- transition assembly (host logic, multi_env_manager.py:113-165) ----------------------------------
+    # ---- transition assembly, list form (the reference's return type) -----------------------------------------
     def get_transitions(self, starting_states, state_history: list, action_history: list, reward_history: list,
                         done_history: list, exploratories_history: list):
-        """n-step, sign-alternating, gamma-discounted two-player transitions ``(s, a, r, s', done)`` split into
-        (maker_transitions, breaker_transitions); exploratory actions after the first step prune a transition."""
-        maker_transitions, breaker_transitions = [], []
-        sh = list(state_history)
-        sh.insert(0, starting_states)
-        side_cache = {}
-
-        def side_of(states):
-            k = id(states)
-            if k not in side_cache:
-                side_cache[k] = states.is_maker if isinstance(states, ObsList) else bool(states[0].x[0, 2] == 1)
-            return side_cache[k]
-
-        for i in range(len(action_history)):
-            start_state = sh[i]
-            action = action_history[i]
-            maker_side = side_of(start_state)
-            transits = maker_transitions if maker_side else breaker_transitions
-            for n_step in self.n_steps:
-                if len(sh) > i + 2 * n_step:
-                    for k in range(len(start_state)):
-                        s_k = start_state[k]
-                        if hasattr(s_k, "backmap"):
-                            s_k.__delattr__("backmap")
-                        assert action[k] < len(s_k.x)
-                        reward = 0
-                        for j in range(i, i + 2 * n_step):
-                            reward += reward_history[j][k] * ((-((j - i) % 2)) * 2 + 1) * (self.gamma ** ((j - i) // 2))
-                            if done_history[j][k]:
-                                sobs = self.starting_obs
-                                sobs.__delattr__("backmap")
-                                sobs.x[:, 2] = 1.0 if maker_side else 0.0
-                                sobs.x._hex_is_maker = maker_side
-                                sobs.x._hex_hint_version = sobs.x._version
-                                transits.append((s_k, action[k], reward, sobs, True))
-                                break
-                            if self.prune_exploratories and j > i and exploratories_history[j][k]:
-                                break
-                        else:
-                            nxt = sh[i + 2 * n_step][k]
-                            if hasattr(nxt, "backmap"):
-                                nxt.__delattr__("backmap")
-                            transits.append((s_k, action[k], reward, nxt, False))
-        return maker_transitions, breaker_transitions
+        """``(maker_transitions, breaker_transitions)``, each a list of ``(s, a, r, s', done)`` -- the reference's
+        n-step, sign-alternating, gamma-discounted two-player transitions, an exploratory action after the first step
+        pruning a transition (graph_game/multi_env_manager.py:113-165).  Built from ``assemble_transitions`` (the
+        rewards, windows and emission order are computed once, vectorised over envs); this method only materialises the
+        per-transition ``Data`` views the list API promises: ``backmap`` removed from the states, a fresh start
+        observation with the side column set for terminal transitions."""
+        blocks = self.assemble_transitions(starting_states, state_history, action_history, reward_history,
+                                           done_history, exploratories_history)
+        out = []
+        for blk in blocks:
+            lst = []
+            for src, env, act, rew, nxt, done in zip(blk.src_step.tolist(), blk.env.tolist(), blk.action.tolist(),
+                                                     blk.reward.tolist(), blk.next_step.tolist(), blk.done.tolist()):
+                s_k = blk.obs_list[src][env]
+                if hasattr(s_k, "backmap"):
+                    s_k.__delattr__("backmap")
+                assert act < len(s_k.x)
+                if done:
+                    s_next = self.starting_obs
+                    s_next.__delattr__("backmap")
+                    s_next.x[:, 2] = 1.0 if blk.maker_side else 0.0
+                    s_next.x._hex_is_maker = blk.maker_side
+                    s_next.x._hex_hint_version = s_next.x._version
+                else:
+                    s_next = blk.obs_list[nxt][env]
+                    if hasattr(s_next, "backmap"):
+                        s_next.__delattr__("backmap")
+                lst.append((s_k, action_history[src][env], rew, s_next, bool(done)))
+            out.append(lst)
+        return out[0], out[1]

@@ -66,6 +66,22 @@ def _ptr_array(tensors: Sequence[torch.Tensor]):
     return (C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
+_STICKY = {}
+
+
+def sticky_status(device) -> torch.Tensor:
+    """One int32 error word per device, zero unless a kernel found broken input (bits: GraphStructure.check).  The
+    one-launch CSR build and the fused kernels OR into it and never clear it, so no per-batch memset is needed; the
+    first ``check()`` after an error reports it and clears the word (errors are sticky across batches until then)."""
+    dev = torch.device(device)
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    t = _STICKY.get(key)
+    if t is None:
+        t = torch.zeros(1, dtype=torch.int32, device=dev)
+        _STICKY[key] = t
+    return t
+
+
 class GraphStructure:
     """Target-major CSR of a batch + its transpose + 1/deg, built once per batch on the device.
 
@@ -92,9 +108,9 @@ class GraphStructure:
         L = _lib.lib()
         self.n, self.e = n, e
         if gptr is not None and b > 0:
-            ibuf = torch.empty(2 * (n + 1) + 1, dtype=torch.int32, device=dev)
+            ibuf = torch.empty(2 * (n + 1), dtype=torch.int32, device=dev)
             self.rowptr, self.rowptr_t = ibuf[:n + 1], ibuf[n + 1:2 * (n + 1)]
-            self.status = ibuf[2 * (n + 1):]
+            self.status = sticky_status(dev)
             self.col = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
             self.col_t = torch.empty(max(e, 1), dtype=torch.int32, device=dev)
             self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
@@ -132,15 +148,19 @@ class GraphStructure:
         self.rowptr, self.col, self.invdeg = rowptr, col, invdeg
         self.rowptr_t = rowptr if rowptr_t is None else rowptr_t
         self.col_t = col if col_t is None else col_t
-        self.status = torch.zeros(1, dtype=torch.int32, device=rowptr.device)
+        self.status = sticky_status(rowptr.device)
         return self
 
     def check(self) -> None:
-        """Host-synchronising validity check (debug aid; not called on the hot path)."""
-        if int(self.status.item()) != 0:
+        """Host-synchronising validity check (debug aid; not called on the hot path).  Batches built by the one-launch
+        CSR build share the device's sticky error word: an error is reported by the first check after it, then cleared."""
+        code = int(self.status.item())
+        if code != 0:
+            if self.status is _STICKY.get((self.status.device.type, self.status.device.index)):
+                self.status.zero_()
             raise IndexError("invalid batch structure (status=%d): 1 = node id outside [0,%d), 2 = graph larger than "
                              "128 nodes reached the fused kernel, 4 = an edge connects two graphs (or a batch passed as grouped is "
-                             "not), 8 = graph above 2048 nodes in the grouped build" % (int(self.status.item()), self.n))
+                             "not), 8 = graph above 2048 nodes in the grouped build" % (code, self.n))
 
 
 def graph_ptr(graph_indices: Optional[torch.Tensor], ptr: Optional[torch.Tensor], n: int, device):

@@ -60,7 +60,9 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst,
  * order -- graph(dst[i]) non-decreasing, what Batch.from_data_list / collate_batch (cpp_hex/hex_graph_game/util.cpp:22-41)
  * and hexgnn_env_observe produce.  Node ranges of the graphs: gptr (int32 [b+1]) or, when ptr64 is given, the int64 `ptr` of
  * the batch, in which case gptr_out [b+1] receives the int32 copy the other calls take.  status bits as above plus
- * 8 = a graph has more than 2048 nodes (use hexgnn_csr_build). */
+ * 8 = a graph has more than 2048 nodes (use hexgnn_csr_build).  Unlike hexgnn_csr_build this call does NOT clear the
+ * status word (caller-zeroed, OR-ed into, like the fused calls): one long-lived "sticky" error word per device serves
+ * every batch without a memset launch per step. */
 int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
                              const int64_t* ptr64, int* gptr_out, int* rowptr, int* col, int* rowptr_t, int* col_t,
                              float* invdeg, int* status, hexgnn_stream_t stream);

@@ -188,13 +188,15 @@ def test_reference_checkpoint_format_round_trip(tmp_path):
     model.import_norm_cache(None, None, None)          # norm=False: a no-op, as in the reference
 
 
-def test_vectorised_transition_assembly_matches_loop_form_on_host():
-    """Env_manager.assemble_transitions (numpy over envs) against the reference loop of get_transitions
-    (multi_env_manager.py:113-165), on fabricated histories -- no GPU involved: the manager is built without its device
-    handles and its start observation is stubbed."""
+def test_transition_assembly_matches_the_oracle_loop_on_host():
+    """Env_manager.assemble_transitions (numpy over envs) and the list form built on it (get_transitions) against the
+    ORACLE's restatement of the reference loop (oracle/env_ref.py RefEnvManager.get_transitions <-
+    graph_game/multi_env_manager.py:113-165), on fabricated histories -- no GPU involved: the manager is built without
+    its device handles and its start observation is stubbed."""
     import numpy as np
     from gnn_hex_amd.data import Data
     from gnn_hex_amd.multi_env_manager import Env_manager, ObsList
+    from oracle import env_ref
 
     class FakeObs(ObsList):
         def __init__(self, k, maker):
@@ -206,6 +208,9 @@ def test_vectorised_transition_assembly_matches_loop_form_on_host():
         def __getitem__(self, i):
             return self._d[i]
 
+    def fresh_start():
+        return Data(x=torch.zeros((3, 3)), edge_index=torch.zeros((2, 2), dtype=torch.long), backmap=torch.arange(3))
+
     class HostOnlyManager(Env_manager):      # no device handles: only the transition maths is exercised
         def __init__(self, n_steps, prune):
             self.gamma, self.n_steps, self.prune_exploratories = 0.9, n_steps, prune
@@ -216,25 +221,37 @@ def test_vectorised_transition_assembly_matches_loop_form_on_host():
 
         @property
         def starting_obs(self):
-            return Data(x=torch.zeros((3, 3)), edge_index=torch.zeros((2, 2), dtype=torch.long), backmap=torch.arange(3))
+            return fresh_start()
 
     rng = np.random.default_rng(3)
     for prune in (True, False):
         for n_steps in ([1], [2], [1, 3]):
             mgr = HostOnlyManager(n_steps, prune)
-            if True:
-                T, E = 14, 6
-                start = FakeObs(E, True)
-                states = [FakeObs(E, (t % 2) == 1) for t in range(T)]       # side alternates: state t+1 after move t
-                actions = [rng.integers(0, 3, E) for _ in range(T)]
-                dones = [rng.random(E) < 0.15 for _ in range(T)]
-                rewards = [np.where(d, rng.choice([-1.0, 1.0], E), 0.0) for d in dones]
-                expl = [rng.random(E) < 0.25 for _ in range(T)]
-                mb, bb = mgr.assemble_transitions(start, states, actions, rewards, dones, expl)
-                ml, bl = mgr.get_transitions(start, states, actions, rewards, dones, expl)
-                for block, lst in ((mb, ml), (bb, bl)):
-                    assert len(block) == len(lst) and len(lst) > 0
-                    assert block.action.tolist() == [int(t[1]) for t in lst]
-                    assert np.allclose(block.reward, [t[2] for t in lst])
-                    assert block.done.tolist() == [bool(t[4]) for t in lst]
-                    assert (block.next_step[block.done] == -1).all() and (block.next_step[~block.done] >= 0).all()
+            class OracleSelf:                      # what RefEnvManager.get_transitions reads from `self`
+                starting_obs = property(lambda self: fresh_start())
+            oracle_self = OracleSelf()
+            oracle_self.n_steps, oracle_self.gamma, oracle_self.prune_exploratories = n_steps, 0.9, prune
+            T, E = 14, 6
+            start = FakeObs(E, True)
+            states = [FakeObs(E, (t % 2) == 1) for t in range(T)]       # side alternates: state t+1 after move t
+            actions = [rng.integers(0, 3, E) for _ in range(T)]
+            dones = [rng.random(E) < 0.15 for _ in range(T)]
+            rewards = [np.where(d, rng.choice([-1.0, 1.0], E), 0.0) for d in dones]
+            expl = [rng.random(E) < 0.25 for _ in range(T)]
+            mb, bb = mgr.assemble_transitions(start, states, actions, rewards, dones, expl)
+            ml, bl = mgr.get_transitions(start, states, actions, rewards, dones, expl)
+            om, ob = env_ref.RefEnvManager.get_transitions(oracle_self, start, states, actions, rewards, dones, expl)
+            sh = [start] + states
+            for block, lst, want in ((mb, ml, om), (bb, bl, ob)):
+                assert len(block) == len(lst) == len(want) and len(want) > 0
+                assert block.action.tolist() == [int(t[1]) for t in want] == [int(t[1]) for t in lst]
+                assert np.allclose(block.reward, [t[2] for t in want]) and np.allclose([t[2] for t in lst], [t[2] for t in want])
+                assert block.done.tolist() == [bool(t[4]) for t in want] == [bool(t[4]) for t in lst]
+                assert (block.next_step[block.done] == -1).all() and (block.next_step[~block.done] >= 0).all()
+                for k, (got, exp) in enumerate(zip(lst, want)):
+                    assert got[0] is exp[0]                                     # the very same state object
+                    assert got[0] is sh[int(block.src_step[k])][int(block.env[k])]
+                    if exp[4]:                                                  # terminal: a fresh start observation
+                        assert not hasattr(got[3], "backmap") and float(got[3].x[0, 2]) == float(exp[3].x[0, 2])
+                    else:
+                        assert got[3] is exp[3]
