@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--eager", dest="graph", action="store_false",
                     help="issue every step through Python / torch.autograd (what an unmodified train.py does); with N > 1 "
                          "this also overlaps the all-reduce with the backward")
-    ap.add_argument("--preheat-ms", type=float, default=150.0,
+    ap.add_argument("--preheat-ms", type=float, default=400.0,
                     help="untimed device preheat before the W warm-up steps: the step is repeated until this much wall time "
                          "has passed, so that the clocks, the caching allocator and the TLBs are in their steady state when "
                          "the K timed steps start (a cold start runs its first 20 steps ~5 %% slower); 0 disables it")
