@@ -13,11 +13,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("data", ["D0", "D1"])
-def test_bench_two_ranks_gloo_rehearsal(data):
+@pytest.mark.parametrize("data,issue", [("D0", "--graph"), ("D1", "--graph"), ("D1", "--eager")])
+def test_bench_two_ranks_gloo_rehearsal(data, issue):
+    """--graph: each rank replays its captured step, one all-reduce after the replay.  --eager: the staged backward hands
+    the two halves of the flat gradient buffer to GradSync from inside loss.backward() (the overlap path; through gloo
+    the segments are reduced synchronously, same arithmetic)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "S256",
-           "--data", data, "--steps", "6", "--warmup", "2", "--no-cpu-baseline", "--no-split"]
+           "--data", data, "--steps", "6", "--warmup", "2", "--preheat-ms", "20", "--no-cpu-baseline", "--no-split", issue]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -28,3 +31,5 @@ def test_bench_two_ranks_gloo_rehearsal(data):
     assert out["scaling"] == "weak" and out["value"] > 0
     assert abs(out["value"] - 512 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     assert out["config"]["collective"]["backend"].startswith("gloo")
+    assert out["config"]["collective"]["overlapped_with_backward"] == (issue == "--eager")
+    assert out["config"]["hip_graph"] == (issue == "--graph")

@@ -254,6 +254,24 @@ def test_mixed_side_batch_asserts_like_reference():
         hip(x.cuda(), ei.cuda(), batch.cuda(), ptr.cuda())
 
 
+def test_sticky_status_word_reports_once_and_clears():
+    """The one-launch CSR build ORs into one long-lived error word per device (no memset per batch): the first check()
+    after an error raises and clears it, later healthy batches check clean."""
+    from gnn_hex_amd import ops
+    if ops.get_math() != "fp32" or not ops._FUSED_ENABLED:
+        pytest.skip("mode-independent")
+    ei = torch.tensor([[0, 1, 3, 4], [1, 0, 4, 3]]).cuda()
+    gptr = torch.tensor([0, 3, 5], dtype=torch.int32, device="cuda")
+    good = ops.GraphStructure(ei, 5, gptr, 2)
+    good.check()
+    bad = ops.GraphStructure(torch.tensor([[0, 4], [4, 0]]).cuda(), 5, gptr, 2)       # an edge between the two graphs
+    assert bad.status is good.status is ops.sticky_status("cuda")
+    with pytest.raises(IndexError):
+        good.check()                 # sticky: whoever checks first hears about it ...
+    bad.check()                      # ... and the word is clear again
+    ops.GraphStructure(ei, 5, gptr, 2).check()
+
+
 def test_stale_hints_are_dropped_after_in_place_edit():
     """Host-side hints (side to move, largest graph) are stamped with the tensor's version: editing x in place afterwards
     must make the model fall back to the reference's own device check instead of trusting the stale side."""
