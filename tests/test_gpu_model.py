@@ -264,7 +264,7 @@ def test_sticky_status_word_reports_once_and_clears():
     gptr = torch.tensor([0, 3, 5], dtype=torch.int32, device="cuda")
     good = ops.GraphStructure(ei, 5, gptr, 2)
     good.check()
-    bad = ops.GraphStructure(torch.tensor([[0, 4], [4, 0]]).cuda(), 5, gptr, 2)       # an edge between the two graphs
+    bad = ops.GraphStructure(torch.tensor([[4, 0], [0, 4]]).cuda(), 5, gptr, 2)       # edges between the two graphs
     assert bad.status is good.status is ops.sticky_status("cuda")
     with pytest.raises(IndexError):
         good.check()                 # sticky: whoever checks first hears about it ...
