@@ -295,6 +295,7 @@ def main():
         roof["mfma_tflops"] = launch_flops / avg_s / 1e12
         roof["mfma_peak_tflops"] = mfma_peak
         roof["mfma_frac"] = roof["mfma_tflops"] / mfma_peak
+        roof["binding_roof"] = "mfma"     # refined below once the measured HBM traffic of the launch is known
         # measured HBM bytes per launch of that kernel: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs,
         # gfx950 FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes), committed under profiles/; same config only
         roof["traffic"] = None
@@ -305,6 +306,9 @@ def main():
             for k, v in json.load(open(tpath)).items():
                 if want in k:
                     roof["traffic"] = v["hbm_bytes_per_launch"]
+        if roof["traffic"]:
+            roof["measured_hbm_frac"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS
+            roof["binding_roof"] = "mfma" if roof["mfma_frac"] >= roof["measured_hbm_frac"] else "hbm"
         roof["kernel"] = KNAMES[dom]
         roof["avg_launch_us"] = avg_s * 1e6
         roof["launches_per_step"] = launches / args.steps

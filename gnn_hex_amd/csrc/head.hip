@@ -337,20 +337,25 @@ __global__ __launch_bounds__(256) void td_loss_fwd_kernel(int n, int k, const fl
 }
 
 // One launch: every workgroup clears its 1024-entry range of dq, then accumulates the selected nodes that fall into it
-// (the zeroing memset used to be a launch of its own).  No float atomics: of the entries naming the same node, the FIRST
-// one sums all of them in list order and stores once, so duplicated selections (PER samples with replacement) give a
-// bit-reproducible gradient.  The pairwise scan runs over the <= 1024 entries staged in LDS per chunk.
+// (the zeroing memset used to be a launch of its own).  Bit-reproducible with duplicated selections (PER samples with
+// replacement): an LDS counter per node of the range says how many list entries name it (integer atomics: order-free).
+// A node named once or twice is accumulated with a float atomic into the zeroed word -- 0 + a (+ b) is the same bits in
+// either order, floating-point addition being commutative; only three or more addends depend on the order -- and a node
+// named three times or more (rare outside tiny batches) is summed in list order by its first entry and stored once.
 __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const int64_t* __restrict__ sel,
                                                          const float* __restrict__ td, const float* __restrict__ w,
                                                          int loss_fn, const float* __restrict__ gloss,
                                                          float* __restrict__ dq) {
-    __shared__ int s_i[1024];
-    __shared__ float s_g[1024];
+    __shared__ __attribute__((aligned(16))) int s_i[1024];
+    __shared__ __attribute__((aligned(16))) float s_g[1024];
+    __shared__ int s_cnt[1024];
     const int lo = blockIdx.x * 1024, hi = min(lo + 1024, n);
     for (int i = lo + threadIdx.x; i < hi; i += 256) dq[i] = 0.f;
     const float gl = gloss[0] / (float)k;
     for (int c0 = 0; c0 < k; c0 += 1024) {
         const int kk = min(1024, k - c0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < 1024; j += 256) { s_cnt[j] = 0; s_i[j] = -1; s_g[j] = 0.f; }
         __syncthreads();
         for (int j = threadIdx.x; j < kk; j += 256) {
             const int64_t i = sel[c0 + j];
@@ -359,22 +364,28 @@ __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const in
             const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
             s_i[j] = mine ? (int)i : -1;
             s_g[j] = gl * (w ? w[c0 + j] : 1.f) * dl;
+            if (mine) atomicAdd(&s_cnt[(int)i - lo], 1);
         }
         __syncthreads();
         for (int j = threadIdx.x; j < kk; j += 256) {
             const int i = s_i[j];
             if (i < 0) continue;                       // not in this workgroup's range (most entries)
-            // one pass over the chunk without early exits (independent LDS reads pipeline; a dependent early-exit loop
-            // cost 20 us here): is an earlier entry naming the same node? sum of the later ones, in list order
+            if (s_cnt[i - lo] <= 2) { atomicAdd(dq + i, s_g[j]); continue; }
+            // three or more: is an earlier entry naming the same node? sum of the later ones, in list order
             bool first = true;
             float acc = s_g[j];
-#pragma unroll 8
-            for (int q = 0; q < kk; ++q) {
-                const bool same = s_i[q] == i;
-                first = first && !(same && q < j);
-                acc += (same && q > j) ? s_g[q] : 0.f;
+            for (int q4 = 0; q4 < (kk + 3) / 4; ++q4) {
+                const int4 ii = reinterpret_cast<const int4*>(s_i)[q4];
+                const f32x4 gg = reinterpret_cast<const f32x4*>(s_g)[q4];
+                const int q = 4 * q4;
+                first = first && !((ii.x == i && q < j) || (ii.y == i && q + 1 < j) || (ii.z == i && q + 2 < j) ||
+                                   (ii.w == i && q + 3 < j));
+                acc += (ii.x == i && q > j) ? gg[0] : 0.f;
+                acc += (ii.y == i && q + 1 > j) ? gg[1] : 0.f;
+                acc += (ii.z == i && q + 2 > j) ? gg[2] : 0.f;
+                acc += (ii.w == i && q + 3 > j) ? gg[3] : 0.f;
             }
-            if (first) dq[i] += acc;   // only this thread touches dq[i] in this chunk; chunks are separated by the barrier
+            if (first) atomicAdd(dq + i, acc);   // one add per node and chunk (chunks of 1024 entries are barrier-separated)
         }
     }
 }

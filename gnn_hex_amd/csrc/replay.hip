@@ -20,18 +20,21 @@ namespace hexgnn {
 __global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const int* __restrict__ idx,
                                                          const double* __restrict__ prio_alpha,
                                                          double* __restrict__ sum_tree, double* __restrict__ min_tree) {
-    __shared__ int s_idx[2048];
-    const bool in_lds = k <= 2048;
-    if (in_lds) {
-        for (int i = threadIdx.x; i < k; i += 1024) s_idx[i] = idx[i];
-        __syncthreads();
-    }
+    __shared__ __attribute__((aligned(16))) int s_idx[2048];
+    for (int i = threadIdx.x; i < 2048; i += 1024) s_idx[i] = i < k ? idx[i] : -1;     // k <= 2048 (host entry point)
+    __syncthreads();
     for (int i = threadIdx.x; i < k; i += 1024) {
-        const int slot = in_lds ? s_idx[i] : idx[i];
+        const int slot = s_idx[i];
         if (slot < 0 || slot >= cap) continue;               // out-of-range slots are ignored
-        bool last = true;           // no early exit: independent LDS reads pipeline, a dependent exit test serialises them
-#pragma unroll 8
-        for (int j = i + 1; j < k; ++j) last = last && (in_lds ? s_idx[j] : idx[j]) != slot;
+        // a later entry with the same slot?  Four entries per LDS access, no early exit (a dependent exit test makes every
+        // iteration wait for its own LDS round trip)
+        bool last = true;
+        for (int q4 = (i + 1) / 4; q4 < (k + 3) / 4; ++q4) {
+            const int4 v = reinterpret_cast<const int4*>(s_idx)[q4];
+            const int q = 4 * q4;
+            last = last && !((v.x == slot && q > i) || (v.y == slot && q + 1 > i) || (v.z == slot && q + 2 > i) ||
+                             (v.w == slot && q + 3 > i));
+        }
         if (!last) continue;
         const int leaf = cap + slot;
         sum_tree[leaf] = prio_alpha[i];
@@ -40,7 +43,7 @@ __global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const 
     __syncthreads();
     for (int width = cap >> 1, shift = 1; width >= 1; width >>= 1, ++shift) {
         for (int i = threadIdx.x; i < k; i += 1024) {
-            const int slot = in_lds ? s_idx[i] : idx[i];
+            const int slot = s_idx[i];
             if (slot < 0 || slot >= cap) continue;
             const int node = (cap + slot) >> shift;         // duplicates recompute the same value
             const double l = sum_tree[2 * node], r = sum_tree[2 * node + 1];
