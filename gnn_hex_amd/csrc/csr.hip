@@ -151,6 +151,31 @@ __device__ __forceinline__ int csr_lower_bound_256(const int64_t* __restrict__ d
     return lo;
 }
 
+// Both ends of a graph's edge range in the SAME probe rounds: every thread loads its probe for each target before the
+// two counts (one memory round trip per round instead of two searches back to back).
+__device__ __forceinline__ void csr_lower_bound2_256(const int64_t* __restrict__ dst, int e, int64_t ta, int64_t tb,
+                                                     int& ra, int& rb) {
+    int lo_a = 0, hi_a = e, lo_b = 0, hi_b = e;
+    while (lo_a < hi_a || lo_b < hi_b) {
+        const int step_a = (hi_a - lo_a + 255) / 256, step_b = (hi_b - lo_b + 255) / 256;
+        const int pa = lo_a + (int)threadIdx.x * step_a, pb = lo_b + (int)threadIdx.x * step_b;
+        const int64_t va = (lo_a < hi_a && pa < hi_a) ? dst[pa] : ta;      // inactive search / probe: "not below"
+        const int64_t vb = (lo_b < hi_b && pb < hi_b) ? dst[pb] : tb;
+        const int ca = __syncthreads_count(va < ta);
+        const int cb = __syncthreads_count(vb < tb);
+        if (lo_a < hi_a) {
+            if (ca == 0) hi_a = lo_a;
+            else { const int nlo = lo_a + (ca - 1) * step_a + 1; hi_a = min(hi_a, lo_a + ca * step_a); lo_a = nlo; }
+        }
+        if (lo_b < hi_b) {
+            if (cb == 0) hi_b = lo_b;
+            else { const int nlo = lo_b + (cb - 1) * step_b + 1; hi_b = min(hi_b, lo_b + cb * step_b); lo_b = nlo; }
+        }
+    }
+    ra = lo_a;
+    rb = lo_b;
+}
+
 __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, const int64_t* __restrict__ src,
                                                          const int64_t* __restrict__ dst, const int* __restrict__ gptr,
                                                          const int64_t* __restrict__ ptr64, int* __restrict__ gptr_out,
@@ -167,8 +192,8 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
     const int cnt = r1 - r0;
     if (cnt > kCsrMaxGraph || cnt < 0) { if (tid == 0) atomicOr(status, 8); return; }
     for (int i = tid; i < cnt; i += 256) { s_cnt[0][i] = 0; s_cnt[1][i] = 0; }
-    const int eb = csr_lower_bound_256(dst, e, r0);
-    const int ee = csr_lower_bound_256(dst, e, r1);
+    int eb, ee;
+    csr_lower_bound2_256(dst, e, r0, r1, eb, ee);
     const int ne = ee - eb;
     const bool in_lds = ne <= kCsrLdsEdges;
     __syncthreads();
