@@ -25,11 +25,14 @@ class GradSync:
     extra collective per step and raises on a mismatch instead of reducing mismatched buckets."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], group: Optional[dist.ProcessGroup] = None,
-                 average: bool = True, check: bool = False):
+                 average: bool = True, check: bool = False, single_rank_collectives: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
         self.average = average
         self.check = check
+        # world size 1 normally skips every collective; True issues them anyway (a 1-rank RCCL group on one GPU exercises
+        # the exact call sequence of the N-rank path: async AVG all-reduce on buffer segments, waits, checks)
+        self._min_world = 0 if single_rank_collectives else 1
         self._flat: Optional[torch.Tensor] = None
         self._key = None
         self._segments = []          # (data_ptr, numel, work) of the segments reduced from inside the backward
@@ -74,7 +77,7 @@ class GradSync:
 
     def _on_segment(self, flat: torch.Tensor, lo: int, hi: int) -> None:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1 or hi <= lo:
+        if world <= self._min_world or hi <= lo:
             return
         seg = flat[lo:hi]
         work = None
@@ -108,7 +111,7 @@ class GradSync:
         if not active:
             return 0
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
-        if world == 1:
+        if world <= self._min_world:
             self._segments = []
             return sum(p.numel() for p in active)
         if self.check:

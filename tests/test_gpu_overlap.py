@@ -100,3 +100,48 @@ def test_first_segment_is_handed_over_before_the_second_gemm_finishes():
         assert gap_ms * 1e3 > 40.0          # the lower half of the weight-gradient GEMM (~100 us at GNN-L B=256)
     finally:
         ops.set_grad_stage_hook(None)
+
+
+def test_rccl_call_sequence_on_a_one_rank_group():
+    """The N-rank path's exact RCCL calls on the one GPU this box has: a 1-rank "nccl" process group (device bound), the
+    staged backward handing two segments of the flat gradient buffer to async ReduceOp.AVG all-reduces on the group's
+    stream, all_reduce() waiting for them, the same-set check, and the plain one-bucket path -- gradients must come out
+    unchanged (an average over one rank), bit for bit."""
+    import os
+    import socket
+    import torch.distributed as dist
+    from gnn_hex_amd import ops
+    from gnn_hex_amd.dist import GradSync
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        hip, _ = make_pair(10, 35, seed=63)
+        x, ei, batch, ptr = batch_tensors("D1", [7] * 64)
+        sel, tgt = sel_and_targets(ptr)
+        data = [t.cuda() for t in (x, ei, batch, ptr, sel, tgt)]
+        _, g_plain = _step(hip, data)
+        sync = GradSync(hip.parameters(), check=True, single_rank_collectives=True)
+        sync.enable_overlap()
+        _, g_stage = _step(hip, data)
+        assert len(sync._segments) == 2 and all(w is not None for _, _, w in sync._segments)
+        n = sync.all_reduce()
+        torch.cuda.synchronize()
+        assert n == sum(p.numel() for p in hip.parameters() if p.grad is not None) and not sync._segments
+        for k, p in hip.named_parameters():
+            if g_stage[k] is not None:
+                assert torch.equal(p.grad, g_stage[k]), k               # AVG over one rank: unchanged
+                assert (p.grad - g_plain[k]).abs().max().item() < 2e-6 * max(1.0, g_plain[k].abs().max().item())
+        sync.enable_overlap(False)
+        _, g_one = _step(hip, data)                                     # one bucket, SUM + 1/world
+        assert sync.all_reduce() == n
+        torch.cuda.synchronize()
+        for k, p in hip.named_parameters():
+            if g_one[k] is not None:
+                assert torch.equal(p.grad, g_one[k]), k
+    finally:
+        ops.set_grad_stage_hook(None)
+        dist.destroy_process_group()
