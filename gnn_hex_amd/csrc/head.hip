@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     float* __restrict__ q, float* __restrict__ out_v, float* __restrict__ adv_raw, float* __restrict__ pooled,
     int* __restrict__ amax, int* __restrict__ amin, float* __restrict__ z, float* __restrict__ vraw) {
     __shared__ __attribute__((aligned(16))) float s_w[128];
-    __shared__ float s_pool[4 * 128];
+    __shared__ __attribute__((aligned(16))) float s_pool[4 * 128];
     __shared__ float s_z[64];
     __shared__ float s_red[4];
     __shared__ float s_v;
@@ -71,23 +71,40 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     if (tid < 128) s_w[tid] = tid < H ? lin_w[tid] : 0.f;
     __syncthreads();
 
-    // 1. advantages: one thread per row, 16-byte loads along the row (all independent => deep MLP)
+    // 1. advantages: four lanes per row (64 rows per pass); lane s of a row takes the 16-byte column groups s, s+4, ...
+    //    (a wave-wide load = 16 rows x 64 contiguous bytes, up to eight of them in flight), then two butterfly adds.  One
+    //    thread per row with a rolled column loop paid a memory round trip per 16 bytes: 47 us for a 171-row graph.
     const float lb = lin_b[0];
     float tsum = 0.f;
-    for (int row = r0 + tid; row < r1; row += 256) {
+    const int sub = tid & 3, q4n = hp / 4;
+    for (int row = r0 + (tid >> 2); row < r1; row += 64) {     // the four lanes of a row agree on the trip count
         const f32x4* hr = reinterpret_cast<const f32x4*>(h + (size_t)row * hp);
         const f32x4* wv = reinterpret_cast<const f32x4*>(s_w);
-        float a = 0.f;
-        for (int c = 0; c < hp / 4; ++c) {
-            const f32x4 hv = hr[c], ww = wv[c];
-            a += hv[0] * ww[0] + hv[1] * ww[1] + hv[2] * ww[2] + hv[3] * ww[3];
+        f32x4 hv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = sub + 4 * u;
+            hv[u] = c < q4n ? hr[c] : f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        a += lb;
-        adv_raw[row] = a;
-        const float t = 2.f * tanhf(a);
-        tsum += t;
-        if (mode == 2) q[row] = t;
-        if (mode >= 3) q[row] = a;          // raw advantages (HeadNetwork.forward)
+        float a = 0.f;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = sub + 4 * u;
+            if (c < q4n) {
+                const f32x4 ww = wv[c];
+                a += hv[u][0] * ww[0] + hv[u][1] * ww[1] + hv[u][2] * ww[2] + hv[u][3] * ww[3];
+            }
+        }
+        a += __shfl_xor(a, 1);
+        a += __shfl_xor(a, 2);
+        if (sub == 0) {
+            a += lb;
+            adv_raw[row] = a;
+            const float t = 2.f * tanhf(a);
+            tsum += t;
+            if (mode == 2) q[row] = t;
+            if (mode >= 3) q[row] = a;          // raw advantages (HeadNetwork.forward)
+        }
     }
     if (mode == 2 || mode == 4) return;
     const float adv_total = block_sum_256(tsum, s_red);
@@ -98,7 +115,21 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
         float sum = 0.f, mx = -INFINITY, mn = INFINITY;
         int ax = -1, an = -1;
         if (c < H) {
-            for (int row = r0 + ph; row < r1; row += 2) {
+            // eight rows' loads in flight per step (the loop-carried sum / extremum chain is cheap; one load per iteration
+            // made the loop cost a memory round trip per row: 47 us for a 171-row graph)
+            int row = r0 + ph;
+            for (; row + 14 < r1; row += 16) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = h[(size_t)(row + 2 * u) * hp + c];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    sum += v[u];
+                    if (v[u] > mx) { mx = v[u]; ax = row + 2 * u; }
+                    if (v[u] < mn) { mn = v[u]; an = row + 2 * u; }
+                }
+            }
+            for (; row < r1; row += 2) {
                 const float v = h[(size_t)row * hp + c];
                 sum += v;
                 if (v > mx) { mx = v; ax = row; }
@@ -124,13 +155,29 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     }
     __syncthreads();
 
-    // 3. value MLP
-    for (int k = wave; k < H2; k += 4) {
-        const float* wr = v0_w + (size_t)k * H4;
-        float p = 0.f;
-        for (int c = lane; c < H4; c += 64) p += wr[c] * s_pool[c];
-        p = wave_sum(p);
-        if (lane == 0) {
+    // 3. value MLP.  Thread (k = tid / 8, part = tid % 8) of a pass takes hidden unit k (32 per pass) and the 16-byte column
+    //    groups part, part + 8, ... of its 4H-wide weight row: up to 16 independent loads in flight, an 8-lane butterfly
+    //    to finish (one wave per unit with a shuffle reduction per unit paid a memory round trip per unit).
+    for (int k0 = 0; k0 < H2; k0 += 32) {
+        const int k = k0 + (tid >> 3), part = tid & 7;
+        const f32x4* wrow = reinterpret_cast<const f32x4*>(v0_w + (size_t)(k < H2 ? k : 0) * H4);
+        f32x4 wv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = part + 8 * j;
+            wv[j] = (k < H2 && q < H) ? wrow[q] : f32x4{0.f, 0.f, 0.f, 0.f};       // a 4H-float row = H float4 groups
+        }
+        f32x4 p4 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = part + 8 * j;
+            if (q < H) p4 += wv[j] * reinterpret_cast<const f32x4*>(s_pool)[q];
+        }
+        float p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
+        p += __shfl_xor(p, 1);
+        p += __shfl_xor(p, 2);
+        p += __shfl_xor(p, 4);
+        if (part == 0 && k < H2) {
             const float zz = fmaxf(p + v0_b[k], 0.f);
             s_z[k] = zz;
             z[(size_t)g * H2 + k] = zz;
@@ -148,14 +195,16 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
     }
     __syncthreads();
 
-    // 4. dueling combine (each thread re-reads the adv_raw it wrote itself)
+    // 4. dueling combine (each thread re-reads the adv_raw it wrote itself: lane 0 of a row's four lanes)
     const float mean_adv = adv_total / (float)max(cnt, 1);
     const float V = s_v;
     if ((mode == 1 || mode == 3) && tid == 0) out_v[g] = V;
     if (mode == 3) return;
-    for (int row = r0 + tid; row < r1; row += 256) {
-        const float t = 2.f * tanhf(adv_raw[row]);
-        q[row] = (mode == 0 ? V : 0.f) + t - mean_adv;
+    if (sub == 0) {
+        for (int row = r0 + (tid >> 2); row < r1; row += 64) {
+            const float t = 2.f * tanhf(adv_raw[row]);
+            q[row] = (mode == 0 ? V : 0.f) + t - mean_adv;
+        }
     }
 }
 
@@ -174,10 +223,10 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     __shared__ float s_dar[1024];   // per-row advantage gradient of this graph (graphs beyond 1024 rows re-read global)
     const int g = blockIdx.x;
     const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x;
     const int H2 = H / 2, H4 = 4 * H;
-    const float w0 = lane < H ? lin_w[lane] : 0.f;
-    const float w1 = lane + 64 < H ? lin_w[lane + 64] : 0.f;
+    __shared__ float s_lw[128];
+    if (tid < 128) s_lw[tid] = tid < H ? lin_w[tid] : 0.f;      // visible after the barrier in front of the row loops
 
     float mean_dq = 0.f, inv_cnt = 1.f / (float)max(cnt, 1);
     const bool has_value = mode != 2 && mode != 4, raw = mode >= 3;
@@ -199,7 +248,13 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         __syncthreads();
         for (int c = tid; c < H4; c += 256) {
             float p = 0.f;
-            for (int k = 0; k < H2; ++k) p += v0_w[(size_t)k * H4 + c] * s_dz[k];
+            for (int k = 0; k < H2; k += 16) {            // sixteen rows' loads in flight, same summation order
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = k + u < H2 ? v0_w[(size_t)(k + u) * H4 + c] : 0.f;
+#pragma unroll
+                for (int u = 0; u < 16; ++u) if (k + u < H2) p += wv[u] * s_dz[k + u];
+            }
             s_dp[c] = p;
         }
     }
@@ -210,31 +265,52 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         if (row - r0 < 1024) s_dar[row - r0] = dar;
     }
     __syncthreads();
-    // dh rows: one wave per row; advantage-linear gradient: column c = tid&127, two row phases
-    for (int row = r0 + wave; row < r1; row += 4) {
-        const float dar = (row - r0 < 1024) ? s_dar[row - r0] : dadv[row];
-        float* dr = dh + (size_t)row * hp;
+    // dh rows: four lanes per row (64 rows per pass), 16-byte stores; advantage-linear gradient below: column c = tid&127
+    {
+        const int sub = tid & 3, q4n = hp / 4;
+        for (int row = r0 + (tid >> 2); row < r1; row += 64) {
+            const float dar = (row - r0 < 1024) ? s_dar[row - r0] : dadv[row];
+            f32x4* dr = reinterpret_cast<f32x4*>(dh + (size_t)row * hp);
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int c = lane + 64 * half;
-            if (c < hp) {
-                float v = 0.f;
-                if (c < H) {
-                    v = dar * (half ? w1 : w0);
-                    if (has_value) {
-                        v += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
-                        if (s_ax[c] == row) v += s_dp[H + c];
-                        if (s_an[c] == row) v += s_dp[2 * H + c];
+            for (int u = 0; u < 8; ++u) {
+                const int q = sub + 4 * u;
+                if (q < q4n) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 4 * q + j;
+                        float t = 0.f;
+                        if (c < H) {
+                            t = dar * s_lw[c];
+                            if (has_value) {
+                                t += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
+                                if (s_ax[c] == row) t += s_dp[H + c];
+                                if (s_an[c] == row) t += s_dp[2 * H + c];
+                            }
+                        }
+                        v[j] = t;
                     }
+                    dr[q] = v;
                 }
-                dr[c] = v;
             }
         }
     }
     {
         const int c = tid & 127, ph = tid >> 7;
         float acc = 0.f, accb = 0.f;
-        for (int row = r0 + ph; row < r1; row += 2) {
+        int row = r0 + ph;
+        for (; row + 14 < r1 && c < hp; row += 16) {        // eight rows' loads in flight per step, same summation order
+            float v[8], d[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int rr = row + 2 * u;
+                v[u] = h[(size_t)rr * hp + c];
+                d[u] = (rr - r0 < 1024) ? s_dar[rr - r0] : dadv[rr];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) { acc += d[u] * v[u]; accb += d[u]; }
+        }
+        for (; row < r1; row += 2) {
             const float d = (row - r0 < 1024) ? s_dar[row - r0] : dadv[row];
             if (c < hp) acc += d * h[(size_t)row * hp + c];
             accb += d;
