@@ -198,43 +198,64 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
     const bool in_lds = ne <= kCsrLdsEdges;
     __syncthreads();
     int flags = 0;
-    for (int i = eb + tid; i < ee; i += 256) {
-        const int64_t sv = src[i], dv = dst[i];
-        if (sv < 0 || sv >= n || dv < 0 || dv >= n) { flags |= 1; continue; }
-        if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) { flags |= 4; continue; }
+    // The first kKeep edges of every thread (<= 1024 edges per graph: all of a board graph's) are loaded in one batch of
+    // independent loads and stay in registers for the fill pass below; a load per loop iteration paid a memory round trip
+    // per 256 edges, twice.
+    constexpr int kKeep = 4;
+    int64_t ks[kKeep], kd[kKeep];
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u) {
+        const int i = eb + tid + 256 * u;
+        ks[u] = i < ee ? src[i] : -1;
+        kd[u] = i < ee ? dst[i] : -1;
+    }
+    auto count_edge = [&](const int64_t sv, const int64_t dv) {
+        if (sv < 0 || sv >= n || dv < 0 || dv >= n) { flags |= 1; return; }
+        if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) { flags |= 4; return; }
         atomicAdd(&s_cnt[0][(int)dv - r0], 1);
         atomicAdd(&s_cnt[1][(int)sv - r0], 1);
-    }
+    };
+#pragma unroll
+    for (int u = 0; u < kKeep; ++u) if (eb + tid + 256 * u < ee) count_edge(ks[u], kd[u]);
+    for (int i = eb + tid + 256 * kKeep; i < ee; i += 256) count_edge(src[i], dst[i]);
     if (flags) atomicOr(status, flags);
     __syncthreads();
-    // exclusive scans over cnt <= 2048 entries: 8 consecutive entries per thread, block scan of the 256 partials
+    // exclusive scans over cnt <= 2048 entries: 8 consecutive entries per thread, then a block scan of the 256 partials of
+    // both arrays at once by wave shuffles (one barrier; the LDS Hillis-Steele form took 32)
     constexpr int kPer = kCsrMaxGraph / 256;
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        int local[2][kPer], sum[2] = {0, 0};
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        int local[kPer], sum = 0;
+        for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int i = tid * kPer + k;
-            local[k] = i < cnt ? s_cnt[t][i] : 0;
-            sum += local[k];
+            for (int k = 0; k < kPer; ++k) {
+                const int i = tid * kPer + k;
+                local[t][k] = i < cnt ? s_cnt[t][i] : 0;
+                sum[t] += local[t][k];
+            }
+        int inc[2] = {sum[0], sum[1]};
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int v0 = __shfl_up(inc[0], off), v1 = __shfl_up(inc[1], off);
+            if (lane >= off) { inc[0] += v0; inc[1] += v1; }
         }
-        s_part[t][tid] = sum;
+        if (lane == 63) { s_part[0][wave] = inc[0]; s_part[1][wave] = inc[1]; }
         __syncthreads();
-        for (int off = 1; off < 256; off <<= 1) {
-            const int v = tid >= off ? s_part[t][tid - off] : 0;
-            __syncthreads();
-            s_part[t][tid] += v;
-            __syncthreads();
-        }
-        int run = s_part[t][tid] - sum;
 #pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int i = tid * kPer + k;
-            if (i <= cnt) s_start[t][i] = run;
-            run += local[k];
+        for (int t = 0; t < 2; ++t) {
+            int woff = 0;
+            for (int w = 0; w < wave; ++w) woff += s_part[t][w];
+            int run = woff + inc[t] - sum[t];
+#pragma unroll
+            for (int k = 0; k < kPer; ++k) {
+                const int i = tid * kPer + k;
+                if (i <= cnt) s_start[t][i] = run;
+                run += local[t][k];
+            }
+            // entry [cnt] of a graph with exactly kCsrMaxGraph nodes lies past the last scanned index: the block total
+            if (tid == 255) s_start[t][cnt] = run;
         }
-        // entry [cnt] of a graph with exactly kCsrMaxGraph nodes lies past the last scanned index: the block total
-        if (tid == 255) s_start[t][cnt] = s_part[t][255];
     }
     __syncthreads();
     for (int i = tid; i < cnt; i += 256) {
@@ -249,13 +270,15 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
     // Two explicit code paths: a pointer that may be LDS or global becomes a FLAT pointer, and flat accesses into a large
     // LDS allocation faulted on gfx950 (HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, found with random-playout batches).
     auto fill_and_sort = [&](auto* c0, auto* c1) {
-        for (int i = eb + tid; i < ee; i += 256) {
-            const int64_t sv = src[i], dv = dst[i];
-            if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) continue;
+        auto fill_edge = [&](const int64_t sv, const int64_t dv) {
+            if (sv < r0 || sv >= r1 || dv < r0 || dv >= r1) return;
             const int d = (int)dv - r0, sl = (int)sv - r0;
             c0[s_start[0][d] + atomicAdd(&s_cnt[0][d], 1)] = (int)sv;
             c1[s_start[1][sl] + atomicAdd(&s_cnt[1][sl], 1)] = (int)dv;
-        }
+        };
+#pragma unroll
+        for (int u = 0; u < kKeep; ++u) if (eb + tid + 256 * u < ee) fill_edge(ks[u], kd[u]);
+        for (int i = eb + tid + 256 * kKeep; i < ee; i += 256) fill_edge(src[i], dst[i]);
         __syncthreads();
         // rows ascending (deterministic CSR)
         for (int i = tid; i < 2 * cnt; i += 256) {
