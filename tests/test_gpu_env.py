@@ -24,7 +24,8 @@ def _assert_env_equals_oracle(st, i, game):
     assert int(st["total_moves"][i]) == game.total_num_moves
 
 
-@pytest.mark.parametrize("size,num_envs,steps", [(5, 16, 40), (7, 32, 60), (11, 64, 80), (13, 8, 60), (15, 4, 170), (17, 3, 220)])
+@pytest.mark.parametrize("size,num_envs,steps", [(5, 16, 40), (7, 32, 60), (11, 64, 80), (13, 8, 60), (15, 4, 170), (17, 3, 220),
+                                                 (19, 2, 300), (25, 2, 520), (6, 8, 40), (3, 5, 12)])
 def test_lockstep_random_play_bit_exact(hexref, size, num_envs, steps):
     from gnn_hex_amd.multi_env_manager import Env_manager
     mgr = Env_manager(num_envs, size, gamma=0.97)

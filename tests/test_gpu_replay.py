@@ -51,6 +51,51 @@ def test_per_trees_and_sampling_match_oracle():
         assert np.allclose(ow.cpu().numpy(), rw, rtol=1e-6, atol=0)
 
 
+def test_per_trees_at_the_reference_buffer_size():
+    """README.md:5,7: --buffer_size=260000 --batch_size=256 --prioritized_er_beta0=0.6.  Trees of capacity 2^18 filled
+    in blocks of 2048 / 5000 entries (the launch-chunked update path), then 256-sample stratified draws: tree sums,
+    sampled slots and importance weights against the oracle, bit for bit (fp64 sums in the same order)."""
+    from gnn_hex_amd import _lib, ops
+    from oracle.replay_ref import SegmentTreePER
+    L = _lib.lib()
+    cap = 1 << 18
+    st = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+    mt = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+    _lib.check(L.hexgnn_per_init(cap, st.data_ptr(), mt.data_ptr(), ops._stream()))
+    ref = SegmentTreePER(cap)
+    rng = np.random.default_rng(11)
+    size = 0
+    for k in (2048, 5000, 2048):
+        idx = np.arange(size, size + k, dtype=np.int32)              # ring slots filled in order
+        pa = rng.random(k) ** 0.5 + 1e-3
+        ref.update(idx, pa)
+        di, dp = torch.from_numpy(idx).cuda(), torch.from_numpy(pa).cuda()
+        _lib.check(L.hexgnn_per_update(cap, k, di.data_ptr(), dp.data_ptr(), st.data_ptr(), mt.data_ptr(), ops._stream()))
+        size += k
+    # a priority update of a sampled batch (with the duplicates sampling with replacement produces)
+    upd = rng.integers(0, size, 256).astype(np.int32)
+    upd[7] = upd[200]
+    pa = rng.random(256) + 1e-3
+    ref.update(upd, pa)
+    du, dp = torch.from_numpy(upd).cuda(), torch.from_numpy(pa).cuda()
+    _lib.check(L.hexgnn_per_update(cap, 256, du.data_ptr(), dp.data_ptr(), st.data_ptr(), mt.data_ptr(), ops._stream()))
+    torch.cuda.synchronize()
+    got_sum, got_min = st.cpu().numpy(), mt.cpu().numpy()
+    assert np.array_equal(got_sum[1:], ref.sum[1:])
+    fin = np.isfinite(ref.min)
+    assert np.array_equal(got_min[fin], ref.min[fin])
+    for beta in (0.6, 1.0):
+        u = rng.random(256)
+        ri, rw = ref.sample(u, size, beta)
+        oi = torch.empty(256, dtype=torch.int32, device="cuda")
+        ow = torch.empty(256, dtype=torch.float32, device="cuda")
+        dv = torch.from_numpy(u).cuda()
+        _lib.check(L.hexgnn_per_sample(cap, size, 256, beta, dv.data_ptr(), st.data_ptr(), mt.data_ptr(), oi.data_ptr(),
+                                       ow.data_ptr(), ops._stream()))
+        assert np.array_equal(oi.cpu().numpy(), ri)
+        assert np.allclose(ow.cpu().numpy(), rw, rtol=1e-6, atol=0)
+
+
 def test_per_update_duplicates_last_wins_and_large_lists():
     """PER samples with replacement, so update_priorities sees duplicated slots: the last occurrence must win in BOTH
     trees (oracle: sequential loop), deterministically, also across the 2048-entry launch chunks of a long list."""
