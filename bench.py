@@ -110,12 +110,16 @@ def main():
         raise SystemExit("%d ranks but %d GPUs (RCCL needs one GPU per rank)" % (world, ndev))
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
+
+    def init_group():
+        """Called AFTER the step graphs are captured: the replicas are built from the same seed on every rank (nothing to
+        broadcast), and no collective library thread is alive while a HIP-graph capture is in progress."""
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if args.backend == "nccl":
+                dist.init_process_group("nccl", device_id=dev)
+            else:
+                dist.init_process_group("gloo")
 
     from helpers import batch_tensors, make_pair, sel_and_targets
     from gnn_hex_amd import _lib
@@ -192,6 +196,8 @@ def main():
             graphs[i & 1].replay()
             if world > 1:
                 sync.all_reduce()
+
+    init_group()
 
     def barrier():
         torch.cuda.synchronize()

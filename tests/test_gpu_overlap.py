@@ -142,6 +142,29 @@ def test_rccl_call_sequence_on_a_one_rank_group():
         for k, p in hip.named_parameters():
             if g_one[k] is not None:
                 assert torch.equal(p.grad, g_one[k]), k
+        # HIP-graph capture of the step while the RCCL group is alive (bench.py captures before it creates the group; a
+        # training script may not), then replay + the one-bucket all-reduce on the graph's gradient buffers
+        from gnn_hex_amd.graphs import GraphedStep
+        params = list(hip.parameters())
+        xh = ops.attach_hints(data[0], is_maker=True, max_nodes=int((ptr[1:] - ptr[:-1]).max()))   # no host sync in a capture
+        data[1]._hex_grouped = True
+
+        def fn():
+            for p in params:
+                p.grad = None
+            q = hip(xh, data[1], data[2], data[3])
+            loss = torch.nn.functional.mse_loss(q[data[4]], data[5])
+            loss.backward()
+            return loss
+
+        gstep = GraphedStep(fn, params)
+        for _ in range(2):
+            gstep.replay()
+            assert sync.all_reduce() == n
+        torch.cuda.synchronize()
+        for k, p in hip.named_parameters():
+            if g_one[k] is not None:
+                assert torch.equal(p.grad, g_one[k]), k
     finally:
         ops.set_grad_stage_hook(None)
         dist.destroy_process_group()
