@@ -4,7 +4,7 @@ pieces, README.md:5,7 flags): 128 parallel Hex-11 envs, eps-greedy acting with t
 into two prioritized replay rings (maker / breaker), double-DQN targets from a target network, importance-weighted MSE,
 Adam, priority updates.  Everything between two prints stays on the GPU except one read-back per 16-move rollout.
 
-    DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 python examples/selfplay_train.py --iters 50
+    python examples/selfplay_train.py --iters 50
 
 The reference's training script itself lives in an un-vendored submodule and is not rebuilt; this file shows how its loop
 maps onto the drop-in API and measures end-to-end frames/s and updates/s."""
@@ -21,7 +21,7 @@ import torch  # noqa: E402
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from gnn_hex_amd import ops  # noqa: E402
 from gnn_hex_amd.models import get_pre_defined  # noqa: E402
-from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager  # noqa: E402
+from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager, RolloutStitcher  # noqa: E402
 from gnn_hex_amd.replay import GraphReplayBuffer  # noqa: E402
 
 
@@ -52,6 +52,7 @@ def main():
     bufs = {True: GraphReplayBuffer(cap, args.hex_size, prioritized=True, alpha=0.5),
             False: GraphReplayBuffer(cap, args.hex_size, prioritized=True, alpha=0.5)}
     rollout = DeviceRollout(mgr, q_net, steps=args.rollout, eps=0.12, graph=not args.no_graph)
+    stitch = RolloutStitcher(mgr)      # carries the last 2 * n_step moves of a rollout into the next assembly
     frames = updates = games = 0
     last_loss = float("nan")
     t0 = time.perf_counter()
@@ -59,8 +60,7 @@ def main():
         res = rollout.run()
         frames += args.envs * args.rollout
         games += int(res.dones.sum())
-        mb, bb = mgr.assemble_transitions(res.states[0], res.states[1:], list(res.actions), list(res.rewards),
-                                          list(res.dones), list(res.exploratories))
+        mb, bb = stitch.assemble(res)
         bufs[True].put_block(mb)
         bufs[False].put_block(bb)
         for side in (True, False):

@@ -284,6 +284,60 @@ class DeviceRollout:
         return RolloutResult(states, ranks, verts, rewards, dones, expl, infos)
 
 
+class RolloutStitcher:
+    """Transitions across rollout boundaries.  An n-step transition that starts in move i needs the histories up to move
+    i + 2 n_step, so the last 2 n_step - 1 moves of a rollout cannot produce transitions on their own (3 of 16 moves at
+    n_step = 2).  The stitcher keeps that tail -- observations as detached snapshot copies, actions, rewards, dones,
+    exploratory flags -- and prepends it to the next rollout's histories: every move of a continuous self-play stream then
+    starts exactly one transition per n_step, and none twice (windows of a shorter n_step that were already complete in the
+    previous rollout are skipped).
+
+        stitch = RolloutStitcher(mgr)
+        maker_block, breaker_block = stitch.assemble(rollout.run())      # instead of mgr.assemble_transitions(...)
+    """
+
+    def __init__(self, mgr: "Env_manager"):
+        self.mgr = mgr
+        self.keep = 2 * max(mgr.n_steps) - 1     # moves whose longest window was still incomplete at the rollout's end
+        self._tail = None      # (states [keep + 1], actions, rewards, dones, exploratories) of the previous rollout's end
+
+    def reset(self):
+        """Forget the tail (after ``mgr.reset()`` / ``change_hex_size``: the stream is no longer continuous)."""
+        self._tail = None
+
+    def assemble(self, res: RolloutResult):
+        T = len(res.actions)
+        if T < self.keep:
+            raise ValueError("a rollout must be at least 2 * n_step - 1 = %d moves long" % self.keep)
+        states = list(res.states)
+        acts, rews = list(res.actions), list(res.rewards)
+        dones, expl = list(res.dones), list(res.exploratories)
+        emitted = None
+        if self._tail is not None:
+            t_states, t_acts, t_rews, t_dones, t_expl = self._tail
+            # the tail's last observation IS this rollout's first one (same boards): keep the tail's copy for the prefix
+            states = t_states[:-1] + states
+            acts, rews, dones, expl = t_acts + acts, t_rews + rews, t_dones + dones, t_expl + expl
+            # a shorter window (n_step below the maximum) starting in the first 2 (n_max - n_step) prefix moves was already
+            # complete in the previous rollout
+            emitted = {n: self.keep + 1 - 2 * n for n in self.mgr.n_steps}
+        blocks = self.mgr.assemble_transitions(states[0], states[1:], acts, rews, dones, expl, _already_emitted=emitted)
+        # next prefix: the last `keep` moves with their keep + 1 observations, snapshots copied out of the rollout's ring
+        k = self.keep
+        tail_states = []
+        for st in states[-(k + 1):]:
+            if isinstance(st, SnapObs) and st._owner is not None:
+                cp = SnapObs.__new__(SnapObs)
+                cp.__dict__.update(st.__dict__)
+                cp._snap = tuple(t.clone() for t in st._snap)
+                cp._owner = None
+                cp._items = {}
+                st = cp
+            tail_states.append(st)
+        self._tail = (tail_states, acts[-k:], rews[-k:], dones[-k:], expl[-k:])
+        return blocks
+
+
 class _EnvView:
     """Read-only stand-in for the per-env ``Hex_game`` objects of the reference's ``Env_manager.envs``."""
 
@@ -550,7 +604,7 @@ class Env_manager:
 
     # ---- transition assembly, array form (same semantics as get_transitions below, no per-transition objects) --
     def assemble_transitions(self, starting_states, state_history: list, action_history: list, reward_history: list,
-                             done_history: list, exploratories_history: list):
+                             done_history: list, exploratories_history: list, _already_emitted=None):
         """``get_transitions`` (multi_env_manager.py:113-165) vectorised over the envs: returns
         ``(maker_block, breaker_block)`` of ``TransitionBlock`` whose entries appear in exactly the order the list
         form emits them.  Histories may hold ``ObsList`` observations (states stay on the device as board snapshots)."""
@@ -570,6 +624,8 @@ class Env_manager:
             for n_step in self.n_steps:
                 if not len(sh) > i + 2 * n_step:
                     continue
+                if _already_emitted is not None and i < _already_emitted.get(n_step, 0):
+                    continue        # RolloutStitcher: this window was complete, and emitted, in the previous rollout
                 w = 2 * n_step
                 jj = np.arange(w)
                 coef = ((-(jj % 2)) * 2 + 1) * (float(self.gamma) ** (jj // 2))          # sign * gamma^((j-i)//2)

@@ -293,3 +293,41 @@ def test_rollout_result_goes_stale_unless_detached():
     for s, c in zip(second.states, copies):                      # detached: unaffected by the third run
         assert all(torch.equal(a, b) for a, b in zip(s.snapshot(), c))
     assert any(not torch.equal(k[0], c[0]) for k, c in zip(kept, copies))
+
+
+def test_rollout_stitcher_covers_every_move_once():
+    """Transitions across rollout boundaries: stitched assembly of three consecutive rollouts (each alone loses its last
+    2 * n_step - 1 moves) must equal, as a multiset of (start step, env, action, reward, next step, done), the assembly of
+    the concatenated histories in one call."""
+    import torch
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager, RolloutStitcher
+    from helpers import make_pair
+    hip, _ = make_pair(3, 35, seed=4)
+    n_step, T, k = 2, 8, 12
+    mgr = Env_manager(k, 5, gamma=0.97, n_steps=[n_step, 1])
+    mgr.reset()
+    ro = DeviceRollout(mgr, hip, steps=T, eps=0.4, graph=False)
+    stitch = RolloutStitcher(mgr)
+    runs, got = [], {True: [], False: []}
+    for r in range(3):
+        res = ro.run().detach()                       # detached: the one-shot assembly below reads all three again
+        runs.append(res)
+        off = max(0, r * T - stitch.keep)             # absolute move index of the stitched histories' first move
+        for side, blk in zip((True, False), stitch.assemble(res)):
+            for s_, e_, a_, rw, nx, d_ in zip(blk.src_step.tolist(), blk.env.tolist(), blk.action.tolist(),
+                                              blk.reward.tolist(), blk.next_step.tolist(), blk.done.tolist()):
+                got[side].append((s_ + off, e_, a_, round(rw, 9), -1 if nx < 0 else nx + off, d_))
+    states = [runs[0].states[0]] + [s for res in runs for s in res.states[1:]]
+    cat = lambda name: [x for res in runs for x in list(getattr(res, name))]       # noqa: E731
+    blocks = mgr.assemble_transitions(states[0], states[1:], cat("actions"), cat("rewards"), cat("dones"),
+                                      cat("exploratories"))
+    for side, blk in zip((True, False), blocks):
+        want = sorted(zip(blk.src_step.tolist(), blk.env.tolist(), blk.action.tolist(),
+                          [round(v, 9) for v in blk.reward.tolist()],
+                          [-1 if v < 0 else v for v in blk.next_step.tolist()], blk.done.tolist()))
+        assert sorted(got[side]) == want and len(want) > 0
+    # every move 0 .. 3T - 2*n_step - 1 of every env starts a 2-step transition unless pruned: more than a lone rollout gives
+    lone = sum(len(b) for b in mgr.assemble_transitions(runs[0].states[0], runs[0].states[1:], list(runs[0].actions),
+                                                        list(runs[0].rewards), list(runs[0].dones),
+                                                        list(runs[0].exploratories)))
+    assert sum(len(v) for v in got.values()) > 3 * lone

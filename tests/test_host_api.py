@@ -255,3 +255,60 @@ def test_transition_assembly_matches_the_oracle_loop_on_host():
                         assert not hasattr(got[3], "backmap") and float(got[3].x[0, 2]) == float(exp[3].x[0, 2])
                     else:
                         assert got[3] is exp[3]
+
+
+def test_rollout_stitcher_on_host():
+    """RolloutStitcher: three consecutive rollouts assembled with the carried-over tail must give exactly the transitions
+    of ONE assembly over the concatenated histories (each window once, also with two different n_step values), on
+    fabricated histories without a GPU."""
+    import numpy as np
+    from gnn_hex_amd.data import Data
+    from gnn_hex_amd.multi_env_manager import Env_manager, ObsList, RolloutResult, RolloutStitcher
+
+    class FakeObs(ObsList):
+        def __init__(self, k, maker):
+            super().__init__(None, None, None, None, None, list(range(0, 3 * k + 1, 3)), list(range(0, 2 * k + 1, 2)), None,
+                             maker, 3, None)
+            self._d = [Data(x=torch.tensor([[1.0, 1.0, float(maker)]] * 3), edge_index=torch.zeros((2, 2), dtype=torch.long))
+                       for _ in range(k)]
+
+        def __getitem__(self, i):
+            return self._d[i]
+
+    class HostOnlyManager(Env_manager):
+        def __init__(self, n_steps, prune):
+            self.gamma, self.n_steps, self.prune_exploratories = 0.9, n_steps, prune
+            self._base, self._base_sizes, self._h = None, None, None
+
+        def _observe_handle(self, *a, **k):
+            return FakeObs(1, True)
+
+    for n_steps in ([2], [2, 1], [1], [3, 1]):
+        rng = np.random.default_rng(sum(n_steps))
+        T, E = 8, 5
+        mgr = HostOnlyManager(n_steps, True)
+        stitch = RolloutStitcher(mgr)
+        assert stitch.keep == 2 * max(n_steps) - 1
+        allstates, runs, got = [FakeObs(E, True)], [], {True: [], False: []}
+        for r in range(3):
+            states = [allstates[-1]] + [FakeObs(E, ((r * T + t + 1) % 2) == 0) for t in range(T)]
+            allstates += states[1:]
+            acts = [rng.integers(0, 3, E) for _ in range(T)]
+            dones = [rng.random(E) < 0.15 for _ in range(T)]
+            rews = [np.where(d, rng.choice([-1.0, 1.0], E), 0.0) for d in dones]
+            expl = [rng.random(E) < 0.25 for _ in range(T)]
+            res = RolloutResult(states, np.array(acts), np.array(acts), np.array(rews), np.array(dones), np.array(expl), None)
+            runs.append(res)
+            off = max(0, r * T - stitch.keep)
+            for side, blk in zip((True, False), stitch.assemble(res)):
+                for s_, e_, a_, rw, nx, d_ in zip(blk.src_step.tolist(), blk.env.tolist(), blk.action.tolist(),
+                                                  blk.reward.tolist(), blk.next_step.tolist(), blk.done.tolist()):
+                    got[side].append((s_ + off, e_, a_, round(rw, 9), -1 if nx < 0 else nx + off, d_))
+        cat = lambda name: [x for res in runs for x in list(getattr(res, name))]       # noqa: E731
+        blocks = mgr.assemble_transitions(allstates[0], allstates[1:], cat("actions"), cat("rewards"), cat("dones"),
+                                          cat("exploratories"))
+        for side, blk in zip((True, False), blocks):
+            want = sorted(zip(blk.src_step.tolist(), blk.env.tolist(), blk.action.tolist(),
+                              [round(v, 9) for v in blk.reward.tolist()],
+                              [-1 if v < 0 else v for v in blk.next_step.tolist()], blk.done.tolist()))
+            assert sorted(got[side]) == want and len(want) > 0, (n_steps, side)
