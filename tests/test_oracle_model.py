@@ -121,3 +121,77 @@ def test_parameter_counts_and_state_dict_keys():
     assert "gnn.convs.0.lin_r.bias" not in keys
     assert s.state_dict()["gnn.convs.0.lin_l.weight"].shape == (35, 2)
     assert s.state_dict()["maker_head.value_head.layers.0.weight"].shape == (17, 140)
+
+
+def _dense_numpy_forward(sd, layers, hidden, x, ei, batch, norm=False, noisy=False, eps=1e-5):
+    """An INDEPENDENT float64 restatement of the network in dense linear algebra (numpy; adjacency-count matrices instead
+    of gather / scatter, explicit loops instead of autograd modules).  It shares no code with oracle/model_ref.py: agreement
+    between the two guards the oracle against restatement slips (it cannot pin either to torch_geometric)."""
+    g = lambda k: sd[k].double().numpy()                                          # noqa: E731
+    x = x.double().numpy()
+    n = x.shape[0]
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    A = np.zeros((n, n))
+    np.add.at(A, (dst, src), 1.0)                    # A[i, j] = number of edges j -> i (duplicates counted)
+    deg = np.maximum(A.sum(1, keepdims=True), 1.0)
+    M = A / deg                                      # mean over in-edges; rows without in-edges stay zero
+    maker = x[0, 2] == 1
+
+    def ln(h, prefix):
+        c = h - h.mean()
+        return c / (c.std() + eps) * g(prefix + ".weight") + g(prefix + ".bias")
+
+    def stack(h, prefix, count):
+        for i in range(count):
+            h = (M @ h) @ g("%s.convs.%d.lin_l.weight" % (prefix, i)).T + g("%s.convs.%d.lin_l.bias" % (prefix, i)) \
+                + h @ g("%s.convs.%d.lin_r.weight" % (prefix, i)).T
+            if norm:
+                h = ln(h, "%s.norms.%d" % (prefix, i))
+            h = np.maximum(h, 0.0)
+        return h
+
+    emb = stack(x[:, :2], "gnn", layers)
+    if norm:
+        emb = ln(emb, "after_embed_norm")
+    head = "maker_head" if maker else "breaker_head"
+    h = stack(emb, head + ".gnn", 2)
+    if noisy:
+        w = g(head + ".linear.weight_mu") + g(head + ".linear.weight_sigma") * g(head + ".linear.weight_epsilon")
+        b = g(head + ".linear.bias_mu") + g(head + ".linear.bias_sigma") * g(head + ".linear.bias_epsilon")
+    else:
+        w, b = g(head + ".linear.weight"), g(head + ".linear.bias")
+    adv = 2.0 * np.tanh(h @ w.T + b)[:, 0]
+    bt = batch.numpy()
+    q = np.zeros(n)
+    for gi in range(int(bt.max()) + 1):
+        rows = np.nonzero(bt == gi)[0]
+        hg = h[rows]
+        pooled = np.concatenate([hg.sum(0), hg.max(0), hg.min(0), hg.mean(0)])
+        z = np.maximum(g(head + ".value_head.layers.0.weight") @ pooled + g(head + ".value_head.layers.0.bias"), 0.0)
+        v = np.tanh(g(head + ".value_head.layers.1.weight") @ z + g(head + ".value_head.layers.1.bias"))[0]
+        q[rows] = v + adv[rows] - adv[rows].mean()
+    return q
+
+
+@pytest.mark.parametrize("norm,noisy", [(False, False), (True, False), (False, True), (True, True)])
+@pytest.mark.parametrize("maker", [True, False])
+def test_oracle_agrees_with_an_independent_dense_restatement(norm, noisy, maker):
+    from argparse import Namespace
+    torch.manual_seed(5)
+    args = Namespace(num_layers=4, hidden_channels=12, norm=norm, noisy_dqn=noisy, noisy_sigma0=0.5, num_head_layers=2)
+    ref = get_pre_defined_ref("modern_two_headed", args).double()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if "norm" in k:
+                p.add_(torch.randn(p.shape, dtype=torch.float64) * 0.3)
+    # board graphs plus a directed / duplicated / isolated-node graph
+    x, ei, batch, ptr = batch_tensors("D1", [5, 7, 6], maker=maker)
+    n0 = x.shape[0]
+    extra_x = torch.tensor([[3., 1., x[0, 2]], [0., 1., x[0, 2]], [2., 0., x[0, 2]], [1., 0., x[0, 2]]])
+    extra_ei = torch.tensor([[0, 0, 2, 2], [1, 1, 1, 0]]) + n0          # duplicate edge 0->1, node 3 isolated
+    x = torch.cat([x, extra_x]); ei = torch.cat([ei, extra_ei], 1)
+    batch = torch.cat([batch, torch.full((4,), 3)])
+    with torch.no_grad():
+        q_ref = ref(x.double(), ei, batch).numpy()
+    q_dense = _dense_numpy_forward(ref.state_dict(), 4, 12, x, ei, batch, norm=norm, noisy=noisy)
+    assert np.abs(q_ref - q_dense).max() < 1e-10
