@@ -494,7 +494,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     QSTAMP(0, 0, 0);
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
-    if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
+    if (cnt > kRows) {
+        // a graph that does not fit the tile reached this kernel (stale size hint): flag it AND poison its outputs, so
+        // the failure is visible in the data even if nobody reads the status word
+        if (tid == 0) { atomicOr(a.status, 2); if (a.out_v) a.out_v[gi] = __builtin_nanf(""); }
+        for (int i = tid; i < cnt; i += 512) a.q[r0 + i] = __builtin_nanf("");
+        return;
+    }
     const int H = a.H;
     const int lrow = wave * 16 + r;                 // local row of this lane
     const bool rvalid = lrow < cnt;

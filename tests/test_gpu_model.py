@@ -254,6 +254,24 @@ def test_mixed_side_batch_asserts_like_reference():
         hip(x.cuda(), ei.cuda(), batch.cuda(), ptr.cuda())
 
 
+def test_wrong_size_hint_poisons_the_output_instead_of_returning_garbage():
+    """A stale / wrong largest-graph hint sends a 150-node graph to the 128-row fused kernel: the kernel must flag it in
+    the status word AND write NaN into that graph's Q values (the other graphs stay correct)."""
+    from gnn_hex_amd import ops
+    if ops.get_math() != "fp32" or not ops._FUSED_ENABLED:
+        pytest.skip("fused kernels only, once")
+    hip, ref = make_pair(3, 35, seed=24)
+    x, ei, batch, ptr = _random_batch([20, 150, 16], seed=8, directed=False, p_edge=0.03)
+    xd = ops.attach_hints(x.cuda(), is_maker=True, max_nodes=100)          # a lie: the second graph has 150 nodes
+    with torch.no_grad():
+        q = hip(xd, ei.cuda(), batch.cuda(), ptr.cuda())
+        q_ref = ref(x, ei, batch, ptr)
+    torch.cuda.synchronize()
+    p0, p1, p2 = int(ptr[1]), int(ptr[2]), int(ptr[3])
+    assert torch.isnan(q[p0:p1]).all()
+    assert (q[:p0].cpu() - q_ref[:p0]).abs().max() < TOL and (q[p1:p2].cpu() - q_ref[p1:p2]).abs().max() < TOL
+
+
 def test_sticky_status_word_reports_once_and_clears():
     """The one-launch CSR build ORs into one long-lived error word per device (no memset per batch): the first check()
     after an error raises and clears it, later healthy batches check clean."""
