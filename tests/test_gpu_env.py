@@ -331,3 +331,40 @@ def test_rollout_stitcher_covers_every_move_once():
                                                         list(runs[0].rewards), list(runs[0].dones),
                                                         list(runs[0].exploratories)))
     assert sum(len(v) for v in got.values()) > 3 * lone
+
+
+@pytest.mark.parametrize("total,world", [(128, 8), (1024, 8)])
+def test_env_shards_equal_one_manager(total, world):
+    """BASELINE config 4 shards parallel_envs=1024 eight ways (rank r owns envs [r*P/W, (r+1)*P/W), gnn_hex_amd.dist.
+    shard_range).  Rehearsed on one GPU: W shard managers stepped with the slices of one action vector must stay identical,
+    env for env, to ONE manager of all P envs -- states, rewards, dones, observations -- so a rank's shard is exactly its
+    slice of the single-process run."""
+    import torch
+    from gnn_hex_amd.data import Batch
+    from gnn_hex_amd.dist import shard_range
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    size, steps = 11, 24
+    whole = Env_manager(total, size, gamma=0.97)
+    whole.reset()
+    shards = []
+    for r in range(world):
+        lo, hi = shard_range(total, r, world)
+        m = Env_manager(hi - lo, size, gamma=0.97)
+        m.reset()
+        shards.append((lo, hi, m))
+    rng = np.random.default_rng(total)
+    for t in range(steps):
+        valid = whole.get_valid_actions()
+        acts = [int(v[rng.integers(len(v))]) for v in valid]
+        obs, rew, done, _ = whole.step(acts)
+        st = whole._state()
+        b = Batch.from_data_list(obs)
+        for lo, hi, m in shards:
+            o2, r2, d2, _ = m.step(acts[lo:hi])
+            assert np.array_equal(r2, rew[lo:hi]) and np.array_equal(d2, done[lo:hi])
+            s2 = m._state()
+            for key in ("adj", "alive", "maker_turn", "total_moves"):
+                assert np.array_equal(np.asarray(s2[key]), np.asarray(st[key])[lo:hi]), (key, lo)
+            n0, n1 = obs.node_off[lo], obs.node_off[hi]
+            assert torch.equal(o2.x, obs.x[n0:n1]) and torch.equal(o2.backmap, obs.backmap[n0:n1])
+        assert b.x.shape[0] == obs.node_off[-1]
