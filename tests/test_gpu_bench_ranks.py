@@ -33,3 +33,20 @@ def test_bench_two_ranks_gloo_rehearsal(data, issue):
     assert out["config"]["collective"]["backend"].startswith("gloo")
     assert out["config"]["collective"]["overlapped_with_backward"] == (issue == "--eager")
     assert out["config"]["hip_graph"] == (issue == "--graph")
+
+
+@pytest.mark.timeout(900)
+def test_bench_four_ranks_gloo_rehearsal():
+    """Four self-spawned ranks on the one GPU (the box allows six GPU processes: 4 ranks + this one): weak scaling
+    bookkeeping (global batch 1024, value = 1024 graphs / step time) and identical replicas after the averaged update."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--backend", "gloo", "--config", "S256",
+           "--data", "D1", "--steps", "4", "--warmup", "1", "--preheat-ms", "10", "--no-cpu-baseline", "--no-split"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=840)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 1024 and out["config"]["parallelism"] == "dp4"
+    assert out["replicas_identical"] is True and out["scaling"] == "weak"
+    assert abs(out["value"] - 1024 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
