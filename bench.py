@@ -43,6 +43,87 @@ KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_
           8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
 
 
+def make_batches(config, data, B, dev, rank=0):
+    """The two resident batches (maker to move / breaker to move) of a configuration; D1 graphs differ per rank."""
+    from helpers import batch_tensors, sel_and_targets
+    sizes_fn = CONFIGS[config][2]
+    batches = []
+    for maker in (True, False):
+        if data == "D0":
+            x, ei, bv, ptr = batch_tensors("D0", sizes_fn(B), maker=maker)
+        else:
+            from oracle import env_ref          # input generation only (before any timed region)
+            import numpy as np
+            xs, eis, bvs, ptrs, off = [], [], [], [0], 0
+            for g, size in enumerate(sizes_fn(B)):
+                game = env_ref.random_position(size, 100000 * rank + g, maker)
+                gx, gei, _ = game.observe()
+                xs.append(gx); eis.append(gei + off); bvs.append(np.full(gx.shape[0], g, dtype=np.int64))
+                off += gx.shape[0]; ptrs.append(off)
+            x, ei, bv, ptr = (torch.from_numpy(np.concatenate(xs, 0)), torch.from_numpy(np.concatenate(eis, 1)),
+                              torch.from_numpy(np.concatenate(bvs)), torch.tensor(ptrs, dtype=torch.long))
+        sel, tgt = sel_and_targets(ptr, seed=1 + rank)       # every rank regresses on its own targets
+        xd = x.to(dev)
+        xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
+        xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
+        eid = ei.to(dev)
+        eid._hex_grouped = True           # collated graph by graph (what Batch.from_data_list produces and marks)
+        batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
+                            cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
+    return batches
+
+
+def secondary_config(config, data, B, dev, steps, warmup, preheat_ms):
+    """One more BASELINE configuration measured the same way as the headline (HIP-graph replay, preheat, W warm-up steps,
+    K timed steps), so that the driver's record carries it too.  Returns a small dict; never raises."""
+    try:
+        from helpers import make_pair
+        from gnn_hex_amd import ops as hexops
+        from gnn_hex_amd.graphs import GraphedStep
+        num_layers, hidden, _, label = CONFIGS[config]
+        hip, _ = make_pair(num_layers, hidden, seed=0, device=dev)
+        batches = make_batches(config, data, B, dev)
+        plist = list(hip.parameters())
+
+        def local_step(bt):
+            def fn():
+                for p in plist:
+                    p.grad = None
+                q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
+                loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"])
+                loss.backward()
+                return loss
+            return fn
+
+        g0 = GraphedStep(local_step(batches[0]), plist)
+        g1 = GraphedStep(local_step(batches[1]), plist, pool=g0.pool())
+        graphs = (g0, g1)
+        t_pre, k = time.perf_counter(), 0
+        while (time.perf_counter() - t_pre) * 1e3 < preheat_ms:
+            for i in range(16):
+                graphs[i & 1].replay()
+            torch.cuda.synchronize()
+            k += 16
+        for i in range(warmup):
+            graphs[i & 1].replay()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            graphs[i & 1].replay()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        n = (batches[0]["n"] + batches[1]["n"]) / 2.0
+        e = (batches[0]["e"] + batches[1]["e"]) / 2.0
+        step_bytes = 2 * (bytes_fwd(n, e, 2) + (num_layers + 1) * bytes_fwd(n, e, hidden))
+        return {"workload": "%s, %s board graphs (N=%d, E=%d)" % (label, "start-position" if data == "D0" else
+                                                                  "random-playout", batches[0]["n"], batches[0]["e"]),
+                "value": B * steps / dt, "unit": "graphs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+                "warmup": warmup, "preheat_steps": k,
+                "step_hbm_roofline_frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+    except Exception as exc:  # noqa: BLE001  (a secondary line must never take the headline down)
+        return {"workload": "%s %s" % (config, data), "error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def flops_fwd(n, b, h, layers):
     """dense FLOPs of one forward (= of one backward data chain, = of the weight-gradient GEMMs)."""
     return 4.0 * n * 2 * h + (layers + 1) * 4.0 * n * h * h + 2.0 * n * h + 2.0 * b * (4 * h * (h // 2) + h // 2)
@@ -86,6 +167,9 @@ def main():
                     help="N > 1: one all-reduce after the backward instead of the staged backward whose first gradient "
                          "segment is reduced while the rest of the weight-gradient GEMM computes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the extra lines for the other single-GPU BASELINE configurations (D1 boards, GNN-S, MIX) that "
+                         "the default N=1 run appends as `other_configs`")
     ap.add_argument("--no-split", action="store_true", help="skip the informational split-precision timing (clean profiles)")
     args = ap.parse_args()
     if args.graph is None:
@@ -139,29 +223,7 @@ def main():
 
     # two resident batches (maker to move / breaker to move), alternated per step; each rank draws its own
     # graphs for D1 (seed offset by rank), D0 is the same start position everywhere.
-    batches = []
-    for maker in (True, False):
-        if args.data == "D0":
-            x, ei, bv, ptr = batch_tensors("D0", sizes_fn(B), maker=maker)
-        else:
-            from oracle import env_ref
-            import numpy as np
-            xs, eis, bvs, ptrs, off = [], [], [], [0], 0
-            for g, size in enumerate(sizes_fn(B)):
-                game = env_ref.random_position(size, 100000 * rank + g, maker)
-                gx, gei, _ = game.observe()
-                xs.append(gx); eis.append(gei + off); bvs.append(np.full(gx.shape[0], g, dtype=np.int64))
-                off += gx.shape[0]; ptrs.append(off)
-            x, ei, bv, ptr = (torch.from_numpy(np.concatenate(xs, 0)), torch.from_numpy(np.concatenate(eis, 1)),
-                              torch.from_numpy(np.concatenate(bvs)), torch.tensor(ptrs, dtype=torch.long))
-        sel, tgt = sel_and_targets(ptr, seed=1 + rank)       # every rank regresses on its own targets
-        xd = x.to(dev)
-        xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
-        xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
-        eid = ei.to(dev)
-        eid._hex_grouped = True           # collated graph by graph (what Batch.from_data_list produces and marks)
-        batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
-                            cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
+    batches = make_batches(args.config, args.data, B, dev, rank)
 
     plist = list(hip.parameters())
 
@@ -339,6 +401,13 @@ def main():
             hexops.set_math("fp32")
             split = {"math": "f16x3", "value": B * args.steps / dt2, "unit": "graphs/s", "ms_per_step": dt2 / args.steps * 1e3}
 
+        others = None
+        if world == 1 and not args.no_other_configs and args.config == "L256" and args.data == "D0" and B == 256 \
+                and args.math == "fp32":
+            note("the other single-GPU BASELINE configurations (same protocol)")
+            others = [secondary_config(c, d, 256, dev, args.steps, args.warmup, min(args.preheat_ms, 150.0))
+                      for c, d in (("L256", "D1"), ("S256", "D0"), ("MIX", "D0"))]
+
         cpu = None
         if world == 1 and not args.no_cpu_baseline:      # rank 0 at N=1 only (bench contract)
             note("CPU baseline sweep (bounded: ~40 s)")
@@ -355,7 +424,7 @@ def main():
                                    % (label, "start-position" if args.data == "D0" else "random-playout",
                                       B, batches[0]["n"], batches[0]["e"]),
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * world},
-            "roofline": roof, "cpu_baseline": cpu, "split_precision_mode": split,
+            "roofline": roof, "cpu_baseline": cpu, "split_precision_mode": split, "other_configs": others,
         }
         if world > 1:
             out["replicas_identical"] = replicas_identical
