@@ -444,13 +444,16 @@ template <int NT> struct DwShape {
 template <int NT>
 __global__ __launch_bounds__(64 * DwShape<NT>::kWaves) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
     constexpr int HP = 16 * NT;
-    constexpr int R = 32;
+#ifndef HEXGNN_DW_RH
+#define HEXGNN_DW_RH 16
+#endif
+    constexpr int RH = HEXGNN_DW_RH;                    // rows per chunk (a multiple of 4); two chunk buffers
     constexpr int AS = 2 * HP + 16;                     // == 16 (mod 32): conflict-free fragment reads
     constexpr int GS = (NT % 2 == 1) ? HP : HP + 16;
     constexpr int NTHR = 64 * DwShape<NT>::kWaves;
     constexpr int NB = DwShape<NT>::kRegB;
-    __shared__ __attribute__((aligned(16))) float As[R * AS];
-    __shared__ __attribute__((aligned(16))) float Gs[R * GS];
+    __shared__ __attribute__((aligned(16))) float As[2 * RH * AS];
+    __shared__ __attribute__((aligned(16))) float Gs[2 * RH * GS];
     const int li = blockIdx.y, s = blockIdx.x;
     const float* __restrict__ xin = a.xin[li];
     const float* __restrict__ agg = a.agg[li];
@@ -466,9 +469,11 @@ __global__ __launch_bounds__(64 * DwShape<NT>::kWaves) void sage_dw_kernel(DwArg
     for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     float bsum = 0.f;
 
-    // software pipeline: the global loads of chunk i+1 are in flight while chunk i is multiplied out of LDS
-    constexpr int Q = NT * 4;                       // float4 pieces per row
-    constexpr int kPer = (R * Q + NTHR - 1) / NTHR; // pieces per thread per matrix
+    // Double-buffered RH-row chunks (two workgroups per CU as before), ONE barrier per chunk: the global loads of chunk i+2 are
+    // in flight and the LDS writes of chunk i+1 are issued ahead of chunk i's MFMAs and complete under them.  (Single-buffered
+    // 32-row chunks, two barriers each, left the pipe idle while a workgroup staged: 216 -> 210 us at RH = 16.)
+    constexpr int Q = NT * 4;
+    constexpr int kPer = (RH * Q + NTHR - 1) / NTHR;
     f32x4 ra[kPer], rx[kPer], rg[kPer];
     auto issue = [&](int rc) {
 #pragma unroll
@@ -477,46 +482,56 @@ __global__ __launch_bounds__(64 * DwShape<NT>::kWaves) void sage_dw_kernel(DwArg
             const int rr = p / Q, q = p % Q;
             const int row = rc + rr;
             ra[k] = f32x4{0.f, 0.f, 0.f, 0.f}; rx[k] = ra[k]; rg[k] = ra[k];
-            if (p < R * Q && row < r_end) {
+            if (p < RH * Q && row < r_end) {
                 ra[k] = reinterpret_cast<const f32x4*>(agg + (size_t)row * HP)[q];
                 rx[k] = reinterpret_cast<const f32x4*>(xin + (size_t)row * HP)[q];
                 rg[k] = reinterpret_cast<const f32x4*>(gg + (size_t)row * HP)[q];
             }
         }
     };
-    if (r_beg < r_end) issue(r_beg);
-    for (int rc = r_beg; rc < r_end; rc += R) {
+    auto stage = [&](int buf) {
 #pragma unroll
         for (int k = 0; k < kPer; ++k) {
             const int p = tid + NTHR * k;
-            if (p < R * Q) {
+            if (p < RH * Q) {
                 const int rr = p / Q, q = p % Q;
-                *reinterpret_cast<f32x4*>(&As[rr * AS + 4 * q]) = ra[k];
-                *reinterpret_cast<f32x4*>(&As[rr * AS + HP + 4 * q]) = rx[k];
-                *reinterpret_cast<f32x4*>(&Gs[rr * GS + 4 * q]) = rg[k];
+                *reinterpret_cast<f32x4*>(&As[(buf * RH + rr) * AS + 4 * q]) = ra[k];
+                *reinterpret_cast<f32x4*>(&As[(buf * RH + rr) * AS + HP + 4 * q]) = rx[k];
+                *reinterpret_cast<f32x4*>(&Gs[(buf * RH + rr) * GS + 4 * q]) = rg[k];
             }
         }
-        __syncthreads();
-        if (rc + R < r_end) issue(rc + R);
+    };
+    if (r_beg < r_end) {
+        issue(r_beg);
+        stage(0);
+        if (r_beg + RH < r_end) issue(r_beg + RH);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int rc = r_beg; rc < r_end; rc += RH, buf ^= 1) {
+        if (rc + RH < r_end) stage(buf ^ 1);                 // chunk i+1 -> the other buffer (its readers passed the last barrier)
+        if (rc + 2 * RH < r_end) issue(rc + 2 * RH);
+        const float* Ab = As + buf * RH * AS;
+        const float* Gb = Gs + buf * RH * GS;
         if (!extra) {
 #pragma unroll
-            for (int ks = 0; ks < R / 4; ++ks) {
-                const float av = Gs[(4 * ks + kq) * GS + 16 * w + m];
+            for (int ks = 0; ks < RH / 4; ++ks) {
+                const float av = Gb[(4 * ks + kq) * GS + 16 * w + m];
                 bsum += av;
 #pragma unroll
                 for (int t = 0; t < NB; ++t) {
-                    const float bv = As[(4 * ks + kq) * AS + 16 * t + m];
+                    const float bv = Ab[(4 * ks + kq) * AS + 16 * t + m];
                     acc[t] = mfma16x16x4(av, bv, acc[t]);
                 }
             }
         } else {
 #pragma unroll
-            for (int ks = 0; ks < R / 4; ++ks) {
-                const float bv0 = As[(4 * ks + kq) * AS + 16 * NB + m];
-                const float bv1 = As[(4 * ks + kq) * AS + 16 * (NB + 1) + m];
+            for (int ks = 0; ks < RH / 4; ++ks) {
+                const float bv0 = Ab[(4 * ks + kq) * AS + 16 * NB + m];
+                const float bv1 = Ab[(4 * ks + kq) * AS + 16 * (NB + 1) + m];
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    const float av = Gs[(4 * ks + kq) * GS + 16 * t + m];
+                    const float av = Gb[(4 * ks + kq) * GS + 16 * t + m];
                     acc[2 * t] = mfma16x16x4(av, bv0, acc[2 * t]);
                     acc[2 * t + 1] = mfma16x16x4(av, bv1, acc[2 * t + 1]);
                 }

@@ -1,14 +1,14 @@
 #!/bin/bash
-# A/B of two builds of libhexgnn.so on ONE box (gpurun): tools/ab.sh ab/libhexgnn_base.so ab/libhexgnn_exp.so [bench args]
-# Alternates the two libraries three times and prints value / ms_per_step / the three kernel times of each run.
-A=$1; B=$2; shift 2
+# A/B of builds of libhexgnn.so on ONE box (gpurun): tools/ab.sh ab/libhexgnn_base.so ab/libhexgnn_exp.so [more libs ...]
+# Alternates the libraries three times and prints value / ms_per_step / the three kernel times of each run.
+# Extra bench arguments: BENCH_ARGS="--data D1" tools/ab.sh ...
 for rep in 1 2 3; do
-  for lib in $A $B; do
+  for lib in "$@"; do
     cp $lib gnn_hex_amd/libhexgnn.so
-    python bench.py --no-cpu-baseline --no-split --steps 100 --warmup 20 "$@" 2>/dev/null | python -c "
+    python bench.py --no-cpu-baseline --no-split --no-other-configs --steps 100 --warmup 20 $BENCH_ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); k=d['roofline']['kernel_ms_per_step']
 print('$lib', round(d['value']), round(d['ms_per_step'],4), {n[:8]: round(v*1e3,1) for n,v in k.items()})"
   done
 done
-cp $A gnn_hex_amd/libhexgnn.so
+cp $1 gnn_hex_amd/libhexgnn.so
