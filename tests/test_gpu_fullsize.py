@@ -83,3 +83,31 @@ def test_full_batch_against_oracle(name, hinted, path):
         worst = max(worst, gerr)
         assert gerr < TOL * max(1.0, g_ref[k].abs().max().item()), "%s: %s grad max abs err %g" % (name, k, gerr)
     print("%s %s: Q err %.3g, worst grad err %.3g" % (name, path, err, worst))
+
+
+@pytest.mark.parametrize("name", ["L256-D1", "S256-D0"])
+def test_full_batch_acting_and_two_output_forms(name, path):
+    """The forward forms the acting loop and the double-DQN target use, at the benchmark batch: advantages_only (raw
+    2 tanh(a) per node, what DeviceRollout feeds the action selection) and seperate=True (value per graph, centred
+    advantages per node), forward only, against the oracle."""
+    from gnn_hex_amd.models import get_pre_defined
+    from helpers import model_args
+    layers, hidden, kind, sizes, maker = CASES[name]
+    state, (x, ei, batch, ptr, sel, tgt), _, _ = _oracle(name)
+    _, ref = make_pair(layers, hidden, seed=0, device="cpu")
+    ref.load_state_dict(state)
+    hip = get_pre_defined("modern_two_headed", model_args(layers, hidden))
+    hip.load_state_dict(state)
+    hip = hip.cuda()
+    xd, eid = x.cuda(), ei.cuda()
+    xd._hex_is_maker = maker
+    xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())
+    eid._hex_grouped = True
+    with torch.no_grad():
+        a_ref = ref(x, ei, batch, ptr, advantages_only=True)
+        v_ref, c_ref = ref(x, ei, batch, ptr, seperate=True)
+        a = hip(xd, eid, batch.cuda(), ptr.cuda(), advantages_only=True)
+        v, c = hip(xd, eid, batch.cuda(), ptr.cuda(), seperate=True)
+    assert a.shape == a_ref.shape and (a.cpu() - a_ref).abs().max().item() < TOL
+    assert v.shape == v_ref.shape == (256,) and (v.cpu() - v_ref).abs().max().item() < TOL
+    assert (c.cpu() - c_ref).abs().max().item() < TOL
