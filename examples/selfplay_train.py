@@ -33,10 +33,14 @@ def main():
     ap.add_argument("--hidden", type=int, default=110)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=30)
+    ap.add_argument("--warm", type=int, default=5, help="untimed iterations first (graph capture, first launches, allocator)")
     ap.add_argument("--rollout", type=int, default=16, help="moves per env between updates")
     ap.add_argument("--updates", type=int, default=2, help="gradient steps per side and iteration")
     ap.add_argument("--math", default="fp32", choices=["fp32", "f16x3"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--async-rollout", action="store_true",
+                    help="issue the next rollout before this iteration's updates: the GPU plays while the host prepares "
+                         "the update batches; the actor's weights are then one iteration (4 updates) old")
     args = ap.parse_args()
     ops.set_math(args.math)
     gamma, n_step = 0.97, 2
@@ -45,7 +49,7 @@ def main():
     torch.manual_seed(0)
     q_net = get_pre_defined("modern_two_headed", margs).cuda()
     target_net = copy.deepcopy(q_net)
-    opt = torch.optim.Adam(q_net.parameters(), lr=4e-4)
+    opt = torch.optim.Adam(q_net.parameters(), lr=4e-4, fused=True)     # one launch for all 66 parameter tensors
     mgr = Env_manager(args.envs, args.hex_size, gamma=gamma, n_steps=[n_step])
     mgr.reset()
     cap = 65536
@@ -56,19 +60,29 @@ def main():
     frames = updates = games = 0
     last_loss = float("nan")
     t0 = time.perf_counter()
-    for it in range(args.iters):
-        res = rollout.run()
+    ahead = None
+    for it in range(-args.warm, args.iters):
+        if it == 0:       # start of the timed part
+            torch.cuda.synchronize()
+            frames = updates = games = 0
+            t0 = time.perf_counter()
+        res = rollout.run_end(ahead) if ahead is not None else rollout.run()
         frames += args.envs * args.rollout
         games += int(res.dones.sum())
         mb, bb = stitch.assemble(res)
         bufs[True].put_block(mb)
         bufs[False].put_block(bb)
-        for side in (True, False):
-            buf = bufs[side]
-            if len(buf) < args.batch:
-                continue
-            for _ in range(args.updates):
-                idx, w, s, s2, act, r, d = buf.sample(args.batch, beta=0.6)
+        # Updates alternate between the two buffers, and a buffer's next draw (stream-ordered behind its own priority
+        # update) is started right after its update is issued: while the host waits for those indices and builds that
+        # batch, the GPU runs the OTHER buffer's update.
+        sides = [sd for sd in (True, False) if len(bufs[sd]) >= args.batch]
+        pending = {sd: bufs[sd].sample_begin(args.batch, beta=0.6) for sd in sides}
+        # (after put_block: the run overwrites the snapshot ring; after the first draws: they need not wait for the rollout)
+        ahead = rollout.run_begin() if args.async_rollout else None
+        for k in range(args.updates):
+            for side in sides:
+                buf = bufs[side]
+                idx, w, s, s2, act, r, d = buf.sample_end(pending[side])
                 with torch.no_grad():
                     q_on = q_net(s2.x, s2.edge_index, s2.batch, s2.ptr)
                     q_tg = target_net(s2.x, s2.edge_index, s2.batch, s2.ptr)
@@ -80,14 +94,18 @@ def main():
                 loss.backward()
                 opt.step()
                 buf.update_priorities(idx, td.abs() + 1e-3)
+                if k + 1 < args.updates:
+                    pending[side] = buf.sample_begin(args.batch, beta=0.6)
                 updates += 1
                 last_loss = loss.detach()
-        if (it + 1) % 10 == 0:
+        if (it + 1) % 10 == 0 and it >= 0:
             target_net.load_state_dict(q_net.state_dict())
+    if ahead is not None:
+        rollout.run_end(ahead)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print("hex %d, %d envs, GNN %dx%d, math %s: %.0f env frames/s, %.1f updates/s (batch %d), %d games finished, last loss %.4f"
-          % (args.hex_size, args.envs, args.layers, args.hidden, args.math, frames / dt, updates / dt, args.batch, games,
+    print("hex %d, %d envs, GNN %dx%d, math %s%s: %.0f env frames/s, %.1f updates/s (batch %d), %d games finished, last loss %.4f"
+          % (args.hex_size, args.envs, args.layers, args.hidden, args.math, ", rollout one iteration ahead" if args.async_rollout else "", frames / dt, updates / dt, args.batch, games,
              float(last_loss)))
 
 

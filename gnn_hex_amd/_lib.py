@@ -67,6 +67,7 @@ _SIGS = {
     "hexgnn_states_observe": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, C.c_int64, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_per_init": (ci, [ci, vp, vp, vp]),
     "hexgnn_per_update": (ci, [ci, ci, vp, vp, vp, vp, vp]),
+    "hexgnn_per_update_td": (ci, [ci, ci, vp, ci, vp, C.c_double, C.c_double, vp, vp, vp, vp]),
     "hexgnn_per_sample": (ci, [ci, ci, ci, C.c_double, vp, vp, vp, vp, vp, vp]),
     "hexgnn_select_actions": (ci, [ci, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]),
     "hexgnn_td_loss_forward": (ci, [ci, ci, vp, vp, vp, vp, ci, vp, vp, vp]),

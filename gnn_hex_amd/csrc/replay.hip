@@ -17,11 +17,43 @@ namespace hexgnn {
 // its LAST occurrence, as a sequential loop would: an occurrence writes only if no later entry names the same slot
 // (pairwise scan of the list in LDS; the host entry point feeds at most 2048 entries per launch), so sum and min tree
 // always agree.
+//
+// Fused form (hexgnn_per_update_td): the priorities come from the caller's TD errors, p_i = |td_i| + eps, leaf value p_i^alpha,
+// and the running maximum priority *max_prio (what new transitions are stored with) is raised to max_i p_i -- or, with
+// td == nullptr, every listed slot gets (*max_prio)^alpha (a block of new transitions).  One launch instead of the ten small
+// torch kernels of abs / cast / add / max / maximum / pow / index conversion.
+struct PerFused {
+    const float* td; const long long* idx64; double alpha, eps; double* max_prio;
+};
 __global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const int* __restrict__ idx,
-                                                         const double* __restrict__ prio_alpha,
+                                                         const double* __restrict__ prio_alpha, PerFused f,
                                                          double* __restrict__ sum_tree, double* __restrict__ min_tree) {
     __shared__ __attribute__((aligned(16))) int s_idx[2048];
-    for (int i = threadIdx.x; i < 2048; i += 1024) s_idx[i] = i < k ? idx[i] : -1;     // k <= 2048 (host entry point)
+    __shared__ double s_red[16];
+    for (int i = threadIdx.x; i < 2048; i += 1024) {     // k <= 2048 (host entry point)
+        int v = -1;
+        if (i < k) {
+            if (f.idx64) { const long long w = f.idx64[i]; v = (w >= 0 && w < (long long)cap) ? (int)w : -1; }
+            else v = idx[i];
+        }
+        s_idx[i] = v;
+    }
+    const bool fused = prio_alpha == nullptr;
+    double fill = 0.0;
+    if (fused && f.td) {         // running maximum first (block reduce; one workgroup per launch, launches are stream-ordered)
+        double m = 0.0;
+        for (int i = threadIdx.x; i < k; i += 1024) { const double p = (double)fabsf(f.td[i]) + f.eps; m = p > m ? p : m; }
+        for (int o = 32; o >= 1; o >>= 1) { const double t = __shfl_xor(m, o); m = t > m ? t : m; }
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double mm = *f.max_prio;
+            for (int w = 0; w < 16; ++w) mm = s_red[w] > mm ? s_red[w] : mm;
+            *f.max_prio = mm;
+        }
+    } else if (fused) {
+        fill = pow(*f.max_prio, f.alpha);
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < k; i += 1024) {
         const int slot = s_idx[i];
@@ -37,8 +69,9 @@ __global__ __launch_bounds__(1024) void per_update_kernel(int cap, int k, const 
         }
         if (!last) continue;
         const int leaf = cap + slot;
-        sum_tree[leaf] = prio_alpha[i];
-        min_tree[leaf] = prio_alpha[i];
+        const double pa = !fused ? prio_alpha[i] : (f.td ? pow((double)fabsf(f.td[i]) + f.eps, f.alpha) : fill);
+        sum_tree[leaf] = pa;
+        min_tree[leaf] = pa;
     }
     __syncthreads();
     for (int width = cap >> 1, shift = 1; width >= 1; width >>= 1, ++shift) {
@@ -105,7 +138,25 @@ int hexgnn_per_update(int capacity_pow2, int k, const int* idx, const double* pr
     // with its last occurrence (stream order)
     for (int o = 0; o < k; o += 2048) {
         const int kk = k - o < 2048 ? k - o : 2048;
-        per_update_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(capacity_pow2, kk, idx + o, prio_alpha + o, sum_tree, min_tree);
+        per_update_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(capacity_pow2, kk, idx + o, prio_alpha + o, PerFused{}, sum_tree, min_tree);
+    }
+    return check_launch();
+}
+
+int hexgnn_per_update_td(int capacity_pow2, int k, const void* idx, int idx_bits, const float* td, double alpha, double eps,
+                         double* max_priority, double* sum_tree, double* min_tree, hexgnn_stream_t stream_) {
+    if (capacity_pow2 < 1 || (capacity_pow2 & (capacity_pow2 - 1)) || k < 0 || !sum_tree || !min_tree || !max_priority ||
+        (idx_bits != 32 && idx_bits != 64) || !(alpha >= 0.0) || !(eps >= 0.0))
+        return HEXGNN_EINVAL;
+    if (k == 0) return HEXGNN_OK;
+    if (!idx) return HEXGNN_EINVAL;
+    for (int o = 0; o < k; o += 2048) {
+        const int kk = k - o < 2048 ? k - o : 2048;
+        PerFused f{td ? td + o : nullptr, idx_bits == 64 ? static_cast<const long long*>(idx) + o : nullptr, alpha, eps,
+                   max_priority};
+        per_update_kernel<<<1, 1024, 0, (hipStream_t)stream_>>>(capacity_pow2, kk,
+                                                                idx_bits == 32 ? static_cast<const int*>(idx) + o : nullptr,
+                                                                nullptr, f, sum_tree, min_tree);
     }
     return check_launch();
 }

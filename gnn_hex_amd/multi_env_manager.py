@@ -239,17 +239,35 @@ class DeviceRollout:
 
     # -- public ----------------------------------------------------------------------------------------
     def run(self) -> RolloutResult:
+        return self.run_end(self.run_begin())
+
+    def run_begin(self):
+        """Issue the rollout (stream-ordered, nothing is waited for) and return a handle for ``run_end``.  Work issued
+        between the two calls runs behind the rollout on the GPU while the host is free -- e.g. a learner that starts the
+        next rollout before it issues this iteration's updates (the actor then plays with weights one iteration old).
+        The previous run's observations must have been stored (``put_block``) by now: this run overwrites their ring."""
         mgr = self.mgr
         if mgr.global_onturn != self.start_side:
             raise RuntimeError("this rollout was built with %r to move" % self.start_side)
+        if getattr(self, "_open", False):
+            raise RuntimeError("run_begin() called twice without run_end()")
         sizes0 = mgr._sizes.copy()
         self._run_no += 1
-        owner = (self, self._run_no)
         self._upload_offsets()
         if self._graph is not None:
             self._graph.replay()
         else:
             self._body()
+        self._open = True
+        return (self._run_no, sizes0)
+
+    def run_end(self, handle) -> RolloutResult:
+        mgr = self.mgr
+        run_no, sizes0 = handle
+        if not getattr(self, "_open", False) or run_no != self._run_no:
+            raise RuntimeError("run_end() needs the handle of the rollout issued last")
+        self._open = False
+        owner = (self, run_no)
         res = self.result.cpu().numpy()                      # the only read-back (also the synchronisation point)
         if res[:, :, 4].any():
             t, i = np.argwhere(res[:, :, 4])[0]

@@ -118,13 +118,15 @@ class GraphReplayBuffer:
         self.pos = int((self.pos + k) % C)
         self.size = min(C, self.size + k)
         if self.prioritized:
-            pa = (self.max_priority ** self.alpha).expand(k).contiguous()
-            self._tree_update(st.to(torch.int32), pa)
+            self._tree_update_td(st, None)         # new transitions enter at the running maximum priority
 
     def _store_indexed(self, obs_list, start_obs, steps: np.ndarray, envs: np.ndarray, slots: np.ndarray, side: bool):
         """Copy board snapshots ``obs_list[steps[i]][envs[i]]`` (``steps[i] == -1``: the start position) into ring
-        slots; one batched device copy per distinct observation."""
+        slots: the distinct observations' snapshots are concatenated once and all entries move in ONE indexed copy per
+        array (a loop over the observations cost ~8 small launches each: 4 ms of host time per 16-move rollout block)."""
         dev = self.device
+        rows = np.zeros(len(steps), dtype=np.int64)      # row of every entry inside the concatenated snapshots
+        adjs, alives, off = [], [], 0
         for st in np.unique(steps):
             m = steps == st
             obs = start_obs if st < 0 else obs_list[int(st)]
@@ -133,12 +135,20 @@ class GraphReplayBuffer:
             noff, eoff = np.asarray(obs.node_off), np.asarray(obs.edge_off)
             self.n_nodes[sl] = noff[idx + 1] - noff[idx]
             self.n_edges[sl] = eoff[idx + 1] - eoff[idx]
-            it = torch.from_numpy(idx).to(dev)
-            sd = torch.from_numpy(sl).to(dev)
             snap_adj, snap_alive = obs.snapshot()
-            self.adj[sd] = snap_adj[it]
-            self.alive[sd] = snap_alive[it]
-        self.side[torch.from_numpy(slots).to(dev)] = 1 if side else 0
+            adjs.append(snap_adj)
+            alives.append(snap_alive)
+            rows[m] = off + idx
+            off += snap_adj.shape[0]
+        if not adjs:
+            return
+        src = torch.from_numpy(rows).to(dev)
+        dst = torch.from_numpy(np.ascontiguousarray(slots, dtype=np.int64)).to(dev)
+        all_adj = adjs[0] if len(adjs) == 1 else torch.cat(adjs)
+        all_alive = alives[0] if len(alives) == 1 else torch.cat(alives)
+        self.adj.index_copy_(0, dst, all_adj.index_select(0, src))
+        self.alive.index_copy_(0, dst, all_alive.index_select(0, src))
+        self.side.index_fill_(0, dst, 1 if side else 0)
         self.side_host[slots] = 1 if side else 0
 
     def put_block(self, block) -> None:
@@ -153,23 +163,23 @@ class GraphReplayBuffer:
             src, env, act, rew, nxt, done = (v[-C:] for v in (src, env, act, rew, nxt, done))
             k = C
         slots = (self.pos + np.arange(k)) % C
-        self._store_indexed(block.obs_list, block.start_obs, src, env, slots, block.maker_side)
-        self._store_indexed(block.obs_list, block.start_obs, nxt, env, slots + C, block.maker_side)
+        # states into slots [0, C), next states into [C, 2C): one pass
+        self._store_indexed(block.obs_list, block.start_obs, np.concatenate([src, nxt]), np.concatenate([env, env]),
+                            np.concatenate([slots, slots + C]), block.maker_side)
         dev = self.device
-        st = torch.from_numpy(slots).to(dev)
-        self.action[st] = torch.from_numpy(np.ascontiguousarray(act)).to(dev)
-        self.reward[st] = torch.from_numpy(np.ascontiguousarray(rew, dtype=np.float32)).to(dev)
-        self.done[st] = torch.from_numpy(np.ascontiguousarray(done)).to(dev)
+        # slots | actions | done flags | reward bit patterns in ONE host->device copy
+        stage = np.empty((4, k), dtype=np.int64)
+        stage[0], stage[1], stage[2] = slots, act, done
+        stage[3] = np.ascontiguousarray(rew, dtype=np.float32).view(np.int32)
+        sd = torch.from_numpy(stage).to(dev)
+        st = sd[0]
+        self.action.index_copy_(0, st, sd[1])
+        self.done.index_copy_(0, st, sd[2].bool())
+        self.reward.index_copy_(0, st, sd[3].int().view(torch.float32))
         self.pos = int((self.pos + k) % C)
         self.size = min(C, self.size + k)
         if self.prioritized:
-            pa = (self.max_priority ** self.alpha).expand(k).contiguous()
-            self._tree_update(st.to(torch.int32), pa)
-
-    def _tree_update(self, idx32: torch.Tensor, prio_alpha: torch.Tensor):
-        _lib.check(_lib.lib().hexgnn_per_update(self.cap2, int(idx32.numel()), idx32.data_ptr(), prio_alpha.data_ptr(),
-                                                self.sum_tree.data_ptr(), self.min_tree.data_ptr(), ops._stream()),
-                   "hexgnn_per_update")
+            self._tree_update_td(st, None)         # new transitions enter at the running maximum priority
 
     # ---- sampling ----------------------------------------------------------------------------------------
     def _build_batch(self, slots_dev: torch.Tensor, slots_host: np.ndarray) -> Batch:
@@ -210,6 +220,13 @@ class GraphReplayBuffer:
         """Returns ``(indices, weights, state, next_state, action, reward, done)`` (weights all one when the buffer is
         not prioritized), states as device ``Batch`` objects.  One device->host copy of the sampled indices is needed
         to size the batches (the graph sizes live on the host)."""
+        return self.sample_end(self.sample_begin(batch_size, beta, generator))
+
+    def sample_begin(self, batch_size: int, beta: Optional[float] = None, generator: Optional[torch.Generator] = None):
+        """First half of ``sample``: draws the indices on the device (stream-ordered behind every priority update issued
+        so far) and starts their copy to pinned host memory; returns a handle for ``sample_end``.  A loop with several
+        buffers can begin the next buffer's draw before it waits for this one, so that the host builds one batch while
+        the GPU still runs the previous update (examples/selfplay_train.py)."""
         if self.size == 0:
             raise ValueError("empty buffer")
         dev = self.device
@@ -224,7 +241,20 @@ class GraphReplayBuffer:
         else:
             idx = torch.randint(0, self.size, (batch_size,), device=dev, generator=generator)
             w = torch.ones(batch_size, dtype=torch.float32, device=dev)
-        host = idx.cpu().numpy()
+        host = torch.empty(batch_size, dtype=torch.int64, pin_memory=True)
+        host.copy_(idx, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        return (idx, w, host, ev, (self.pos, self.size))
+
+    def sample_end(self, pending):
+        idx, w, host_t, ev, stamp = pending
+        if stamp != (self.pos, self.size):
+            raise RuntimeError("transitions were stored between sample_begin and sample_end: the drawn slots may have been "
+                               "overwritten")
+        ev.synchronize()
+        host = host_t.numpy().copy()
+        batch_size = len(host)
         state = self._build_batch(idx, host)
         nxt = self._build_batch(idx + self.capacity, host + self.capacity)
         # all stored states of one buffer share the mover's side (maker / breaker buffers are separate)
@@ -235,8 +265,21 @@ class GraphReplayBuffer:
         return idx, w, state, nxt, self.action[idx], self.reward[idx], self.done[idx]
 
     def update_priorities(self, indices: torch.Tensor, td_errors: torch.Tensor) -> None:
+        """priority_i = |td_i| + eps (the running maximum is raised to the largest), leaf = priority^alpha: one launch."""
         if not self.prioritized:
             return
-        p = td_errors.detach().abs().to(torch.float64).flatten() + self.eps
-        self.max_priority = torch.maximum(self.max_priority, p.max())
-        self._tree_update(indices.to(device=self.device, dtype=torch.int32).contiguous(), (p ** self.alpha).contiguous())
+        idx = indices.to(device=self.device)
+        if idx.dtype not in (torch.int32, torch.int64):
+            idx = idx.long()
+        idx = idx.contiguous().flatten()
+        td = td_errors.detach().to(device=self.device, dtype=torch.float32).contiguous().flatten()
+        if td.numel() != idx.numel():
+            raise ValueError("indices and td_errors differ in length")
+        self._tree_update_td(idx, td)
+
+    def _tree_update_td(self, idx: torch.Tensor, td: Optional[torch.Tensor]):
+        _lib.check(_lib.lib().hexgnn_per_update_td(self.cap2, int(idx.numel()), idx.data_ptr(),
+                                                   64 if idx.dtype == torch.int64 else 32,
+                                                   td.data_ptr() if td is not None else None, self.alpha, self.eps,
+                                                   self.max_priority.data_ptr(), self.sum_tree.data_ptr(),
+                                                   self.min_tree.data_ptr(), ops._stream()), "hexgnn_per_update_td")

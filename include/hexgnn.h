@@ -276,6 +276,11 @@ int hexgnn_states_observe(int hex_size, int k, const uint64_t* adj, const uint8_
 int hexgnn_per_init(int capacity_pow2, double* sum_tree, double* min_tree, hexgnn_stream_t stream);
 int hexgnn_per_update(int capacity_pow2, int k, const int* idx, const double* prio_alpha, double* sum_tree,
                       double* min_tree, hexgnn_stream_t stream);
+/* Fused priority update (one launch): td != NULL: p_i = |td[i]| + eps, leaf idx[i] <- p_i^alpha (last occurrence of a slot
+ * wins), *max_priority <- max(*max_priority, max_i p_i); td == NULL: every listed leaf <- (*max_priority)^alpha (a block of
+ * new transitions stored at the running maximum).  idx: int32 (idx_bits 32) or int64 (64) slots; out-of-range ones are ignored. */
+int hexgnn_per_update_td(int capacity_pow2, int k, const void* idx, int idx_bits, const float* td, double alpha, double eps,
+                         double* max_priority, double* sum_tree, double* min_tree, hexgnn_stream_t stream);
 int hexgnn_per_sample(int capacity_pow2, int size, int b, double beta, const double* u, const double* sum_tree,
                       const double* min_tree, int* out_idx, float* out_w, hexgnn_stream_t stream);
 

@@ -252,6 +252,33 @@ def test_device_rollout_equals_step_by_step_loop(graph):
         assert a.global_onturn == b.global_onturn and (a._sizes == b._sizes).all()
 
 
+def test_split_rollout_equals_run_with_work_issued_in_between():
+    """run_begin / run_end with GPU work issued between the two (a learner preparing its update while the actor plays)
+    give the games run() gives; a second run_begin or a foreign handle is refused."""
+    import torch
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
+    from helpers import make_pair
+    hip, _ = make_pair(3, 35, seed=4)
+    a, b = Env_manager(8, 5, gamma=0.9), Env_manager(8, 5, gamma=0.9)
+    a.reset(); b.reset()
+    ra = DeviceRollout(a, hip, steps=8, eps=0.0, graph=True)
+    rb = DeviceRollout(b, hip, steps=8, eps=0.0, graph=True)
+    for _round in range(2):
+        want = ra.run()
+        h = rb.run_begin()
+        with pytest.raises(RuntimeError, match="twice"):
+            rb.run_begin()
+        junk = torch.randn(512, 512, device="cuda") @ torch.randn(512, 512, device="cuda")   # queued behind the rollout
+        got = rb.run_end(h)
+        assert junk.isfinite().all()
+        assert got.vertices.tolist() == want.vertices.tolist() and got.dones.tolist() == want.dones.tolist()
+        assert got.rewards.tolist() == want.rewards.tolist()
+        for sa, sb in zip(want.states, got.states):
+            assert sa.node_off == sb.node_off and torch.equal(sa.snapshot()[0], sb.snapshot()[0])
+    with pytest.raises(RuntimeError, match="handle"):
+        rb.run_end(h)
+
+
 def test_device_rollout_feeds_replay():
     """Rollout histories -> vectorised n-step assembly -> device replay ring -> sampled batches the model accepts."""
     import torch

@@ -96,6 +96,55 @@ def test_per_trees_at_the_reference_buffer_size():
         assert np.allclose(ow.cpu().numpy(), rw, rtol=1e-6, atol=0)
 
 
+@pytest.mark.parametrize("bits", [32, 64])
+def test_fused_priority_update_matches_oracle(bits):
+    """hexgnn_per_update_td: leaf = (|td| + eps)^alpha with the last occurrence of a slot winning, running maximum raised to
+    the largest priority; td == NULL stores (running maximum)^alpha -- against the oracle fed with numpy's values (pow may
+    differ in the last place between libms: 1e-14 relative), over a list longer than one launch chunk."""
+    from gnn_hex_amd import _lib, ops
+    from oracle.replay_ref import SegmentTreePER
+    L = _lib.lib()
+    cap, alpha, eps = 1 << 13, 0.5, 1e-6
+    st = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+    mt = torch.empty(2 * cap, dtype=torch.float64, device="cuda")
+    _lib.check(L.hexgnn_per_init(cap, st.data_ptr(), mt.data_ptr(), ops._stream()))
+    mp = torch.ones((), dtype=torch.float64, device="cuda")
+    ref = SegmentTreePER(cap)
+    rng = np.random.default_rng(21)
+    dt = np.int32 if bits == 32 else np.int64
+    # 1. a block of new transitions at the running maximum (1.0)
+    new = np.arange(0, 5000).astype(dt)
+    ref.update(new.astype(np.int32), np.full(len(new), 1.0 ** alpha))
+    dn = torch.from_numpy(new).cuda()
+    _lib.check(L.hexgnn_per_update_td(cap, len(new), dn.data_ptr(), bits, None, alpha, eps, mp.data_ptr(), st.data_ptr(),
+                                      mt.data_ptr(), ops._stream()))
+    # 2. TD errors for a sampled batch with duplicates, longer than one chunk; one out-of-range slot is ignored
+    k = 3000
+    idx = rng.integers(0, 5000, k).astype(dt)
+    idx[17] = idx[2900]
+    idx[5] = cap + 3 if bits == 64 else -1
+    td = (rng.standard_normal(k) * 3).astype(np.float32)
+    p = np.abs(td).astype(np.float64) + eps
+    keep = (idx >= 0) & (idx < cap)
+    ref.update(idx[keep].astype(np.int32), p[keep] ** alpha)
+    di, dtd = torch.from_numpy(idx).cuda(), torch.from_numpy(td).cuda()
+    _lib.check(L.hexgnn_per_update_td(cap, k, di.data_ptr(), bits, dtd.data_ptr(), alpha, eps, mp.data_ptr(), st.data_ptr(),
+                                      mt.data_ptr(), ops._stream()))
+    torch.cuda.synchronize()
+    assert float(mp) == max(1.0, float(p.max()))         # every entry counts for the maximum, as in the torch expression
+    got_sum, got_min = st.cpu().numpy(), mt.cpu().numpy()
+    assert np.allclose(got_sum[1:], ref.sum[1:], rtol=1e-13, atol=0)
+    fin = np.isfinite(ref.min)
+    assert np.allclose(got_min[fin], ref.min[fin], rtol=1e-13, atol=0) and np.array_equal(np.isfinite(got_min), fin)
+    # 3. the next block of new transitions enters at the raised maximum
+    new2 = np.arange(5000, 5100).astype(dt)
+    dn2 = torch.from_numpy(new2).cuda()
+    _lib.check(L.hexgnn_per_update_td(cap, len(new2), dn2.data_ptr(), bits, None, alpha, eps, mp.data_ptr(), st.data_ptr(),
+                                      mt.data_ptr(), ops._stream()))
+    torch.cuda.synchronize()
+    assert np.allclose(st.cpu().numpy()[cap + 5000:cap + 5100], float(mp) ** alpha, rtol=1e-14, atol=0)
+
+
 def test_per_update_duplicates_last_wins_and_large_lists():
     """PER samples with replacement, so update_priorities sees duplicated slots: the last occurrence must win in BOTH
     trees (oracle: sequential loop), deterministically, also across the 2048-entry launch chunks of a long list."""
@@ -180,6 +229,43 @@ def test_replay_round_trip_with_env_transitions():
     # wrap-around keeps the newest transitions
     buf.put(breaker)
     assert len(buf) == 64
+
+
+def test_split_sampling_equals_sample_and_guards_against_stores():
+    """sample_begin / sample_end (the draw started early, the batch built later: examples/selfplay_train.py) return what
+    sample() returns for the same generator state -- also with another buffer's draw and a priority update of that other
+    buffer in between -- and refuse to finish a draw across a put()."""
+    from gnn_hex_amd.multi_env_manager import Env_manager
+    from gnn_hex_amd.replay import GraphReplayBuffer
+    rng = np.random.default_rng(11)
+    mgr = Env_manager(12, 5, gamma=0.97, n_steps=[2])
+    obs0, states, actions, rewards, dones, expl = _play(mgr, 14, rng)
+    maker, breaker = mgr.get_transitions(obs0, states, actions, rewards, dones, expl)
+    bufs = []
+    for _ in range(2):
+        a, b = GraphReplayBuffer(64, 5, prioritized=True, alpha=0.5), GraphReplayBuffer(64, 5, prioritized=True, alpha=0.5)
+        a.put(maker[:40]); b.put(breaker[:40])
+        a.update_priorities(torch.arange(8, device="cuda"), torch.linspace(0.5, 9.0, 8, device="cuda"))
+        bufs.append((a, b))
+    (a1, b1), (a2, b2) = bufs
+    g1 = torch.Generator(device="cuda").manual_seed(5)
+    g2 = torch.Generator(device="cuda").manual_seed(5)
+    want = a1.sample(16, beta=0.6, generator=g1)
+    pend = a2.sample_begin(16, beta=0.6, generator=g2)
+    other = b2.sample_begin(16, beta=0.6)                     # interleaved work on the other buffer
+    b2.update_priorities(other[0], torch.ones(16, device="cuda"))
+    b2.sample_end(other)
+    got = a2.sample_end(pend)
+    for w_, g_ in zip(want, got):
+        if torch.is_tensor(w_):
+            assert torch.equal(w_, g_)
+        else:
+            assert torch.equal(w_.x, g_.x) and torch.equal(w_.edge_index, g_.edge_index) and torch.equal(w_.ptr, g_.ptr)
+            assert w_.x._hex_is_maker == g_.x._hex_is_maker and w_.x._hex_max_nodes == g_.x._hex_max_nodes
+    pend = a2.sample_begin(8, beta=0.6)
+    a2.put(maker[40:44])
+    with pytest.raises(RuntimeError, match="between sample_begin and sample_end"):
+        a2.sample_end(pend)
 
 
 def test_sampled_batch_drives_the_model():
