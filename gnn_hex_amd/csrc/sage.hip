@@ -11,7 +11,10 @@
 // its row r, the feature chunks {16c+4g .. 16c+4g+3} of every in-neighbour straight into registers; these
 // four floats are the k-slices of four consecutive v_mfma_f32_16x16x4_f32 (the K order is permuted
 // consistently on the packed-weight side).  fp32 in / fp32 accumulate: exact fmaf chains, deterministic.
+#include <type_traits>
+#include <utility>
 #include "hexgnn_internal.h"
+#include "hexgnn_memops.h"
 
 namespace hexgnn {
 
@@ -267,42 +270,212 @@ __device__ __forceinline__ void gather_rows_global(const float* __restrict__ row
     }
 }
 
-// ---- hidden layer forward ----------------------------------------------------------------------------
-template <int NT>
-__global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
-    int n, const int* __restrict__ rowptr, const int* __restrict__ col, const float* __restrict__ invdeg,
-    const float* __restrict__ x, const f32x4* __restrict__ wpack, const float* __restrict__ bias,
-    float* __restrict__ y, float* __restrict__ agg_out, int relu) {
-    constexpr int HP = 16 * NT;
-    extern __shared__ f32x4 wlds[];  // [2NT][NT][64]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 2 * NT * NT * 64; i += 512) wlds[i] = wpack[i];
+template <int B, int E, typename F>
+__device__ __forceinline__ void static_for_(F&& f) {
+    if constexpr (B < E) { f(std::integral_constant<int, B>{}); static_for_<B + 1, E>(f); }
+}
 
+#ifdef HEXGNN_STAMPS
+// profiling builds only (make STAMPS=1, tools/layer_stamps.py): lane 0 of every wave of one mid-grid workgroup records
+// s_memtime at fixed points of the layer-major kernels (the last launch of each kind wins)
+__device__ unsigned long long g_lstamps[2][8][8];
+#define LSTAMP(k, p) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) g_lstamps[k][p][threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define LSTAMP(k, p) do {} while (0)
+#endif
+
+// ---- hidden layer, forward and backward (data) -------------------------------------------------------------------
+//   forward :  y_i   = act( mean_{j in N(i)} x_j W_l^T + x_i W_r^T + b )                       (GN0/torch_script_models.py:52-73)
+//   backward:  dY_i  = ( sum_{j in T(i)} G_j / deg_j ) W_l + G_i W_r,   G' = dY * [y' > 0]       (its autograd transpose, with
+//              the gather moved in front of the contraction: it is linear, and the kernel then has the forward's shape)
+// One 128-row block per 512-thread workgroup, wave w = rows 16w..16w+15, lane (r, g) = row r, 16-byte column slots g, g+4, ...
+// Timeline of a launch (tools/layer_stamps.py; the straight-line version spent 3.7 us staging weights, 9.5 us in the gather's
+// dependent chain rowptr -> column ids -> neighbour rows and 13.5 us in MFMAs, one after the other):
+//   1. both weight parts -> LDS by LDS-DMA (no registers, nothing waits); self rows, CSR row bounds and -- from the batch's
+//      padded neighbour table `ell` [n][16] (hexgnn_ell_build, once per batch) -- the row's first sixteen neighbour ids are
+//      requested alongside: ONE memory round trip, then the barrier;
+//   2. self half (rows x W_r part) on the matrix pipe while the gather runs underneath it: neighbour rows come in three
+//      rounds of four 16-byte-slot sets (raw buffer loads; a missing neighbour is an out-of-range offset = zeros, so every
+//      lane issues the same instructions) and are added in ascending neighbour order between MFMA groups;
+//   3. rows with more than sixteen neighbours finish their sum from the CSR, then the aggregate half, epilogue.
+// Without a table (ell == nullptr) the ids come from the CSR after the barrier: one more dependent round trip.
+constexpr int kEll = HEXGNN_ELL_WIDTH;
+
+__global__ void ell_build_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ col, int* __restrict__ ell) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * kEll) return;
+    const int row = i / kEll, k = i % kEll;
+    const int e = rowptr[row] + k;
+    ell[i] = e < rowptr[row + 1] ? col[e] : -1;
+}
+
+// Gather schedule of the self half: the W * NT 16-byte neighbour loads of a lane are issued kP per gap (a gap = the slot
+// behind one (chunk, tile) group of four MFMAs; a burst of loads instead would hold the wave -- and with it its MFMAs -- in
+// the CU's 64 B/clk vector-memory issue path), neighbour k lands in buffer k % kWin and is added kD gaps after its last
+// load, before the first load of neighbour k + kWin in the same buffer.  Gaps past the last MFMA group run behind the loop.
+template <int NT> struct GatherSched {
+    static constexpr int W = kEll;
+    static constexpr int G = NT * NT;
+    static constexpr int kWin = NT >= 4 ? 4 : 8;
+    static constexpr int kSpan = (7 * G) / 8 > 0 ? (7 * G) / 8 : 1;
+    static constexpr int kPspan = (W * NT + kSpan - 1) / kSpan;
+    static constexpr int kPmax = (kWin * NT - NT + 1) / 2;           // keeps kD >= 1: an add never shares a gap with its loads
+    static constexpr int kP = kPspan < kPmax ? kPspan : kPmax;
+    static constexpr int kD = (kWin * NT - (NT - 1)) / kP - 1;
+    static constexpr int load_gap(int k, int c) { return (k * NT + c) / kP; }
+    static constexpr int add_gap(int k) { return load_gap(k, NT - 1) + kD; }
+    static constexpr int kGaps = add_gap(W - 1) + 1 > G ? add_gap(W - 1) + 1 : G;
+    static constexpr bool ok() {
+        if (kP < 1 || kD < 1) return false;
+        for (int k = 0; k + kWin < W; ++k)
+            if (add_gap(k) > load_gap(k + kWin, 0)) return false;      // (adds run before the loads of a gap)
+        return true;
+    }
+    static_assert(ok(), "a landing buffer would be reloaded before it is consumed");
+};
+
+template <int NT, bool BWD>
+__device__ __forceinline__ void sage_layer_body(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ ell,
+    const float* __restrict__ invdeg, const float* __restrict__ x, const f32x4* __restrict__ wpack,
+    const float* __restrict__ bias, const float* __restrict__ ymask, float* __restrict__ out,
+    float* __restrict__ agg_out, int relu, f32x4* wlds) {
+    constexpr int HP = 16 * NT;
+    constexpr int K = BWD ? 1 : 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    LSTAMP(K, 0);
+    {
+        const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wlds;
+        for (int p = wave; p < 2 * NT * NT; p += 8) dma_piece(wpack + p * 64, 16 * lane, lds_w + p * 1024);
+    }
     const int row0 = (blockIdx.x * 8 + wave) * 16;
     const int r = lane & 15, g = lane >> 4;
     const int row = row0 + r;
+    const bool valid = row < n;
     f32x4 xs[NT], ag[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) { xs[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-    if (row < n) {
+    int e0 = 0, e1 = 0;
+    int nid[kEll];
+#pragma unroll
+    for (int k = 0; k < kEll; ++k) nid[k] = -1;
+    float sc = 0.f;
+    if (valid) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * HP) + g;
 #pragma unroll
         for (int c = 0; c < NT; ++c) xs[c] = xr[4 * c];
-        gather_rows_global<NT>(x, col, rowptr[row], rowptr[row + 1], g, ag);
-        const float sc = invdeg[row];
+        e0 = rowptr[row];
+        e1 = rowptr[row + 1];
+        if (ell) {
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
+            const i32x4* er = reinterpret_cast<const i32x4*>(ell + (size_t)row * kEll);
 #pragma unroll
-        for (int c = 0; c < NT; ++c) ag[c] *= sc;
-        if (agg_out) {
-            f32x4* ar = reinterpret_cast<f32x4*>(agg_out + (size_t)row * HP) + g;
-#pragma unroll
-            for (int c = 0; c < NT; ++c) ar[4 * c] = ag[c];
+            for (int q = 0; q < kEll / 4; ++q) {
+                const i32x4 v = er[q];
+                nid[4 * q] = v[0]; nid[4 * q + 1] = v[1]; nid[4 * q + 2] = v[2]; nid[4 * q + 3] = v[3];
+            }
         }
+        if constexpr (!BWD) sc = invdeg[row];
     }
+    wait_vmem();
+    LSTAMP(K, 1);
     __syncthreads();
+    LSTAMP(K, 3);
+
+    const __amdgpu_buffer_rsrc_t xr_ = slab_rsrc(x);
+    const int deg = e1 - e0;
+    if (!ell) {      // ids from the CSR (zeros past the row's end: the offsets below are then out of range anyway)
+        const __amdgpu_buffer_rsrc_t colr = slab_rsrc(col);
+#pragma unroll
+        for (int k = 0; k < kEll; ++k)
+            nid[k] = __builtin_amdgcn_raw_buffer_load_b32(colr, k < deg ? (unsigned)(e0 + k) * 4u : kOob, 0, 0);
+    }
+    float ns[BWD ? kEll : 1];       // backward: 1 / deg of the neighbour the gradient row comes from
+    if constexpr (BWD) {
+        const __amdgpu_buffer_rsrc_t ir = slab_rsrc(invdeg);
+#pragma unroll
+        for (int k = 0; k < kEll; ++k)
+            ns[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, k < deg ? (unsigned)nid[k] * 4u : kOob, 0, 0));
+    }
+    using GS = GatherSched<NT>;
+    unsigned noff[kEll];             // byte offset of neighbour k's row slot (out of range: no such neighbour -> zeros)
+#pragma unroll
+    for (int k = 0; k < kEll; ++k) noff[k] = k < deg ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
+    int wmax = deg < kEll ? deg : kEll;          // wave-uniform number of neighbour slots anybody in the wave uses
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    f32x4 tb[GS::kWin][NT];
+    auto filler = [&](auto qq) {
+        constexpr int Q = decltype(qq)::value;            // gap index behind the (c, t) group c * NT + t of the self half
+        static_for_<0, kEll>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            if constexpr (GS::add_gap(k) == Q) {
+                if (k < wmax) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        if constexpr (BWD) ag[c] += tb[k % GS::kWin][c] * ns[k];
+                        else ag[c] += tb[k % GS::kWin][c];
+                    }
+                }
+            }
+        });
+        static_for_<Q * GS::kP, (Q + 1) * GS::kP < kEll * NT ? (Q + 1) * GS::kP : kEll * NT>([&](auto ii) {
+            constexpr int i = decltype(ii)::value, k = i / NT, c = i % NT;
+            if (k < wmax) tb[k % GS::kWin][c] = buf_load(xr_, noff[k] + 64 * c);
+        });
+    };
 
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    static_for_<0, NT>([&](auto cc) {
+        constexpr int c = decltype(cc)::value;
+        static_for_<0, NT>([&](auto tt) {
+            constexpr int t = decltype(tt)::value;
+            const f32x4 b = wlds[((NT + c) * NT + t) * 64 + lane];
+            acc[t] = mfma16x16x4(b[0], xs[c][0], acc[t]);
+            acc[t] = mfma16x16x4(b[1], xs[c][1], acc[t]);
+            acc[t] = mfma16x16x4(b[2], xs[c][2], acc[t]);
+            acc[t] = mfma16x16x4(b[3], xs[c][3], acc[t]);
+            __builtin_amdgcn_sched_barrier(0);
+            filler(std::integral_constant<int, c * NT + t>{});
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    });
+    static_for_<NT * NT, GS::kGaps>([&](auto qq) { filler(qq); });     // (narrow layers: the schedule outlasts the MFMA groups)
+    LSTAMP(K, 2);
+    f32x4 ym[BWD ? NT : 1];
+    if constexpr (BWD) {               // the mask rows land under the aggregate half
+        const __amdgpu_buffer_rsrc_t yr_ = slab_rsrc(ymask);
+        const unsigned off = (valid && ymask) ? (unsigned)row * (unsigned)(HP * 4) + 16u * g : kOob;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ym[c] = buf_load(yr_, off + 64 * c);
+    }
+    if (valid) {
+        if (deg > kEll) {              // the rest of a long row (the two terminals of a board late in a game), from the CSR
+            for (int e = e0 + kEll; e < e1; ++e) {
+                const int j = col[e];
+                const f32x4* xj = reinterpret_cast<const f32x4*>(x + (size_t)j * HP) + g;
+                float sj = 1.f;
+                if constexpr (BWD) sj = invdeg[j];
+#pragma unroll
+                for (int c = 0; c < NT; ++c) {
+                    if constexpr (BWD) ag[c] += xj[4 * c] * sj;
+                    else ag[c] += xj[4 * c];
+                }
+            }
+        }
+        if constexpr (!BWD) {
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ag[c] *= sc;
+            if (agg_out) {
+                f32x4* ar = reinterpret_cast<f32x4*>(agg_out + (size_t)row * HP) + g;
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ar[4 * c] = ag[c];
+            }
+        }
+    }
 #pragma unroll
     for (int c = 0; c < NT; ++c) {
 #pragma unroll
@@ -314,92 +487,52 @@ __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
             acc[t] = mfma16x16x4(b[3], ag[c][3], acc[t]);
         }
     }
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 b = wlds[((NT + c) * NT + t) * 64 + lane];
-            acc[t] = mfma16x16x4(b[0], xs[c][0], acc[t]);
-            acc[t] = mfma16x16x4(b[1], xs[c][1], acc[t]);
-            acc[t] = mfma16x16x4(b[2], xs[c][2], acc[t]);
-            acc[t] = mfma16x16x4(b[3], xs[c][3], acc[t]);
-        }
-    }
     // epilogue.  Operands are swapped (a = packed W^T fragment, b = the row fragment), so the MFMA computes the
-    // TRANSPOSED tile: lane (r,g) holds y[row0+r][16t+4g .. 16t+4g+3] -- the same lane layout as the input rows.
-    if (row < n) {
-        f32x4* yr = reinterpret_cast<f32x4*>(y + (size_t)row * HP) + g;
-        const f32x4* br = reinterpret_cast<const f32x4*>(bias) + g;
+    // TRANSPOSED tile: lane (r,g) holds out[row0+r][16t+4g .. 16t+4g+3] -- the same lane layout as the input rows.
+    LSTAMP(K, 4);
+    if (valid) {
+        f32x4* yr = reinterpret_cast<f32x4*>(out + (size_t)row * HP) + g;
+        if constexpr (!BWD) {
+            const f32x4* br = reinterpret_cast<const f32x4*>(bias) + g;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            f32x4 v = acc[t] + br[4 * t];
+            for (int t = 0; t < NT; ++t) {
+                f32x4 v = acc[t] + br[4 * t];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = (v[q] > 0.f || !relu) ? v[q] : 0.f;
-            yr[4 * t] = v;
+                for (int q = 0; q < 4; ++q) v[q] = (v[q] > 0.f || !relu) ? v[q] : 0.f;
+                yr[4 * t] = v;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                f32x4 v = acc[t];
+                if (ymask) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = ym[t][q] > 0.f ? v[q] : 0.f;
+                }
+                yr[4 * t] = v;
+            }
         }
     }
+    LSTAMP(K, 5);
 }
 
-// ---- hidden layer backward (data): G = (dXs' + sum_{j in T(i)} dAggS'_j) * [y>0];  [dAggS|dXs] = G [Wl|Wr] -----
+template <int NT>
+__global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
+    int n, const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ ell,
+    const float* __restrict__ invdeg, const float* __restrict__ x, const f32x4* __restrict__ wpack,
+    const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ agg_out, int relu) {
+    extern __shared__ f32x4 wlds[];  // [2NT][NT][64]: W_l part, then W_r part
+    sage_layer_body<NT, false>(n, rowptr, col, ell, invdeg, x, wpack, bias, nullptr, y, agg_out, relu, wlds);
+}
+
+// G_l rows in, dY = [sum_T G / deg | G] [W_l ; W_r] masked by y_{l-1} (ymask, null: unmasked) out
 template <int NT>
 __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
-    int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t, const float* __restrict__ invdeg,
-    const float* __restrict__ dxs_in, const float* __restrict__ dagg_in /*null: dxs_in is dY*/,
-    const float* __restrict__ y, const f32x4* __restrict__ wpackb,
-    float* __restrict__ g_out, float* __restrict__ dagg_out, float* __restrict__ dxs_out, int relu) {
-    constexpr int HP = 16 * NT;
+    int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t, const int* __restrict__ ell_t,
+    const float* __restrict__ invdeg, const float* __restrict__ g_in, const f32x4* __restrict__ wpackb,
+    const float* __restrict__ ymask, float* __restrict__ out) {
     extern __shared__ f32x4 wlds[];  // [2][NT][NT][64]: W_l part, W_r part
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 2 * NT * NT * 64; i += 512) wlds[i] = wpackb[i];
-
-    const int row0 = (blockIdx.x * 8 + wave) * 16;
-    const int r = lane & 15, g = lane >> 4;
-    const int row = row0 + r;
-    f32x4 gx[NT];
-#pragma unroll
-    for (int c = 0; c < NT; ++c) gx[c] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (row < n) {
-        const f32x4* dr = reinterpret_cast<const f32x4*>(dxs_in + (size_t)row * HP) + g;
-#pragma unroll
-        for (int c = 0; c < NT; ++c) gx[c] = dr[4 * c];
-        if (dagg_in) gather_rows_global<NT>(dagg_in, col_t, rowptr_t[row], rowptr_t[row + 1], g, gx);
-        const f32x4* yr = reinterpret_cast<const f32x4*>(y + (size_t)row * HP) + g;
-        f32x4* go = reinterpret_cast<f32x4*>(g_out + (size_t)row * HP) + g;
-#pragma unroll
-        for (int c = 0; c < NT; ++c) {
-            const f32x4 yv = yr[4 * c];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) gx[c][j] = (yv[j] > 0.f || !relu) ? gx[c][j] : 0.f;
-            go[4 * c] = gx[c];
-        }
-    }
-    __syncthreads();
-
-    f32x4 acc[2 * NT];
-#pragma unroll
-    for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < NT; ++c) {
-#pragma unroll
-        for (int t = 0; t < 2 * NT; ++t) {
-            const f32x4 b = wlds[((t / NT) * NT * NT + c * NT + (t % NT)) * 64 + lane];
-            acc[t] = mfma16x16x4(b[0], gx[c][0], acc[t]);
-            acc[t] = mfma16x16x4(b[1], gx[c][1], acc[t]);
-            acc[t] = mfma16x16x4(b[2], gx[c][2], acc[t]);
-            acc[t] = mfma16x16x4(b[3], gx[c][3], acc[t]);
-        }
-    }
-    // transposed tiles (see the forward kernel): lane (r,g) holds out[row0+r][16t+4g .. +3]
-    if (row < n) {
-        const float sc = invdeg[row];
-        f32x4* da = reinterpret_cast<f32x4*>(dagg_out + (size_t)row * HP) + g;
-        f32x4* dx = reinterpret_cast<f32x4*>(dxs_out + (size_t)row * HP) + g;
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            da[4 * t] = acc[t] * sc;
-            dx[4 * t] = acc[NT + t];
-        }
-    }
+    sage_layer_body<NT, true>(n, rowptr_t, col_t, ell_t, invdeg, g_in, wpackb, nullptr, ymask, out, nullptr, 1, wlds);
 }
 
 // ---- out = dxs + sum_{j in T(i)} dagg_j, optionally masked by y>0 (stack-input gradient / G of a raw first layer) ----
@@ -806,7 +939,7 @@ __global__ __launch_bounds__(64) void sage_first_dw_reduce_kernel(
 
 // ---- host-side dispatch ---------------------------------------------------------------------------------
 template <int NT>
-static void launch_fwd(int n, const int* rowptr, const int* col, const float* invdeg, const float* x,
+static void launch_fwd(int n, const int* rowptr, const int* col, const int* ell, const float* invdeg, const float* x,
                        const void* wp, const float* bias, float* y, float* agg, int relu, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_fwd_kernel<NT>),
@@ -816,13 +949,12 @@ static void launch_fwd(int n, const int* rowptr, const int* col, const float* in
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
     sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
-        n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg, relu);
+        n, rowptr, col, ell, invdeg, x, (const f32x4*)wp, bias, y, agg, relu);
 }
 
 template <int NT>
-static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float* invdeg, const float* dxs_in,
-                       const float* dagg_in, const float* y, const void* wpb, float* g_out, float* dagg_out,
-                       float* dxs_out, int relu, hipStream_t st) {
+static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const int* ell_t, const float* invdeg,
+                       const float* g_in, const void* wpb, const float* ymask, float* out, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_bwd_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
@@ -831,7 +963,7 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
     sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
-        n, rowptr_t, col_t, invdeg, dxs_in, dagg_in, y, (const f32x4*)wpb, g_out, dagg_out, dxs_out, relu);
+        n, rowptr_t, col_t, ell_t, invdeg, g_in, (const f32x4*)wpb, ymask, out);
 }
 
 template <int NT>
@@ -997,13 +1129,14 @@ size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers
 int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
                               const float* invdeg, const float* x, int x_stride, const float* const* wl,
                               const float* const* bl, const float* const* wr, void* wpack, float* acts,
-                              void* saved, int need_backward, int flags, hexgnn_stream_t stream_) {
+                              void* saved, int need_backward, int flags, const int* ell, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
+    if (ell && ((uintptr_t)ell & 15)) return HEXGNN_EINVAL;
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts)) return HEXGNN_EINVAL;
     if (need_backward && !saved) return HEXGNN_EINVAL;
     if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
@@ -1026,7 +1159,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
                                                               (const float*)(wp + p.fwd_off[0]), bias, y, agg, relu);
         } else {
             const float* xin = l == 0 ? x : acts + slab * (l - 1);
-            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, relu, st)));
+            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, ell, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, relu, st)));
         }
     }
     return check_launch();
@@ -1045,8 +1178,9 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
                                int x_stride, const float* acts, const void* saved, const void* wpack,
                                const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
                                float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
-                               hexgnn_stream_t stream_) {
+                               const int* ell_t, hexgnn_stream_t stream_) {
     (void)rowptr; (void)col;
+    if (ell_t && ((uintptr_t)ell_t & 15)) return HEXGNN_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
@@ -1064,8 +1198,6 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
     const char* wp = (const char*)wpack;
     const char* sv = (const char*)saved;
     float* G = (float*)(ws + b.g_off);
-    float* pair[2][2] = {{(float*)(ws + b.pair_off[0][0]), (float*)(ws + b.pair_off[0][1])},
-                         {(float*)(ws + b.pair_off[1][0]), (float*)(ws + b.pair_off[1][1])}};
     float* part = (float*)(ws + b.part_off);
     float* part0 = (float*)(ws + b.part0_off);
 
@@ -1079,30 +1211,22 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
         return check_launch();
     }
 
-    // data-gradient chain, top layer first.  pair[k] = (dAggS, dXs) produced by the layer processed last.
+    // data-gradient chain, top layer first: G_{L-1} = dy * [y_{L-1} > 0], then per hidden-input layer l one launch
+    //   G_{l-1} = ( [ sum_{T} G_l / deg | G_l ] [W_l ; W_r] ) * [y_{l-1} > 0]      (l == 0: the stack-input gradient dx, unmasked)
     const int first_hidden = p.small_first ? 1 : 0;
-    int cur = 0;
-    const float* in_dxs = dy;
-    const float* in_dagg = nullptr;
-    for (int l = p.L - 1; l >= first_hidden; --l) {
-        const float* y = acts + slab * l;
-        const int relu = !(l == p.L - 1 && (flags & HEXGNN_SAGE_LINEAR_LAST));
-        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, in_dxs, in_dagg, y, wp + p.bwd_off[l],
-                                                G + slab * l, pair[cur][0], pair[cur][1], relu, st)));
-        in_dagg = pair[cur][0];
-        in_dxs = pair[cur][1];
-        cur ^= 1;
-    }
     const int q4 = p.hp / 4;
     const unsigned cgrid = (unsigned)(((int64_t)n * q4 + 255) / 256);
-    if (p.small_first) {
-        // G_0 = (dXs_1 + gather dAggS_1) * [y_0 > 0]   (or dy * mask when the stack is a single raw layer)
+    {
         KernelTimer kt(HEXGNN_K_COMBINE, st);
-        const bool relu0 = !(p.L == 1 && (flags & HEXGNN_SAGE_LINEAR_LAST));
-        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, relu0 ? acts : nullptr, G);
-    } else if (dx) {
-        KernelTimer kt(HEXGNN_K_COMBINE, st);
-        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, in_dxs, in_dagg, nullptr, dx);
+        const bool relu_top = !(flags & HEXGNN_SAGE_LINEAR_LAST);
+        sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, dy, nullptr, relu_top ? acts + slab * (p.L - 1) : nullptr,
+                                                   G + slab * (p.L - 1));
+    }
+    for (int l = p.L - 1; l >= first_hidden; --l) {
+        float* out = l >= 1 ? G + slab * (l - 1) : dx;
+        if (!out) break;                                   // l == 0 and nobody asked for the input gradient
+        const float* ymask = l >= 1 ? acts + slab * (l - 1) : nullptr;
+        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, ell_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st)));
     }
 
     rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);
@@ -1110,4 +1234,22 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
     return check_launch();
 }
 
+int hexgnn_ell_build(int n, const int* rowptr, const int* col, int* ell, hexgnn_stream_t stream_) {
+    if (n < 0) return HEXGNN_EINVAL;
+    if (n == 0) return HEXGNN_OK;
+    if (!rowptr || !col || !ell || ((uintptr_t)ell & 15)) return HEXGNN_EINVAL;
+    const int64_t tot = (int64_t)n * kEll;
+    ell_build_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream_>>>(n, rowptr, col, ell);
+    return check_launch();
+}
+
+#ifdef HEXGNN_STAMPS
+// profiling builds only: s_memtime stamps of the layer-major kernels' last launches -> `out` (host pointer, 2 x 8 x 8)
+int hexgnn_debug_layer_stamps(unsigned long long* out, int capacity) {
+    if (capacity < 128) return HEXGNN_EINVAL;
+    if (hipDeviceSynchronize() != hipSuccess) return HEXGNN_EHIP;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hexgnn::g_lstamps), sizeof(unsigned long long) * 128) != hipSuccess) return HEXGNN_EHIP;
+    return 128;
+}
+#endif
 }  // extern "C"
