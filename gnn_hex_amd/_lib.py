@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
 _lib = None
-ABI_VERSION = 3          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
+ABI_VERSION = 2          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
 
 vp = C.c_void_p
 ci = C.c_int
@@ -32,11 +32,10 @@ _SIGS = {
     "hexgnn_graph_ptr": (ci, [ci, ci, vp, vp, vp]),
     "hexgnn_sage_stack_pack_bytes": (sz, [ci, ci, ci]),
     "hexgnn_sage_stack_saved_bytes": (sz, [ci, ci, ci, ci]),
-    "hexgnn_sage_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp, vp]),
-    "hexgnn_ell_build": (ci, [ci, vp, vp, vp, vp]),
+    "hexgnn_sage_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp]),
     "hexgnn_sage_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "hexgnn_sage_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
-                                        vp, vp, vp, vp, sz, ci, vp, vp]),
+                                        vp, vp, vp, vp, sz, ci, vp]),
     "hexgnn_head_saved_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),

@@ -290,24 +290,15 @@ __device__ unsigned long long g_lstamps[2][8][8];
 //              the gather moved in front of the contraction: it is linear, and the kernel then has the forward's shape)
 // One 128-row block per 512-thread workgroup, wave w = rows 16w..16w+15, lane (r, g) = row r, 16-byte column slots g, g+4, ...
 // Timeline of a launch (tools/layer_stamps.py; the straight-line version spent 3.7 us staging weights, 9.5 us in the gather's
-// dependent chain rowptr -> column ids -> neighbour rows and 13.5 us in MFMAs, one after the other):
-//   1. both weight parts -> LDS by LDS-DMA (no registers, nothing waits); self rows, CSR row bounds and -- from the batch's
-//      padded neighbour table `ell` [n][16] (hexgnn_ell_build, once per batch) -- the row's first sixteen neighbour ids are
-//      requested alongside: ONE memory round trip, then the barrier;
-//   2. self half (rows x W_r part) on the matrix pipe while the gather runs underneath it: neighbour rows come in three
-//      rounds of four 16-byte-slot sets (raw buffer loads; a missing neighbour is an out-of-range offset = zeros, so every
-//      lane issues the same instructions) and are added in ascending neighbour order between MFMA groups;
+// dependent chain rowptr -> column ids -> neighbour rows and 13.5 us in MFMAs, one after the other: 29 us):
+//   1. both weight parts -> LDS by LDS-DMA (no registers, nothing waits), self rows and CSR row bounds requested alongside:
+//      ONE memory round trip, then the barrier;
+//   2. self half (rows x W_r part) on the matrix pipe while the gather runs underneath it: the column ids of the row's
+//      first sixteen neighbours, then the neighbour rows as single 16-byte-slot loads spread evenly over the gaps between
+//      MFMA groups (raw buffer loads; a missing neighbour is an out-of-range offset = zeros, so every lane issues the same
+//      instructions), added in ascending neighbour order a few gaps later;
 //   3. rows with more than sixteen neighbours finish their sum from the CSR, then the aggregate half, epilogue.
-// Without a table (ell == nullptr) the ids come from the CSR after the barrier: one more dependent round trip.
-constexpr int kEll = HEXGNN_ELL_WIDTH;
-
-__global__ void ell_build_kernel(int n, const int* __restrict__ rowptr, const int* __restrict__ col, int* __restrict__ ell) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n * kEll) return;
-    const int row = i / kEll, k = i % kEll;
-    const int e = rowptr[row] + k;
-    ell[i] = e < rowptr[row + 1] ? col[e] : -1;
-}
+constexpr int kEll = 16;          // neighbour slots handled inside the self half (longer rows finish from the CSR)
 
 // Gather schedule of the self half: the W * NT 16-byte neighbour loads of a lane are issued kP per gap (a gap = the slot
 // behind one (chunk, tile) group of four MFMAs; a burst of loads instead would hold the wave -- and with it its MFMAs -- in
@@ -336,12 +327,13 @@ template <int NT> struct GatherSched {
 
 template <int NT, bool BWD>
 __device__ __forceinline__ void sage_layer_body(
-    int n, const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ ell,
+    int n, const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ invdeg, const float* __restrict__ x, const f32x4* __restrict__ wpack,
     const float* __restrict__ bias, const float* __restrict__ ymask, float* __restrict__ out,
     float* __restrict__ agg_out, int relu, f32x4* wlds) {
     constexpr int HP = 16 * NT;
-    constexpr int K = BWD ? 1 : 0;
+    constexpr int K = BWD ? 1 : 0;     // stamp set (profiling builds)
+    (void)K;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     LSTAMP(K, 0);
     {
@@ -357,8 +349,6 @@ __device__ __forceinline__ void sage_layer_body(
     for (int c = 0; c < NT; ++c) { xs[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     int e0 = 0, e1 = 0;
     int nid[kEll];
-#pragma unroll
-    for (int k = 0; k < kEll; ++k) nid[k] = -1;
     float sc = 0.f;
     if (valid) {
         const f32x4* xr = reinterpret_cast<const f32x4*>(x + (size_t)row * HP) + g;
@@ -366,15 +356,6 @@ __device__ __forceinline__ void sage_layer_body(
         for (int c = 0; c < NT; ++c) xs[c] = xr[4 * c];
         e0 = rowptr[row];
         e1 = rowptr[row + 1];
-        if (ell) {
-            typedef int i32x4 __attribute__((ext_vector_type(4)));
-            const i32x4* er = reinterpret_cast<const i32x4*>(ell + (size_t)row * kEll);
-#pragma unroll
-            for (int q = 0; q < kEll / 4; ++q) {
-                const i32x4 v = er[q];
-                nid[4 * q] = v[0]; nid[4 * q + 1] = v[1]; nid[4 * q + 2] = v[2]; nid[4 * q + 3] = v[3];
-            }
-        }
         if constexpr (!BWD) sc = invdeg[row];
     }
     wait_vmem();
@@ -384,7 +365,9 @@ __device__ __forceinline__ void sage_layer_body(
 
     const __amdgpu_buffer_rsrc_t xr_ = slab_rsrc(x);
     const int deg = e1 - e0;
-    if (!ell) {      // ids from the CSR (zeros past the row's end: the offsets below are then out of range anyway)
+    {   // column ids of the row's first kEll neighbours (zeros past the row's end: their offsets are out of range anyway).
+        // This second dependent fetch runs under the first MFMA groups; a padded per-batch neighbour table that would have
+        // delivered the ids with the first round trip was built and measured: no difference (227.5 vs 228.3 k graphs/s on MIX).
         const __amdgpu_buffer_rsrc_t colr = slab_rsrc(col);
 #pragma unroll
         for (int k = 0; k < kEll; ++k)
@@ -518,21 +501,21 @@ __device__ __forceinline__ void sage_layer_body(
 
 template <int NT>
 __global__ __launch_bounds__(512) void sage_hidden_fwd_kernel(
-    int n, const int* __restrict__ rowptr, const int* __restrict__ col, const int* __restrict__ ell,
+    int n, const int* __restrict__ rowptr, const int* __restrict__ col,
     const float* __restrict__ invdeg, const float* __restrict__ x, const f32x4* __restrict__ wpack,
     const float* __restrict__ bias, float* __restrict__ y, float* __restrict__ agg_out, int relu) {
     extern __shared__ f32x4 wlds[];  // [2NT][NT][64]: W_l part, then W_r part
-    sage_layer_body<NT, false>(n, rowptr, col, ell, invdeg, x, wpack, bias, nullptr, y, agg_out, relu, wlds);
+    sage_layer_body<NT, false>(n, rowptr, col, invdeg, x, wpack, bias, nullptr, y, agg_out, relu, wlds);
 }
 
 // G_l rows in, dY = [sum_T G / deg | G] [W_l ; W_r] masked by y_{l-1} (ymask, null: unmasked) out
 template <int NT>
 __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
-    int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t, const int* __restrict__ ell_t,
+    int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
     const float* __restrict__ invdeg, const float* __restrict__ g_in, const f32x4* __restrict__ wpackb,
     const float* __restrict__ ymask, float* __restrict__ out) {
     extern __shared__ f32x4 wlds[];  // [2][NT][NT][64]: W_l part, W_r part
-    sage_layer_body<NT, true>(n, rowptr_t, col_t, ell_t, invdeg, g_in, wpackb, nullptr, ymask, out, nullptr, 1, wlds);
+    sage_layer_body<NT, true>(n, rowptr_t, col_t, invdeg, g_in, wpackb, nullptr, ymask, out, nullptr, 1, wlds);
 }
 
 // ---- out = dxs + sum_{j in T(i)} dagg_j, optionally masked by y>0 (stack-input gradient / G of a raw first layer) ----
@@ -939,7 +922,7 @@ __global__ __launch_bounds__(64) void sage_first_dw_reduce_kernel(
 
 // ---- host-side dispatch ---------------------------------------------------------------------------------
 template <int NT>
-static void launch_fwd(int n, const int* rowptr, const int* col, const int* ell, const float* invdeg, const float* x,
+static void launch_fwd(int n, const int* rowptr, const int* col, const float* invdeg, const float* x,
                        const void* wp, const float* bias, float* y, float* agg, int relu, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_fwd_kernel<NT>),
@@ -949,11 +932,11 @@ static void launch_fwd(int n, const int* rowptr, const int* col, const int* ell,
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
     sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
-        n, rowptr, col, ell, invdeg, x, (const f32x4*)wp, bias, y, agg, relu);
+        n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg, relu);
 }
 
 template <int NT>
-static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const int* ell_t, const float* invdeg,
+static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float* invdeg,
                        const float* g_in, const void* wpb, const float* ymask, float* out, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_bwd_kernel<NT>),
@@ -963,7 +946,7 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const int* 
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
     sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
-        n, rowptr_t, col_t, ell_t, invdeg, g_in, (const f32x4*)wpb, ymask, out);
+        n, rowptr_t, col_t, invdeg, g_in, (const f32x4*)wpb, ymask, out);
 }
 
 template <int NT>
@@ -1129,14 +1112,13 @@ size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers
 int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
                               const float* invdeg, const float* x, int x_stride, const float* const* wl,
                               const float* const* bl, const float* const* wr, void* wpack, float* acts,
-                              void* saved, int need_backward, int flags, const int* ell, hexgnn_stream_t stream_) {
+                              void* saved, int need_backward, int flags, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
-    if (ell && ((uintptr_t)ell & 15)) return HEXGNN_EINVAL;
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts)) return HEXGNN_EINVAL;
     if (need_backward && !saved) return HEXGNN_EINVAL;
     if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
@@ -1159,7 +1141,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
                                                               (const float*)(wp + p.fwd_off[0]), bias, y, agg, relu);
         } else {
             const float* xin = l == 0 ? x : acts + slab * (l - 1);
-            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, ell, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, relu, st)));
+            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, relu, st)));
         }
     }
     return check_launch();
@@ -1178,9 +1160,8 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
                                int x_stride, const float* acts, const void* saved, const void* wpack,
                                const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
                                float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
-                               const int* ell_t, hexgnn_stream_t stream_) {
+                               hexgnn_stream_t stream_) {
     (void)rowptr; (void)col;
-    if (ell_t && ((uintptr_t)ell_t & 15)) return HEXGNN_EINVAL;
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
@@ -1226,20 +1207,11 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
         float* out = l >= 1 ? G + slab * (l - 1) : dx;
         if (!out) break;                                   // l == 0 and nobody asked for the input gradient
         const float* ymask = l >= 1 ? acts + slab * (l - 1) : nullptr;
-        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, ell_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st)));
+        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st)));
     }
 
     rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);
     if (rc != HEXGNN_OK) return rc;
-    return check_launch();
-}
-
-int hexgnn_ell_build(int n, const int* rowptr, const int* col, int* ell, hexgnn_stream_t stream_) {
-    if (n < 0) return HEXGNN_EINVAL;
-    if (n == 0) return HEXGNN_OK;
-    if (!rowptr || !col || !ell || ((uintptr_t)ell & 15)) return HEXGNN_EINVAL;
-    const int64_t tot = (int64_t)n * kEll;
-    ell_build_kernel<<<(unsigned)((tot + 255) / 256), 256, 0, (hipStream_t)stream_>>>(n, rowptr, col, ell);
     return check_launch();
 }
 

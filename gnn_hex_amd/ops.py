@@ -9,7 +9,6 @@ from __future__ import annotations
 import ctypes as C
 from typing import List, Optional, Sequence
 
-import os
 import torch
 
 from . import _lib
@@ -90,7 +89,7 @@ class GraphStructure:
     Replaces the per-layer x[edge_index[0]] / scatter(edge_index[1]) indexing of the reference
     (GN0/models.py:276)."""
 
-    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status", "_ell")
+    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status")
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, gptr: Optional[torch.Tensor] = None, b: int = 0,
                  ptr64: Optional[torch.Tensor] = None):
@@ -151,30 +150,6 @@ class GraphStructure:
         self.col_t = col if col_t is None else col_t
         self.status = sticky_status(rowptr.device)
         return self
-
-    def ell_tables(self):
-        """Padded neighbour tables (ell, ell_t) int32 [n, 16] of the CSR and of its transpose for the layer-major kernels
-        (``hexgnn_ell_build``): built on first use, once per batch -- the graph is the same for every layer, forward and
-        backward.  A symmetric batch (rowptr_t is rowptr) shares one table."""
-        t = getattr(self, "_ell", None)
-        if os.environ.get("HEXGNN_NO_ELL"):
-            class _N:
-                def data_ptr(self): return None
-            return (_N(), _N())
-        if t is None:
-            L = _lib.lib()
-            dev = self.rowptr.device
-            ell = torch.empty((max(self.n, 1), 16), dtype=torch.int32, device=dev)
-            _lib.check(L.hexgnn_ell_build(self.n, self.rowptr.data_ptr(), self.col.data_ptr(), ell.data_ptr(), _stream()),
-                       "hexgnn_ell_build")
-            if self.rowptr_t is self.rowptr and self.col_t is self.col:
-                ell_t = ell
-            else:
-                ell_t = torch.empty((max(self.n, 1), 16), dtype=torch.int32, device=dev)
-                _lib.check(L.hexgnn_ell_build(self.n, self.rowptr_t.data_ptr(), self.col_t.data_ptr(), ell_t.data_ptr(),
-                                              _stream()), "hexgnn_ell_build")
-            t = self._ell = (ell, ell_t)
-        return t
 
     def check(self) -> None:
         """Host-synchronising validity check (debug aid; not called on the hot path).  Batches built by the one-launch
@@ -271,8 +246,7 @@ class SageStackFn(torch.autograd.Function):
         _lib.check(L.hexgnn_sage_stack_forward(
             n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
             xin.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), wpack.data_ptr(),
-            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), int(flags),
-            gs.ell_tables()[0].data_ptr() if (n > 0 and (num_layers > 1 or not small)) else None, _stream()),
+            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), int(flags), _stream()),
             "hexgnn_sage_stack_forward")
         if need_bwd:
             ctx.gs = gs
@@ -300,8 +274,7 @@ class SageStackFn(torch.autograd.Function):
             gs.col_t.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(), x_stride, acts.data_ptr(),
             saved.data_ptr(), wpack.data_ptr(), dy.data_ptr(), dx.data_ptr() if dx is not None else None,
             _ptr_array(grads[0::3]), _ptr_array(grads[1::3]), _ptr_array(grads[2::3]), ws.data_ptr(), ws_bytes,
-            ctx.flags, gs.ell_tables()[1].data_ptr() if (n > 0 and (num_layers > 1 or c_in == hidden)) else None, _stream()),
-            "hexgnn_sage_stack_backward")
+            ctx.flags, _stream()), "hexgnn_sage_stack_backward")
         gx = _logical(dx, hidden) if dx is not None else None
         return (gx, None, None, None, None, None) + tuple(grads)
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HEXGNN_ABI_VERSION 3
+#define HEXGNN_ABI_VERSION 2
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
@@ -91,16 +91,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers,
                               const float* x, int x_stride,
                               const float* const* wl, const float* const* bl, const float* const* wr,
                               void* wpack, float* acts, void* saved, int need_backward, int flags,
-                              const int* ell /* hexgnn_ell_build(rowptr, col) of the batch, or NULL */,
                               hexgnn_stream_t stream);
-
-/* Padded neighbour table of a batch: ell[i][k] = k-th neighbour of node i (ascending, as in the sorted CSR) for
- * k < HEXGNN_ELL_WIDTH, -1 past the row's end; 16-byte aligned int32 [n][HEXGNN_ELL_WIDTH].  The graph is the same for all
- * 17 layers of a step and for forward and backward, so the table is built once per batch (and per direction: pass
- * rowptr_t / col_t for the backward call's table) and spares every layer launch the dependent fetch rowptr -> column ids
- * in front of its neighbour-row loads.  Optional everywhere it is accepted: NULL = ids from the CSR (one more round trip). */
-#define HEXGNN_ELL_WIDTH 16
-int hexgnn_ell_build(int n, const int* rowptr, const int* col, int* ell, hexgnn_stream_t stream);
 
 size_t hexgnn_sage_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers);
 /* dy: gradient w.r.t. the stack output, padded layout [n][HP].
@@ -115,7 +106,6 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers,
                                const float* dy, float* dx,
                                float* const* d_wl, float* const* d_bl, float* const* d_wr,
                                void* workspace, size_t workspace_bytes, int flags /* as in the forward call */,
-                               const int* ell_t /* hexgnn_ell_build(rowptr_t, col_t), or NULL */,
                                hexgnn_stream_t stream);
 
 /* ---- head tail: HeadNetwork.forward after its gnn (GN0/models.py:374-384), MLP value head
