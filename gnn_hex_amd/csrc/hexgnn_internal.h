@@ -21,7 +21,7 @@ struct StackPlan {
 int make_plan(int n, int c_in, int hidden, int L, StackPlan* p);
 
 struct BwdPlan {
-    size_t g_off, pair_off[2][2], part_off, part0_off, total;
+    size_t g_off, part_off, part0_off, total;
     int S, rps;
     int S0, rps0;   // raw first layer: many small slices (VALU kernel, one pass over G)
 };

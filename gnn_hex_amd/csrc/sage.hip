@@ -1010,7 +1010,6 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     const size_t slab = align_up(sizeof(float) * (size_t)n * p.hp, 256);
     size_t off = 0;
     b->g_off = off; off += slab * p.L;
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 2; ++j) { b->pair_off[i][j] = off; off += slab; }
     b->S = dw_slices_fp32(n, p.L - (p.small_first ? 1 : 0));
     b->rps = dw_rows_per_slice(n, b->S);
     b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * kDwMaxSlices * p.hp * (2 * p.hp + 1), 256);
