@@ -176,6 +176,7 @@ class DeviceRollout:
         self.alive = torch.zeros((T + 1, k, nv), dtype=torch.uint8, device=dev)
         self._mt = torch.zeros(k, dtype=torch.int32, device=dev)
         self._tm = torch.zeros(k, dtype=torch.int32, device=dev)
+        self._iota = torch.arange(N + 1, dtype=torch.int32, device=dev) if nv > 128 else None
         self._run_no = 0           # bumped by every run(): results of earlier runs view overwritten snapshots
         self._graph = None
         if graph:
@@ -213,6 +214,11 @@ class DeviceRollout:
                                             self.edge_global.data_ptr(), self.gs.rowptr.data_ptr(), self.gs.col.data_ptr(),
                                             self.gs.invdeg.data_ptr(), self.batch_vec.data_ptr(), ops._stream()),
                        "hexgnn_env_observe")
+            if self._iota is not None:
+                # Boards above 128 nodes run on the layer-major kernels, which walk ALL rows of the capacity-sized buffers:
+                # rows past the current total must be empty, not whatever an earlier, larger observation left there (the
+                # row right behind the end marker otherwise shows a bogus degree of thousands: 146 us per layer launch).
+                torch.where(self._iota > self.node_off[k], self.edge_off[k], self.gs.rowptr, out=self.gs.rowptr)
             x = self.x.view(self.x.shape)       # fresh tensor object per step: the hints below differ per side
             x._hex_is_maker = maker
             x._hex_max_nodes = mgr._nv

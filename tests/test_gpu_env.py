@@ -217,7 +217,8 @@ def test_select_actions_greedy_and_exploratory():
 
 
 @pytest.mark.parametrize("graph", [False, True])
-def test_device_rollout_equals_step_by_step_loop(graph):
+@pytest.mark.parametrize("size", [5, 12], ids=["hex5", "hex12-layer-major"])
+def test_device_rollout_equals_step_by_step_loop(graph, size):
     """DeviceRollout (observation -> Q forward -> greedy action -> step, sizes kept on the device, optionally one HIP
     graph) must play exactly the games the public step-by-step API plays, and leave the envs in the same state."""
     import torch
@@ -225,7 +226,9 @@ def test_device_rollout_equals_step_by_step_loop(graph):
     from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
     from helpers import make_pair
     hip, _ = make_pair(3, 35, seed=4)
-    k, size, T = 8, 5, 12
+    # (Hex-12 boards have 146 nodes: the model runs on the layer-major kernels over the rollout's capacity-sized buffers,
+    # whose rows past the shrinking total must read as empty)
+    k, T = 8, 12
     a, b = Env_manager(k, size, gamma=0.9), Env_manager(k, size, gamma=0.9)
     a.reset(); b.reset()
     ro = DeviceRollout(a, hip, steps=T, eps=0.0, graph=graph)
@@ -245,7 +248,8 @@ def test_device_rollout_equals_step_by_step_loop(graph):
             assert rew.tolist() == res.rewards[t].tolist() and dones.tolist() == res.dones[t].tolist()
             for i in range(k):
                 assert ("episode_metrics" in infos[i]) == ("episode_metrics" in res.infos[t][i])
-        assert res.dones.any(), "the rollout should finish at least one Hex-5 game"
+        if size == 5:
+            assert res.dones.any(), "the rollout should finish at least one Hex-5 game"
         sa, sb = a._state(), b._state()
         for key in ("adj", "alive", "maker_turn", "total_moves"):
             assert (sa[key] == sb[key]).all(), key
