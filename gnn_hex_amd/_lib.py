@@ -36,6 +36,11 @@ _SIGS = {
     "hexgnn_sage_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "hexgnn_sage_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, sz, ci, vp]),
+    "hexgnn_sage_norm_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp,
+                                            vp, vp, sz, ci, vp]),
+    "hexgnn_sage_norm_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
+    "hexgnn_sage_norm_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp,
+                                             vp, vp, vp, vp, vp, sz, vp, sz, vp]),
     "hexgnn_head_saved_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_head_backward_workspace_bytes": (sz, [ci, ci, ci]),

@@ -7,6 +7,11 @@ namespace hexgnn {
 
 constexpr int kMaxLayers = 64;
 constexpr int kDwMaxSlices = 64;   // row slices per layer of the weight-gradient GEMM (workspace is sized for this many)
+// slabs a plan with `layers` layers must hold: kDwMaxSlices per layer, and one- / two-layer launches use up to twice that
+inline size_t dw_slab_count(int layers) {
+    const size_t a = (size_t)layers * kDwMaxSlices, b = 4 * (size_t)kDwMaxSlices;
+    return a > b ? a : b;
+}
 
 struct StackPlan {
     int hp, nt, L, c_in;
@@ -26,7 +31,9 @@ struct BwdPlan {
     int S0, rps0;   // raw first layer: many small slices (VALU kernel, one pass over G)
 };
 void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b);
-int dw_slices_for(int n, int hidden_layers, int math);   // slices the weight-gradient launch actually uses (<= BwdPlan::S)
+int dw_slices_for(int n, int hidden_layers, int math, int stack_hidden_layers);   // slices the weight-gradient launch actually uses
+// (<= BwdPlan::S; hidden_layers = layers of this launch, stack_hidden_layers = of the whole stack: only a stack of <= 2 gets the
+// doubled slice count, so that a stage of a longer stack stays inside its kDwMaxSlices-per-layer slab region)
 
 // pack all layers of a stack (forward + backward fragment order, padded bias) -- one launch
 int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,

@@ -164,7 +164,7 @@ int make_qplan(int n, int b, int c_in, int hidden, int L, QPlan* q) {
     const size_t slab = align_up(sizeof(float) * (size_t)n * q->sp.hp, 256);
     size_t off = 0;
     q->ws_g_off = off; off += slab * L;
-    q->ws_part_off = off; off += align_up(sizeof(float) * (size_t)L * kDwMaxSlices * q->sp.hp * (2 * q->sp.hp + 1), 256);
+    q->ws_part_off = off; off += align_up(sizeof(float) * dw_slab_count(L) * q->sp.hp * (2 * q->sp.hp + 1), 256);
     q->ws_part0_off = off; off += align_up(sizeof(float) * (size_t)q->bp.S0 * q->sp.hp * 17, 256);
     q->ws_head_off = off; off += q->hw.total;
     q->ws_first_off = align_up(off, 256); off = q->ws_first_off + sizeof(float) * (size_t)(b > 0 ? b : 1) * 17 * q->sp.hp;
@@ -322,7 +322,7 @@ int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_la
         }
         GradReduceArgs r;
         for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[lo + i]; r.dbl[i] = d_bl[lo + i]; r.dwr[i] = d_wr[lo + i]; }
-        r.part = spart; r.S = dw_slices_for(n, nh, math); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
+        r.part = spart; r.S = dw_slices_for(n, nh, math, qp.sp.L - (qp.sp.small_first ? 1 : 0)); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
         r.blk_per_layer = (qp.sp.hp * (2 * qp.sp.hp + 1) / 4 + 255) / 256;      // one thread per float4 of a slab
         r.first_part = a.first_part; r.b = b; r.c_in = c_in; r.dwl0 = d_wl[0]; r.dbl0 = d_bl[0]; r.dwr0 = d_wr[0];
         r.lin_part = a.lin_part; r.d_lin_w = d_lin_w; r.d_lin_b = d_lin_b;

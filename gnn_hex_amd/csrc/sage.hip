@@ -852,7 +852,15 @@ __global__ void sage_dw_reduce_kernel(DwReduceArgs a, const float* __restrict__ 
     else off = (size_t)hp * 2 * hp + o;
     const float* p = part + (size_t)li * a.S * slab_sz + off;
     float sum = 0.f;
-    for (int s = 0; s < a.S; ++s) sum += p[(size_t)s * slab_sz];
+    int s = 0;
+    for (; s + 8 <= a.S; s += 8) {         // eight slabs' values requested together, added in slice order
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = p[(size_t)(s + j) * slab_sz];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sum += v[j];
+    }
+    for (; s < a.S; ++s) sum += p[(size_t)s * slab_sz];
     if (c < H) a.dwl[li][o * H + c] = sum;
     else if (c < 2 * H) a.dwr[li][o * H + (c - H)] = sum;
     else a.dbl[li][o] = sum;
@@ -980,7 +988,7 @@ static void launch_dw16(const Dw16Args& a, int layers, float* part, hipStream_t 
 // kernel time (a 256-graph batch of mid-game boards, N = 19 938: 20 x 16 = 320 workgroups took as long as the 496 of the
 // start-position batch; 32 x 16 = 512 do not).  Slices stay >= 256 rows.  Split f16 (HBM-bound): (slices x hidden layers)
 // fills the 256 CUs in ONE round and halves the slab traffic of the reduce.  The plan sizes its workspace for the larger.
-static int dw_slices_fp32(int n, int hidden_layers) {
+static int dw_slices_fp32(int n, int hidden_layers, bool wide) {
     const int nh = hidden_layers > 0 ? hidden_layers : 1;
     int base = (n + 1023) / 1024;
     if (base < 1) base = 1;
@@ -989,11 +997,14 @@ static int dw_slices_fp32(int n, int hidden_layers) {
     int s = rounds * kSlots / nh;
     if (s > n / 256) s = n / 256;
     if (s < base) s = base;
-    if (s > kDwMaxSlices) s = kDwMaxSlices;
+    // one- and two-layer stacks (the per-layer calls of --norm=True, the head stack) get twice the slices: 64 workgroups of a
+    // single-layer launch left 7/8 of the 512 slots empty (60 us per layer against 15 us per layer in the batched launch)
+    const int cap = (wide && nh <= 2) ? 2 * kDwMaxSlices : kDwMaxSlices;     // (wide: the whole stack has <= 2 hidden layers)
+    if (s > cap) s = cap;
     return s;
 }
-int dw_slices_for(int n, int hidden_layers, int math) {
-    const int s0 = dw_slices_fp32(n, hidden_layers);
+int dw_slices_for(int n, int hidden_layers, int math, int stack_hidden_layers) {
+    const int s0 = dw_slices_fp32(n, hidden_layers, stack_hidden_layers <= 2);
     if (math != 1) return s0;
     int s = 256 / (hidden_layers > 0 ? hidden_layers : 1);
     if (s > n / 256) s = n / 256;
@@ -1010,9 +1021,9 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     const size_t slab = align_up(sizeof(float) * (size_t)n * p.hp, 256);
     size_t off = 0;
     b->g_off = off; off += slab * p.L;
-    b->S = dw_slices_fp32(n, p.L - (p.small_first ? 1 : 0));
+    b->S = dw_slices_fp32(n, p.L - (p.small_first ? 1 : 0), p.L - (p.small_first ? 1 : 0) <= 2);
     b->rps = dw_rows_per_slice(n, b->S);
-    b->part_off = off; off += align_up(sizeof(float) * (size_t)p.L * kDwMaxSlices * p.hp * (2 * p.hp + 1), 256);
+    b->part_off = off; off += align_up(sizeof(float) * dw_slab_count(p.L) * p.hp * (2 * p.hp + 1), 256);
     b->rps0 = 128;
     b->S0 = (n + b->rps0 - 1) / b->rps0; if (b->S0 < 1) b->S0 = 1;
     b->part0_off = off; off += align_up(sizeof(float) * (size_t)b->S0 * p.hp * 17, 256);
@@ -1065,7 +1076,7 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
             da.g[i] = G + slab * l;
             ra.dwl[i] = d_wl[l]; ra.dbl[i] = d_bl[l]; ra.dwr[i] = d_wr[l];
         }
-        const int S = dw_slices_for(n, nh, (math == 1 && xmax && gmax) ? 1 : 0);
+        const int S = dw_slices_for(n, nh, (math == 1 && xmax && gmax) ? 1 : 0, p.L - (p.small_first ? 1 : 0));
         const int rps = dw_rows_per_slice(n, S);
         da.n = n; da.rows_per_slice = rps; da.S = S;
         ra.S = S; ra.hp = p.hp; ra.hidden = hidden;
@@ -1209,6 +1220,117 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
         HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st)));
     }
 
+    rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);
+    if (rc != HEXGNN_OK) return rc;
+    return check_launch();
+}
+
+/* ---- SAGE stack with the whole-batch LayerNorm of --norm=True between every contraction and its ReLU ------------------------
+ * (CachifiedGNN.forward with norms, GN0/models.py:261-294: conv -> norm -> relu per layer).  One call per direction instead of
+ * a SAGE call + a norm call per layer: the weights are packed once, and the weight gradients of all layers are ONE batched
+ * GEMM + one reduce (per-layer launches of 64-128 workgroups ran at a quarter of the batched rate). */
+size_t hexgnn_sage_norm_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers) {
+    StackPlan p;
+    if (n < 0 || make_plan(n, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
+    BwdPlan b;
+    make_bwd_plan(n, p, &b);
+    return b.total + align_up(sizeof(float) * (size_t)n * p.hp, 256);
+}
+
+int hexgnn_sage_norm_stack_forward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                   const float* invdeg, const float* x, int x_stride, const float* const* wl,
+                                   const float* const* bl, const float* const* wr, const float* const* nw,
+                                   const float* const* nb, float eps, void* wpack, float* pre, float* acts, void* saved,
+                                   float* stats, void* norm_ws, size_t norm_ws_bytes, int need_backward,
+                                   hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    StackPlan p;
+    if (n < 0) return HEXGNN_EINVAL;
+    int rc = make_plan(n, c_in, hidden, num_layers, &p);
+    if (rc != HEXGNN_OK) return rc;
+    if (!wl || !bl || !wr || !nw || !nb || !wpack || !stats || !norm_ws) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts || !pre)) return HEXGNN_EINVAL;
+    if (need_backward && !saved) return HEXGNN_EINVAL;
+    if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
+    for (int l = 0; l < p.L; ++l) if (!nw[l] || !nb[l]) return HEXGNN_EINVAL;
+    rc = launch_pack(p, c_in, hidden, wl, bl, wr, wpack, st, 0);
+    if (rc != HEXGNN_OK) return rc;
+    if (n == 0) return check_launch();
+    const size_t slab = (size_t)n * p.hp;
+    char* wp = (char*)wpack;
+    char* sv = (char*)saved;
+    for (int l = 0; l < p.L; ++l) {
+        float* y = pre + slab * l;
+        const float* bias = (const float*)(wp + p.bias_off[l]);
+        float* agg = need_backward ? (float*)(sv + p.agg_off[l]) : nullptr;
+        if (l == 0 && p.small_first) {
+            KernelTimer kt(HEXGNN_K_SAGE_FIRST, st);
+            sage_first_fwd_kernel<<<(n + 31) / 32, 256, 0, st>>>(n, c_in, p.hp, rowptr, col, invdeg, x, x_stride,
+                                                              (const float*)(wp + p.fwd_off[0]), bias, y, agg, 0);
+        } else {
+            const float* xin = l == 0 ? x : acts + slab * (l - 1);
+            HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, 0, st)));
+        }
+        rc = hexgnn_graph_layernorm_forward(n, hidden, y, nw[l], nb[l], eps, 1, acts + slab * l, stats + 2 * l, norm_ws,
+                                            norm_ws_bytes, stream_);
+        if (rc != HEXGNN_OK) return rc;
+    }
+    return check_launch();
+}
+
+int hexgnn_sage_norm_stack_backward(int n, int c_in, int hidden, int num_layers, const int* rowptr_t, const int* col_t,
+                                    const float* invdeg, const float* x, int x_stride, const float* pre,
+                                    const float* acts, const void* saved, const void* wpack, const float* stats,
+                                    const float* const* nw, float eps, const float* dy, float* dx, float* const* d_wl,
+                                    float* const* d_bl, float* const* d_wr, float* const* d_nw, float* const* d_nb,
+                                    void* workspace, size_t workspace_bytes, void* norm_ws, size_t norm_ws_bytes,
+                                    hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    StackPlan p;
+    if (n < 0) return HEXGNN_EINVAL;
+    int rc = make_plan(n, c_in, hidden, num_layers, &p);
+    if (rc != HEXGNN_OK) return rc;
+    BwdPlan b;
+    make_bwd_plan(n, p, &b);
+    const size_t tmp_off = b.total;
+    if (!workspace || workspace_bytes < b.total + align_up(sizeof(float) * (size_t)n * p.hp, 256)) return HEXGNN_EWORKSPACE;
+    if (!d_wl || !d_bl || !d_wr || !d_nw || !d_nb || !nw || !wpack || !saved || !stats || !norm_ws) return HEXGNN_EINVAL;
+    for (int l = 0; l < p.L; ++l)
+        if (!d_wl[l] || !d_bl[l] || !d_wr[l] || !d_nw[l] || !d_nb[l] || !nw[l]) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr_t || !col_t || !invdeg || !x || !acts || !pre || !dy)) return HEXGNN_EINVAL;
+    const size_t slab = (size_t)n * p.hp;
+    char* ws = (char*)workspace;
+    const char* wp = (const char*)wpack;
+    const char* sv = (const char*)saved;
+    float* G = (float*)(ws + b.g_off);
+    float* part = (float*)(ws + b.part_off);
+    float* part0 = (float*)(ws + b.part0_off);
+    float* tmp = (float*)(ws + tmp_off);
+    if (n == 0) {
+        for (int l = 0; l < p.L; ++l) {
+            const int in = (l == 0) ? c_in : hidden;
+            (void)hipMemsetAsync(d_wl[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_wr[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_bl[l], 0, sizeof(float) * (size_t)hidden, st);
+            (void)hipMemsetAsync(d_nw[l], 0, sizeof(float) * (size_t)hidden, st);
+            (void)hipMemsetAsync(d_nb[l], 0, sizeof(float) * (size_t)hidden, st);
+        }
+        return check_launch();
+    }
+    // top layer first: norm backward (mask by the layer's output, d gamma / d beta) gives G_l = gradient at the contraction's
+    // output; the layer kernel turns it into the gradient at the layer's input = the next norm's dy (one scratch slab)
+    const int first_hidden = p.small_first ? 1 : 0;
+    const float* dcur = dy;
+    for (int l = p.L - 1; l >= 0; --l) {
+        rc = hexgnn_graph_layernorm_backward(n, hidden, pre + slab * l, acts + slab * l, nw[l], stats + 2 * l, dcur, eps, 1,
+                                             G + slab * l, d_nw[l], d_nb[l], norm_ws, norm_ws_bytes, stream_);
+        if (rc != HEXGNN_OK) return rc;
+        if (l < first_hidden) break;
+        float* out = l >= 1 ? tmp : dx;
+        if (!out) break;
+        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], nullptr, out, st)));
+        dcur = tmp;
+    }
     rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);
     if (rc != HEXGNN_OK) return rc;
     return check_launch();

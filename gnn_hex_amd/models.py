@@ -312,12 +312,10 @@ def cachify_gnn(gnn):
             gs = _graph if _graph is not None else ops.GraphStructure(edge_index, x.shape[0])
             if self.norms is None:
                 return ops.sage_stack(x, gs, self.in_channels, self.hidden_channels, self.convs)
-            # --norm=True: the whole-batch statistics sit between a layer's contraction and its activation, so the stack
-            # runs layer by layer: SAGE layer without ReLU, then LayerNorm with the ReLU fused
-            for conv, norm in zip(self.convs, self.norms):
-                x = conv(x, edge_index, _graph=gs)
-                x = norm(x, _relu=True)
-            return x
+            # --norm=True: the whole-batch statistics sit between a layer's contraction and its activation: SAGE layer
+            # without ReLU, then LayerNorm with the ReLU fused, layer by layer inside one call per direction
+            # (convs[i](x, edge_index) and norms[i](x) on their own remain available as modules)
+            return ops.sage_norm_stack(x, gs, self.in_channels, self.hidden_channels, self.convs, self.norms)
 
     return CachifiedGNN
 

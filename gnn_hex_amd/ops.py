@@ -294,6 +294,87 @@ def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, conv
     return out
 
 
+class SageNormStackFn(torch.autograd.Function):
+    """x = relu(norm_l(SAGE_l(x))) for every layer: CachifiedGNN.forward with the LayerNorm of --norm=True (GN0/models.py:
+    261-294, 935, 945) as one call per direction (``hexgnn_sage_norm_stack_*``).  params: per layer lin_l.weight, lin_l.bias,
+    lin_r.weight, norm.weight, norm.bias."""
+
+    @staticmethod
+    def forward(ctx, x, gs: GraphStructure, c_in: int, hidden: int, num_layers: int, eps: float, *params):
+        L = _lib.lib()
+        dev = x.device
+        n = int(x.shape[0])
+        hp = padded_width(hidden)
+        small = c_in != hidden
+        if small:
+            if x.dtype != torch.float32 or x.stride(1) != 1:
+                x = x.float().contiguous()
+            xin, x_stride = x, (x.stride(0) if n > 0 else c_in)
+        else:
+            xin = as_padded(x, hidden, trust_pads=False)
+            x_stride = hp
+        params = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous() for p in params]
+        wl, bl, wr, nw, nb = params[0::5], params[1::5], params[2::5], params[3::5], params[4::5]
+        need_bwd = any(ctx.needs_input_grad)
+        # [pre | acts]: contraction outputs and norm + ReLU outputs of every layer
+        both = torch.empty((2, num_layers, n, hp), dtype=torch.float32, device=dev)
+        pre, acts = both[0], both[1]
+        wpack = _bytes(L.hexgnn_sage_stack_pack_bytes(c_in, hidden, num_layers), dev)
+        saved = _bytes(L.hexgnn_sage_stack_saved_bytes(n, c_in, hidden, num_layers), dev) if need_bwd else None
+        stats = torch.empty((num_layers, 2), dtype=torch.float32, device=dev)
+        nws_bytes = L.hexgnn_graph_layernorm_workspace_bytes(hidden)
+        nws = _bytes(nws_bytes, dev)
+        _lib.check(L.hexgnn_sage_norm_stack_forward(
+            n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(),
+            x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), _ptr_array(nw), _ptr_array(nb), float(eps),
+            wpack.data_ptr(), pre.data_ptr(), acts.data_ptr(), saved.data_ptr() if saved is not None else None,
+            stats.data_ptr(), nws.data_ptr(), nws_bytes, int(need_bwd), _stream()), "hexgnn_sage_norm_stack_forward")
+        if need_bwd:
+            ctx.gs = gs
+            ctx.dims = (n, c_in, hidden, num_layers, hp, x_stride, float(eps))
+            ctx.bufs = (xin, pre, acts, saved, wpack, stats, nw)
+            ctx.param_shapes = [p.shape for p in params]
+        return acts[num_layers - 1][:, :hidden]
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        L = _lib.lib()
+        n, c_in, hidden, num_layers, hp, x_stride, eps = ctx.dims
+        xin, pre, acts, saved, wpack, stats, nw = ctx.bufs
+        gs = ctx.gs
+        dev = acts.device
+        dy = as_padded(grad_out, hidden, trust_pads=True)
+        want_dx = ctx.needs_input_grad[0] and c_in == hidden
+        dx = torch.empty((n, hp), dtype=torch.float32, device=dev) if want_dx else None
+        grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
+        ws_bytes = L.hexgnn_sage_norm_stack_backward_workspace_bytes(n, c_in, hidden, num_layers)
+        ws = _bytes(ws_bytes, dev)
+        nws_bytes = L.hexgnn_graph_layernorm_workspace_bytes(hidden)
+        nws = _bytes(nws_bytes, dev)
+        _lib.check(L.hexgnn_sage_norm_stack_backward(
+            n, c_in, hidden, num_layers, gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(),
+            x_stride, pre.data_ptr(), acts.data_ptr(), saved.data_ptr(), wpack.data_ptr(), stats.data_ptr(), _ptr_array(nw),
+            eps, dy.data_ptr(), dx.data_ptr() if dx is not None else None, _ptr_array(grads[0::5]), _ptr_array(grads[1::5]),
+            _ptr_array(grads[2::5]), _ptr_array(grads[3::5]), _ptr_array(grads[4::5]), ws.data_ptr(), ws_bytes,
+            nws.data_ptr(), nws_bytes, _stream()), "hexgnn_sage_norm_stack_backward")
+        gx = _logical(dx, hidden) if dx is not None else None
+        return (gx, None, None, None, None, None) + tuple(grads)
+
+
+def sage_norm_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, convs, norms) -> torch.Tensor:
+    """conv -> LayerNorm (whole batch) -> ReLU for every layer of a stack (``--norm=True``)."""
+    _require_cuda(x, "x")
+    eps = float(norms[0].eps)
+    params: List[torch.Tensor] = []
+    for conv, norm in zip(convs, norms):
+        if float(norm.eps) != eps:
+            raise ValueError("the norms of one stack must share eps")
+        params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight, norm.weight, norm.bias]
+    out = SageNormStackFn.apply(x, gs, c_in, hidden, len(convs), eps, *params)
+    out._hexgnn_hp = padded_width(hidden)
+    return out
+
+
 class GraphLayerNormFn(torch.autograd.Function):
     """torch_geometric LayerNorm(mode="graph") without a batch vector: normalise over ALL nodes and channels of the batch,
     affine, optional fused ReLU (GN0/models.py:286-289 norm -> act).  C ABI ``hexgnn_graph_layernorm_*``."""

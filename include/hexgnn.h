@@ -151,6 +151,27 @@ int hexgnn_graph_layernorm_backward(int n, int hidden, const float* x, const flo
                                     float* d_weight, float* d_bias, void* workspace, size_t workspace_bytes,
                                     hexgnn_stream_t stream);
 
+/* ---- SAGE stack with that LayerNorm between every layer's contraction and its ReLU (CachifiedGNN.forward with norms,
+ *      GN0/models.py:261-294: x = relu(norm_l(conv_l(x)))): the per-layer sequence above in one call per direction -- weights
+ *      packed once, ALL layers' weight gradients in one batched GEMM.  nw / nb / d_nw / d_nb: HOST arrays of device pointers
+ *      to the norms' weight / bias [hidden] (and their gradients).  pre: [L][n][HP] contraction outputs, acts: [L][n][HP]
+ *      norm + ReLU outputs (the last slab is the result), stats: [L][2]; all three plus saved / wpack go from the forward to
+ *      the backward call.  norm_ws: hexgnn_graph_layernorm_workspace_bytes(hidden). */
+int hexgnn_sage_norm_stack_forward(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                   const float* invdeg, const float* x, int x_stride, const float* const* wl,
+                                   const float* const* bl, const float* const* wr, const float* const* nw,
+                                   const float* const* nb, float eps, void* wpack, float* pre, float* acts, void* saved,
+                                   float* stats, void* norm_ws, size_t norm_ws_bytes, int need_backward,
+                                   hexgnn_stream_t stream);
+size_t hexgnn_sage_norm_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers);
+int hexgnn_sage_norm_stack_backward(int n, int c_in, int hidden, int num_layers, const int* rowptr_t, const int* col_t,
+                                    const float* invdeg, const float* x, int x_stride, const float* pre,
+                                    const float* acts, const void* saved, const void* wpack, const float* stats,
+                                    const float* const* nw, float eps, const float* dy, float* dx, float* const* d_wl,
+                                    float* const* d_bl, float* const* d_wr, float* const* d_nw, float* const* d_nb,
+                                    void* workspace, size_t workspace_bytes, void* norm_ws, size_t norm_ws_bytes,
+                                    hexgnn_stream_t stream);
+
 /* ---- fused per-graph path: the WHOLE network (raw first layer, all body + head SAGE layers, head tail) in one
  *      launch per direction, one workgroup per graph with the node features resident in LDS.  Usable when
  *      hexgnn_qnet_supported(): hidden <= 112, c_in <= 8, every graph <= 128 nodes (status |= 2 and the graph is
