@@ -307,7 +307,7 @@ constexpr int kEll = 16;          // neighbour slots handled inside the self hal
 template <int NT> struct GatherSched {
     static constexpr int W = kEll;
     static constexpr int G = NT * NT;
-    static constexpr int kWin = NT >= 4 ? 4 : 8;
+    static constexpr int kWin = NT >= 8 ? 3 : (NT >= 4 ? 4 : 8);     // landing buffers (three at hidden 113-128: four spill)
     static constexpr int kSpan = (7 * G) / 8 > 0 ? (7 * G) / 8 : 1;
     static constexpr int kPspan = (W * NT + kSpan - 1) / kSpan;
     static constexpr int kPmax = (kWin * NT - NT + 1) / 2;           // keeps kD >= 1: an add never shares a gap with its loads
