@@ -199,26 +199,42 @@ __global__ __launch_bounds__(256) void sage_first_fwd_kernel(
     const int r0 = blockIdx.x * 32;
     for (int i = tid; i < 2 * hp * kSmallCin; i += 256) sW[i] = w0[i];
     for (int i = tid; i < hp; i += 256) sW[2 * 128 * kSmallCin + i] = bias[i];
-    if (tid < 32) {
-        const int row = r0 + tid;
+    {
+        // eight lanes per row: lane k takes neighbours k, k + 8, ... (one thread per row walked the CSR serially: 16 us for a
+        // layer of 2 x 110 FMAs per node); the partial sums meet in a fixed xor tree over the eight lanes
+        const int rr = tid >> 3, k = tid & 7;
+        const int row = r0 + rr;
         float a[kSmallCin], s[kSmallCin];
 #pragma unroll
         for (int q = 0; q < kSmallCin; ++q) { a[q] = 0.f; s[q] = 0.f; }
         if (row < n) {
-            for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+            const int e1 = rowptr[row + 1];
+            for (int e = rowptr[row] + k; e < e1; e += 8) {
                 const float* xr = x + (size_t)col[e] * x_stride;
-                for (int q = 0; q < c_in; ++q) a[q] += xr[q];
-            }
-            const float sc = invdeg[row];
-            const float* xs = x + (size_t)row * x_stride;
-            for (int q = 0; q < c_in; ++q) { a[q] *= sc; s[q] = xs[q]; }
-            if (agg_out) {
 #pragma unroll
-                for (int q = 0; q < kSmallCin; ++q) agg_out[(size_t)row * kSmallCin + q] = a[q];
+                for (int q = 0; q < kSmallCin; ++q) if (q < c_in) a[q] += xr[q];
             }
         }
 #pragma unroll
-        for (int q = 0; q < kSmallCin; ++q) { sA[tid][q] = a[q]; sX[tid][q] = s[q]; }
+        for (int q = 0; q < kSmallCin; ++q) {
+            a[q] += __shfl_xor(a[q], 1);
+            a[q] += __shfl_xor(a[q], 2);
+            a[q] += __shfl_xor(a[q], 4);
+        }
+        if (k == 0) {
+            if (row < n) {
+                const float sc = invdeg[row];
+                const float* xs = x + (size_t)row * x_stride;
+#pragma unroll
+                for (int q = 0; q < kSmallCin; ++q) { a[q] *= sc; if (q < c_in) s[q] = xs[q]; }
+                if (agg_out) {
+#pragma unroll
+                    for (int q = 0; q < kSmallCin; ++q) agg_out[(size_t)row * kSmallCin + q] = a[q];
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < kSmallCin; ++q) { sA[rr][q] = a[q]; sX[rr][q] = s[q]; }
+        }
     }
     __syncthreads();
     const float* sWl = sW;
@@ -889,8 +905,19 @@ __global__ __launch_bounds__(256) void sage_first_dw_kernel(
 #pragma unroll
     for (int q = 0; q < 17; ++q) acc[q] = 0.f;
     if (o < hp) {
-#pragma unroll 4
-        for (int rr = ph; rr < rows; rr += 2) {
+        int rr = ph;
+        for (; rr + 14 < rows; rr += 16) {          // eight rows' loads in flight, same summation order
+            float gv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) gv[u] = g[(size_t)(r_beg + rr + 2 * u) * hp + o];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[q] += gv[u] * s_in[rr + 2 * u][q];
+                acc[16] += gv[u];
+            }
+        }
+        for (; rr < rows; rr += 2) {
             const float gv = g[(size_t)(r_beg + rr) * hp + o];
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[q] += gv * s_in[rr][q];
