@@ -91,7 +91,7 @@ def main():
                 q = q_net(s.x, s.edge_index, s.batch, s.ptr)
                 loss, td = ops.td_loss(q, s.ptr[:-1] + act.long(), y, w, "mse")
                 opt.zero_grad(set_to_none=True)
-                loss.backward()
+                ops.backward(loss)
                 opt.step()
                 buf.update_priorities(idx, td.abs() + 1e-3)
                 if k + 1 < args.updates:

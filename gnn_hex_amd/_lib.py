@@ -77,6 +77,7 @@ _SIGS = {
     "hexgnn_select_actions": (ci, [ci, vp, vp, vp, C.c_float, vp, vp, vp, vp, vp]),
     "hexgnn_td_loss_forward": (ci, [ci, ci, vp, vp, vp, vp, ci, vp, vp, vp]),
     "hexgnn_td_loss_backward": (ci, [ci, ci, vp, vp, vp, ci, vp, vp, vp]),
+    "hexgnn_td_loss_forward_backward": (ci, [ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
     "hexgnn_profile_enable": (ci, [ci]),
     "hexgnn_profile_read": (ci, [vp, vp]),
     "hexgnn_pad_rows": (ci, [ci, ci, vp, ci, vp, vp]),

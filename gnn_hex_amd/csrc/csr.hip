@@ -337,6 +337,7 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst, int* 
                      size_t workspace_bytes, hexgnn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || e < 0 || !rowptr || !rowptr_t || !status || (n > 0 && !invdeg)) return HEXGNN_EINVAL;
+    if (e > 0x1fffffff) return HEXGNN_EUNSUPPORTED;   // the layer kernels fetch column ids through 32-bit byte offsets (e * 4 < 2^31)
     if (e > 0 && (!src || !dst || !col || !col_t)) return HEXGNN_EINVAL;
     if (workspace_bytes < hexgnn_csr_workspace_bytes(n, e) || !workspace) return HEXGNN_EWORKSPACE;
     int* cur = (int*)workspace;
@@ -372,6 +373,7 @@ int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int6
     if (n < 0 || e < 0 || b < 0 || !rowptr || !rowptr_t || !status || (!gptr && !ptr64) || (ptr64 && !gptr_out) ||
         (n > 0 && !invdeg))
         return HEXGNN_EINVAL;
+    if (e > 0x1fffffff) return HEXGNN_EUNSUPPORTED;
     if (e > 0 && (!src || !dst || !col || !col_t)) return HEXGNN_EINVAL;
     // status is OR-ed into and NOT cleared here (a memset launch per batch for a word that stays zero unless the caller's
     // data is broken): the caller hands a word it zeroed, e.g. one long-lived sticky error word per device

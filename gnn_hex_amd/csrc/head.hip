@@ -467,6 +467,77 @@ __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const in
 }
 
 
+// Forward AND backward of the TD loss in ONE launch (the DQN update differentiates the loss itself, so d loss / d q is
+// known the moment the loss is: grad_loss == 1): every workgroup owns a 1024-node range of dq exactly as
+// td_loss_bwd_kernel does, with td_j = q[sel_j] - target_j formed on the fly; workgroup 0 additionally writes td[] and the
+// mean.  Same fixed-shape sums / commuting atomics as the two-launch form: bit-identical results.
+__global__ __launch_bounds__(256) void td_loss_fused_kernel(int n, int k, const float* __restrict__ q,
+                                                           const int64_t* __restrict__ sel, const float* __restrict__ tgt,
+                                                           const float* __restrict__ w, int loss_fn,
+                                                           float* __restrict__ loss, float* __restrict__ td,
+                                                           float* __restrict__ dq) {
+    __shared__ __attribute__((aligned(16))) int s_i[1024];
+    __shared__ __attribute__((aligned(16))) float s_g[1024];
+    __shared__ int s_cnt[1024];
+    __shared__ float red[256];
+    const int lo = blockIdx.x * 1024, hi = min(lo + 1024, n);
+    for (int i = lo + threadIdx.x; i < hi; i += 256) dq[i] = 0.f;
+    const float gl = 1.f / (float)(k > 0 ? k : 1);
+    float acc_loss = 0.f;
+    for (int c0 = 0; c0 < k; c0 += 1024) {
+        const int kk = min(1024, k - c0);
+        __syncthreads();
+        for (int j = threadIdx.x; j < 1024; j += 256) { s_cnt[j] = 0; s_i[j] = -1; s_g[j] = 0.f; }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kk; j += 256) {
+            const int64_t i = sel[c0 + j];
+            const bool inside = i >= 0 && i < n;
+            const bool mine = i >= lo && i < hi;
+            const float d = inside ? q[i] - tgt[c0 + j] : 0.f;
+            const float wj = w ? w[c0 + j] : 1.f;
+            if (blockIdx.x == 0) {
+                td[c0 + j] = d;
+                const float a = fabsf(d);
+                acc_loss += wj * (loss_fn == 0 ? d * d : (a <= 1.f ? 0.5f * d * d : a - 0.5f));
+            }
+            const float dl = loss_fn == 0 ? 2.f * d : fminf(fmaxf(d, -1.f), 1.f);
+            s_i[j] = mine ? (int)i : -1;
+            s_g[j] = gl * wj * dl;
+            if (mine) atomicAdd(&s_cnt[(int)i - lo], 1);
+        }
+        __syncthreads();
+        for (int j = threadIdx.x; j < kk; j += 256) {
+            const int i = s_i[j];
+            if (i < 0) continue;
+            if (s_cnt[i - lo] <= 2) { atomicAdd(dq + i, s_g[j]); continue; }
+            bool first = true;
+            float acc = s_g[j];
+            for (int q4 = 0; q4 < (kk + 3) / 4; ++q4) {
+                const int4 ii = reinterpret_cast<const int4*>(s_i)[q4];
+                const f32x4 gg = reinterpret_cast<const f32x4*>(s_g)[q4];
+                const int qq = 4 * q4;
+                first = first && !((ii.x == i && qq < j) || (ii.y == i && qq + 1 < j) || (ii.z == i && qq + 2 < j) ||
+                                   (ii.w == i && qq + 3 < j));
+                acc += (ii.x == i && qq > j) ? gg[0] : 0.f;
+                acc += (ii.y == i && qq + 1 > j) ? gg[1] : 0.f;
+                acc += (ii.z == i && qq + 2 > j) ? gg[2] : 0.f;
+                acc += (ii.w == i && qq + 3 > j) ? gg[3] : 0.f;
+            }
+            if (first) atomicAdd(dq + i, acc);
+        }
+    }
+    if (blockIdx.x == 0) {      // the mean, in td_loss_fwd_kernel's reduction shape (thread t sums entries t, t+256, ...)
+        red[threadIdx.x] = acc_loss;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) loss[0] = red[0] / (float)(k > 0 ? k : 1);
+    }
+}
+
+
 // ---- acting: per-graph epsilon-greedy / argmax over the non-terminal nodes, mapped to vertex ids ----------------------
 // One wave per graph.  Greedy = first node attaining the maximum of q[gptr[g]+2 : gptr[g+1]] (torch.argmax tie rule;
 // GN0/RainbowDQN/evaluate_elo.py:253-266); with u given, env g explores when u[2g] < eps and then plays node
@@ -533,6 +604,16 @@ int hexgnn_td_loss_backward(int n, int k, const int64_t* sel, const float* td, c
     hipStream_t st = (hipStream_t)stream_;
     if (n < 0 || k < 0 || loss_fn < 0 || loss_fn > 1 || !grad_loss || (n > 0 && !dq) || (k > 0 && (!sel || !td))) return HEXGNN_EINVAL;
     if (n > 0) td_loss_bwd_kernel<<<(n + 1023) / 1024, 256, 0, st>>>(n, k, sel, td, weights, loss_fn, grad_loss, dq);
+    return check_launch();
+}
+
+int hexgnn_td_loss_forward_backward(int n, int k, const float* q, const int64_t* sel, const float* target,
+                                    const float* weights, int loss_fn, float* loss, float* td, float* dq,
+                                    hexgnn_stream_t stream_) {
+    if (n < 0 || k < 0 || loss_fn < 0 || loss_fn > 1 || !loss || (n > 0 && !dq) || (k > 0 && (!q || !sel || !target || !td)))
+        return HEXGNN_EINVAL;
+    td_loss_fused_kernel<<<n > 0 ? (n + 1023) / 1024 : 1, 256, 0, (hipStream_t)stream_>>>(n, k, q, sel, target, weights,
+                                                                                        loss_fn, loss, td, dq);
     return check_launch();
 }
 

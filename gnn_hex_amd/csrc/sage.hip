@@ -28,6 +28,9 @@ int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
     const int hp = padded_width(hidden);
     if (hp < 0 || L < 1 || L > kMaxLayers) return HEXGNN_EUNSUPPORTED;
     if (c_in != hidden && (c_in < 1 || c_in > kSmallCin)) return HEXGNN_EUNSUPPORTED;
+    // rows are addressed through raw-buffer resources with 32-bit byte offsets and num_records 2^31 - 1: a slab of n rows must
+    // stay below 2 GiB (4.7 M nodes at hidden 112: ~150x the largest BASELINE batch), beyond it loads would return zeros
+    if (n > 0 && (size_t)n * hp * sizeof(float) > 0x7fffffffull) return HEXGNN_EUNSUPPORTED;
     p->hp = hp; p->nt = hp / 16; p->L = L; p->c_in = c_in;
     p->small_first = (c_in != hidden);
     size_t off = 0, soff = 0;

@@ -149,6 +149,13 @@ class DeviceRollout:
     def __init__(self, mgr: "Env_manager", model, steps: int = 16, eps: float = 0.05, graph: bool = True):
         if steps < 2 or steps % 2:
             raise ValueError("steps must be a positive even number")
+        if getattr(getattr(model, "gnn", None), "norms", None) is not None:
+            # --norm=True normalises over the LIVE batch (all nodes of the current observation).  The rollout hands the model
+            # capacity-sized buffers (num_envs * nv rows) whose tail rows are stale once nodes have been removed; the
+            # whole-batch statistics of the norm kernels would include them and the Q-values would silently differ from
+            # the reference.  Use the step-by-step API (Env_manager.observe / step), whose batches are exact-size.
+            raise NotImplementedError("DeviceRollout does not support models built with --norm=True (whole-batch LayerNorm "
+                                      "needs exact-size batches); use Env_manager.observe()/step()")
         self.mgr, self.model, self.T, self.eps = mgr, model, steps, float(eps)
         self.start_side = mgr.global_onturn
         dev = mgr.device

@@ -158,9 +158,11 @@ class GraphStructure:
         if code != 0:
             if self.status is _STICKY.get((self.status.device.type, self.status.device.index)):
                 self.status.zero_()
-            raise IndexError("invalid batch structure (status=%d): 1 = node id outside [0,%d), 2 = graph larger than "
+            raise IndexError("invalid batch structure (status=%d): 1 = node id outside [0,n), 2 = graph larger than "
                              "128 nodes reached the fused kernel, 4 = an edge connects two graphs (or a batch passed as grouped is "
-                             "not), 8 = graph above 2048 nodes in the grouped build" % (code, self.n))
+                             "not), 8 = graph above 2048 nodes in the grouped build.  This batch has n = %d; the word is shared "
+                             "by every batch of this device since the last check(), so the error may stem from an EARLIER "
+                             "batch (it is cleared now)" % (code, self.n))
 
 
 def graph_ptr(graph_indices: Optional[torch.Tensor], ptr: Optional[torch.Tensor], n: int, device):
@@ -545,6 +547,9 @@ class QNetFusedFn(torch.autograd.Function):
         if x.dtype != torch.float32 or x.stride(1) != 1:
             x = x.float().contiguous()
         x_stride = x.stride(0) if n > 0 else c_in
+        # a parameter that is computed per forward (FactorizedNoisyLinear's mu + sigma * eps) is no leaf: its gradient is
+        # an intermediate that autograd still has to carry to mu / sigma, so it must not be all-reduced in place
+        ctx.nonleaf_params = any(p.grad_fn is not None for p in params)
         params = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous() for p in params]
         convs, tail = params[:3 * tot], params[3 * tot:]
         wl, bl, wr = convs[0::3], convs[1::3], convs[2::3]
@@ -620,7 +625,10 @@ class QNetFusedFn(torch.autograd.Function):
                   vp_arr(*cp[0::3]), vp_arr(*cp[1::3]), vp_arr(*cp[2::3]), tp[0], tp[1], tp[2], tp[3], tp[4], tp[5],
                   ws.data_ptr(), ws_bytes, status.data_ptr())
         hook = _GRAD_STAGE_HOOK
-        if hook is None or tot < 3 or mode == 2:
+        if hook is None or tot < 3 or mode == 2 or ctx.nonleaf_params:
+            # (non-leaf parameters, --noisy_dqn=True: d_sigma = d_w * eps with per-rank noise is not the average of the ranks'
+            # d_sigma if d_w is averaged first, and the mu / sigma gradients live outside the flat buffer: no staging, GradSync
+            # reduces the finished .grad tensors through its bucket)
             _lib.check(L.hexgnn_qnet_backward(*common, _stream()), "hexgnn_qnet_backward")
         else:
             # two stages: the upper half of the hidden layers + everything small first -- with the head tail they are the
@@ -639,9 +647,16 @@ class QNetFusedFn(torch.autograd.Function):
         return (None,) * 10 + tuple(cg) + tuple(tg)
 
 
+_UNIT_GRAD = False      # set by backward(): the loss itself is the root of the backward pass, i.e. grad_loss == 1
+_ONES = {}
+
+
 class TdLossFn(torch.autograd.Function):
-    """``loss_fn(Q[sel], target)`` of the DQN update as one kernel forward and memset + scatter backward (C ABI
-    ``hexgnn_td_loss_*``): mean of importance-weighted squared ("mse") or Huber errors over the selected nodes."""
+    """``loss_fn(Q[sel], target)`` of the DQN update: mean of importance-weighted squared ("mse") or Huber errors over the
+    selected nodes.  When Q needs a gradient the forward is ONE launch that also produces ``d loss / d Q``
+    (``hexgnn_td_loss_forward_backward``); the backward then hands that buffer on when the loss is the root of the pass
+    (``ops.backward(loss)``: nothing is launched at all) and runs the two-launch form's scatter with the upstream scale
+    otherwise (``loss.backward()`` / a scaled loss: ``hexgnn_td_loss_backward``).  Same bits either way."""
 
     @staticmethod
     def forward(ctx, q, sel, target, weights, loss_fn: int):
@@ -659,10 +674,19 @@ class TdLossFn(torch.autograd.Function):
             raise ValueError("sel / target / weights must have the same length")
         loss = torch.empty((), dtype=torch.float32, device=dev)
         td = torch.empty(k, dtype=torch.float32, device=dev)
-        _lib.check(L.hexgnn_td_loss_forward(n, k, qf.data_ptr(), sel.data_ptr(), tgt.data_ptr(),
-                                            w.data_ptr() if w is not None else None, loss_fn, loss.data_ptr(),
-                                            td.data_ptr(), _stream()), "hexgnn_td_loss_forward")
+        dq = None
+        if ctx.needs_input_grad[0]:
+            dq = torch.empty(n, dtype=torch.float32, device=dev)
+            _lib.check(L.hexgnn_td_loss_forward_backward(n, k, qf.data_ptr(), sel.data_ptr(), tgt.data_ptr(),
+                                                         w.data_ptr() if w is not None else None, loss_fn,
+                                                         loss.data_ptr(), td.data_ptr(), dq.data_ptr(), _stream()),
+                       "hexgnn_td_loss_forward_backward")
+        else:
+            _lib.check(L.hexgnn_td_loss_forward(n, k, qf.data_ptr(), sel.data_ptr(), tgt.data_ptr(),
+                                                w.data_ptr() if w is not None else None, loss_fn, loss.data_ptr(),
+                                                td.data_ptr(), _stream()), "hexgnn_td_loss_forward")
         ctx.save_for_backward(sel, td, w if w is not None else td)
+        ctx.dq = dq
         ctx.has_w, ctx.loss_fn, ctx.shape = w is not None, loss_fn, q.shape
         ctx.mark_non_differentiable(td)
         return loss, td
@@ -671,6 +695,9 @@ class TdLossFn(torch.autograd.Function):
     def backward(ctx, gloss, _gtd):
         if gloss is None:
             return None, None, None, None, None
+        if _UNIT_GRAD and ctx.dq is not None:       # the loss is the root: d loss / d q was produced by the forward launch
+            dq, ctx.dq = ctx.dq, None
+            return dq.view(ctx.shape), None, None, None, None
         sel, td, w = ctx.saved_tensors
         n = 1
         for d in ctx.shape:
@@ -691,7 +718,30 @@ def td_loss(q: torch.Tensor, sel: torch.Tensor, target: torch.Tensor, weights: O
     ``weights`` is None."""
     if q.device.type != "cuda":
         raise _lib.HexGnnError("td_loss runs only on the MI355X HIP path (no CPU fallback)")
-    return TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])
+    out = TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])
+    out[0]._hex_td_root = True
+    return out
+
+
+def backward(loss: torch.Tensor) -> None:
+    """``loss.backward()`` for a loss returned by ``td_loss`` without the two launches autograd adds around it: the
+    ``ones_like(loss)`` fill that seeds the pass, and the scaling scatter of ``d loss / d Q`` (the fused forward launch
+    already produced it for a unit seed).  Any other tensor falls through to ``loss.backward()``.  Gradients are
+    bit-identical to ``loss.backward()``."""
+    global _UNIT_GRAD
+    if not getattr(loss, "_hex_td_root", False) or not loss.is_cuda:
+        loss.backward()
+        return
+    key = (loss.device.type, loss.device.index)
+    one = _ONES.get(key)
+    if one is None:
+        one = torch.ones((), dtype=torch.float32, device=loss.device)
+        _ONES[key] = one
+    _UNIT_GRAD = True
+    try:
+        torch.autograd.backward((loss,), (one,))
+    finally:
+        _UNIT_GRAD = False
 
 
 def greedy_nodes(q: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:

@@ -333,6 +333,12 @@ int hexgnn_td_loss_forward(int n, int k, const float* q, const int64_t* sel, con
 int hexgnn_td_loss_backward(int n, int k, const int64_t* sel, const float* td, const float* weights, int loss_fn,
                             const float* grad_loss, float* dq, hexgnn_stream_t stream);
 
+/* Both of the above in ONE launch for the usual case that the loss itself is differentiated (grad_loss == 1, what
+ * `loss.backward()` of the training loop does): loss, td AND dq[n] = d loss / d q.  Bit-identical to the two calls. */
+int hexgnn_td_loss_forward_backward(int n, int k, const float* q, const int64_t* sel, const float* target,
+                                    const float* weights, int loss_fn, float* loss, float* td, float* dq,
+                                    hexgnn_stream_t stream);
+
 /* ---- acting: epsilon-greedy action per graph straight from the Q / advantage vector (replaces the per-graph python
  *      argmax over action_values[ptr[g]+2 : ptr[g+1]] of GN0/RainbowDQN/evaluate_elo.py:253-266 and the backmap lookup
  *      of Env_manager.validate_actions, graph_game/multi_env_manager.py:62-64).  u: [b][2] uniforms in [0,1) or NULL for

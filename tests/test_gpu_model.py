@@ -509,6 +509,48 @@ def test_td_loss_matches_torch(loss_fn, weighted):
     assert not td.requires_grad
 
 
+@pytest.mark.parametrize("loss_fn", ["mse", "huber"])
+def test_td_loss_one_launch_form_is_bit_identical(loss_fn):
+    """``ops.backward(loss)`` (one launch: loss, td and d loss / d q together, no ones-fill, no scatter launch) against
+    ``loss.backward()`` on the same inputs (forward launch + ``hexgnn_td_loss_backward``): loss, td and the gradient must
+    agree bit for bit -- with duplicated selections (twice and five times the same node), out-of-range entries, weights,
+    and more than one 1024-node range / 1024-entry chunk."""
+    from gnn_hex_amd import ops
+    if ops.get_math() != "fp32" or not ops._FUSED_ENABLED:
+        pytest.skip("mode-independent")
+    gen = torch.Generator().manual_seed(23)
+    n, k = 5000, 2300
+    q0 = (torch.randn(n, generator=gen) * 1.5)
+    sel = torch.randint(0, n, (k,), generator=gen)
+    sel[5] = sel[17]
+    sel[100:105] = sel[99]
+    sel[7] = -1
+    sel[8] = n + 3
+    tgt = torch.randn(k, generator=gen)
+    w = torch.rand(k, generator=gen) + 0.1
+    outs = []
+    for fused in (False, True):
+        qh = q0.clone().cuda().requires_grad_(True)
+        loss, td = ops.td_loss(qh, sel.cuda(), tgt.cuda(), w.cuda(), loss_fn)
+        if fused:
+            ops.backward(loss)
+        else:
+            loss.backward()
+        torch.cuda.synchronize()
+        outs.append((loss.detach().clone(), td.clone(), qh.grad.clone()))
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+    # a scaled loss is not the root of the pass: ops.backward must fall through to autograd
+    qh = q0.clone().cuda().requires_grad_(True)
+    loss, _ = ops.td_loss(qh, sel.cuda(), tgt.cuda(), w.cuda(), loss_fn)
+    ops.backward(loss * 0.5)
+    assert torch.allclose(qh.grad, outs[0][2] * 0.5, rtol=1e-6, atol=1e-9)
+    # no gradient wanted: the forward-only launch
+    with torch.no_grad():
+        l2, td2 = ops.td_loss(q0.cuda(), sel.cuda(), tgt.cuda(), w.cuda(), loss_fn)
+    assert torch.equal(l2, outs[0][0]) and torch.equal(td2, outs[0][1])
+
+
 def test_randomised_configurations():
     """Seeded sweep over widths, depths, batch shapes, edge densities, directed / symmetric graphs, both CSR builds and both
     arithmetic modes of the fused kernels against the oracle (1e-4 on Q, 1e-4 relative to max(1, |g|max) on gradients)."""

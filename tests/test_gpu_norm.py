@@ -128,3 +128,14 @@ def test_norm_model_at_the_benchmark_batch():
         worst_hip, worst_ref = max(worst_hip, eh), max(worst_ref, er)
         assert e32 < TOL or eh < 3.0 * er, "%s: vs fp32 oracle %g, vs float64 %g (fp32 oracle vs float64 %g)" % (k, e32, eh, er)
     print("norm L256-D1 gradients vs the float64 oracle: HIP %.3g, fp32 oracle %.3g" % (worst_hip, worst_ref))
+
+
+def test_device_rollout_refuses_norm_models():
+    """the rollout hands the model capacity-sized buffers whose tail rows are stale after node removals; the
+    whole-batch LayerNorm statistics would include them.  It must refuse instead of returning silently different Q-values."""
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
+    hip, _ = _norm_pair(3, 35, seed=9, noisy=False)
+    mgr = Env_manager(4, 5, device="cuda")
+    mgr.reset()
+    with pytest.raises(NotImplementedError, match="norm"):
+        DeviceRollout(mgr, hip, steps=2, eps=0.0, graph=False)

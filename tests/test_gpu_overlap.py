@@ -165,6 +165,27 @@ def test_rccl_call_sequence_on_a_one_rank_group():
         for k, p in hip.named_parameters():
             if g_one[k] is not None:
                 assert torch.equal(p.grad, g_one[k]), k
+        # --noisy_dqn=True with the overlap switched on: the advantage linear's effective weight mu + sigma * eps
+        # is no leaf, its gradient must not be all-reduced in place inside the backward -- the staging is skipped and the
+        # finished mu / sigma gradients go through the bucket.  One rank: gradients unchanged, no "more than one backward"
+        from argparse import Namespace
+        from gnn_hex_amd.models import get_pre_defined
+        torch.manual_seed(64)
+        noisy = get_pre_defined("modern_two_headed", Namespace(num_layers=4, hidden_channels=35, norm=False, noisy_dqn=True,
+                                                               noisy_sigma0=0.5, num_head_layers=2)).cuda()
+        _, g_ref = _step(noisy, data)
+        nsync = GradSync(noisy.parameters(), check=True, single_rank_collectives=True)
+        nsync.enable_overlap()
+        _, g_n = _step(noisy, data)
+        assert not nsync._segments                       # nothing was handed over from inside the backward
+        nn_ = nsync.all_reduce()
+        torch.cuda.synchronize()
+        assert nn_ == sum(p.numel() for p in noisy.parameters() if p.grad is not None)
+        assert g_n["maker_head.linear.weight_sigma"] is not None or g_n["breaker_head.linear.weight_sigma"] is not None
+        for k, p in noisy.named_parameters():
+            if g_n[k] is not None:
+                assert torch.equal(g_n[k], g_ref[k]), k
+                assert torch.equal(p.grad, g_n[k]), k
     finally:
         ops.set_grad_stage_hook(None)
         dist.destroy_process_group()
