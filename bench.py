@@ -39,36 +39,47 @@ CONFIGS = {
     "MIX": (15, 110, lambda b: [5 + (g % 9) for g in range(b)], "GNN-L mixed Hex-5..13 ragged batch=256"),
 }
 
+WORLD_FOR_WEIGHTS = [1]      # world size seen by make_batches' strong-scaling loss weights
+
 KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel",
           8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
 
 
-def make_batches(config, data, B, dev, rank=0):
-    """The two resident batches (maker to move / breaker to move) of a configuration; D1 graphs differ per rank."""
+def make_batches(config, data, B, dev, rank=0, subset=None):
+    """The two resident batches (maker to move / breaker to move) of a configuration.  Weak scaling: every rank holds its own
+    B graphs (D1 graphs differ per rank).  Strong scaling (`subset` = this rank's graph indices of ONE global B-graph batch,
+    gnn_hex_amd.dist.balance_by_edges): the rank holds only those graphs; D1 seeds are the global graph indices."""
     from helpers import batch_tensors, sel_and_targets
     sizes_fn = CONFIGS[config][2]
+    all_sizes = sizes_fn(B)
+    graphs = list(range(B)) if subset is None else list(subset)
+    sizes = [all_sizes[g] for g in graphs]
     batches = []
     for maker in (True, False):
         if data == "D0":
-            x, ei, bv, ptr = batch_tensors("D0", sizes_fn(B), maker=maker)
+            x, ei, bv, ptr = batch_tensors("D0", sizes, maker=maker)
         else:
             from oracle import env_ref          # input generation only (before any timed region)
             import numpy as np
             xs, eis, bvs, ptrs, off = [], [], [], [0], 0
-            for g, size in enumerate(sizes_fn(B)):
-                game = env_ref.random_position(size, 100000 * rank + g, maker)
+            for g, size in zip(graphs, sizes):
+                game = env_ref.random_position(size, (100000 * rank + g) if subset is None else g, maker)
                 gx, gei, _ = game.observe()
-                xs.append(gx); eis.append(gei + off); bvs.append(np.full(gx.shape[0], g, dtype=np.int64))
+                bvs.append(np.full(gx.shape[0], len(xs), dtype=np.int64)); xs.append(gx); eis.append(gei + off)
                 off += gx.shape[0]; ptrs.append(off)
             x, ei, bv, ptr = (torch.from_numpy(np.concatenate(xs, 0)), torch.from_numpy(np.concatenate(eis, 1)),
                               torch.from_numpy(np.concatenate(bvs)), torch.tensor(ptrs, dtype=torch.long))
         sel, tgt = sel_and_targets(ptr, seed=1 + rank)       # every rank regresses on its own targets
+        # strong scaling: the loss is the mean over the GLOBAL batch -- a rank's mean over its k graphs times k * world / B,
+        # so that the gradient average over the ranks is the global mean even when the edge-balanced parts differ in count
+        wts = None if subset is None else torch.full((len(graphs),), float(len(graphs)) * WORLD_FOR_WEIGHTS[0] / B)
         xd = x.to(dev)
         xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
         xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
         eid = ei.to(dev)
         eid._hex_grouped = True           # collated graph by graph (what Batch.from_data_list produces and marks)
         batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
+                            w=None if wts is None else wts.to(dev), graphs=len(graphs),
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
     return batches
 
@@ -163,6 +174,10 @@ def main():
                     help="untimed device preheat before the W warm-up steps: the step is repeated until this much wall time "
                          "has passed, so that the clocks, the caching allocator and the TLBs are in their steady state when "
                          "the K timed steps start (a cold start runs its first 20 steps ~5 %% slower); 0 disables it")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak (default, the BASELINE metric): every GPU steps its own --batch graphs.  strong: ONE global "
+                         "--batch-graph batch per step, split over the GPUs by edge count (gnn_hex_amd.dist.balance_by_edges); "
+                         "value = --batch graphs per step time")
     ap.add_argument("--sustain-s", type=float, default=2.0,
                     help="after the K timed steps, repeat the step for at least this many seconds and report that window as "
                          "`sustained` (never `value`); 0 disables it")
@@ -170,6 +185,8 @@ def main():
                     help="N > 1: one all-reduce after the backward instead of the staged backward whose first gradient "
                          "segment is reduced while the rest of the weight-gradient GEMM computes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-collective-probe", action="store_true",
+                    help="N = 1: skip the 1-rank RCCL all-reduce latency probe of the gradient bucket (config.collective)")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the extra lines for the other single-GPU BASELINE configurations (D1 boards, GNN-S, MIX) that "
                          "the default N=1 run appends as `other_configs`")
@@ -225,7 +242,20 @@ def main():
 
     # two resident batches (maker to move / breaker to move), alternated per step; each rank draws its own
     # graphs for D1 (seed offset by rank), D0 is the same start position everywhere.
-    batches = make_batches(args.config, args.data, B, dev, rank)
+    subset = None
+    strong = args.scaling == "strong"
+    if strong:
+        # ONE global batch; graph g's directed edge count from the closed form of its board size (start positions) -- the
+        # partition must be known to every rank without building the other ranks' graphs; mid-game boards keep the same
+        # order of sizes, so the start-position counts balance them as well
+        from gnn_hex_amd.dist import balance_by_edges
+        def edges_of(nn):
+            return 2 * (2 * nn + (nn - 2) * (nn - 1) + nn * (nn - 1) + (nn - 1) ** 2)
+        parts = balance_by_edges([edges_of(sz) for sz in sizes_fn(B)], world)
+        subset = parts[rank]
+        WORLD_FOR_WEIGHTS[0] = world
+    batches = make_batches(args.config, args.data, B, dev, rank, subset)
+    gfactor = 1 if strong else world          # graphs per step over all ranks = B * gfactor
 
     plist = list(hip.parameters())
 
@@ -234,7 +264,7 @@ def main():
         for p in plist:              # optimizer.zero_grad(set_to_none=True) over a cached parameter list
             p.grad = None
         q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
-        loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"])
+        loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"], bt["w"])
         hexops.backward(loss)       # == loss.backward(), minus autograd's ones-fill and the TD scatter launch (ops.backward)
         if world > 1:
             sync.all_reduce()
@@ -247,7 +277,7 @@ def main():
                 for p in plist:
                     p.grad = None
                 q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
-                loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"])
+                loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"], bt["w"])
                 hexops.backward(loss)
                 return loss
             return fn
@@ -262,6 +292,12 @@ def main():
                 sync.all_reduce()
 
     init_group()
+    # the first step of every run verifies with one tiny collective that all ranks reduce the SAME parameter set (same side to
+    # move): ranks that disagree would otherwise hang or mix the two heads' gradients (GradSync check)
+    sync.check = world > 1
+    if world > 1:
+        step(0)
+        sync.check = False
 
     def barrier():
         torch.cuda.synchronize()
@@ -302,7 +338,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms_per_step = dt / args.steps * 1e3
-    value = B * world * args.steps / dt
+    value = B * gfactor * args.steps / dt
 
     # what holds under load: the same step for >= `--sustain-s` seconds (same count on every rank), reported beside the
     # K-step line (`value` stays the driver's protocol).  The short window can sit inside a boost period of the box.
@@ -319,7 +355,7 @@ def main():
             t = torch.tensor([dts], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dts = float(t.item())
-        sustained = {"seconds": dts, "steps": ks, "ms_per_step": dts / ks * 1e3, "value": B * world * ks / dts}
+        sustained = {"seconds": dts, "steps": ks, "ms_per_step": dts / ks * 1e3, "value": B * gfactor * ks / dts}
 
     # N > 1: the replicas must stay identical -- one more step, a plain SGD update from the all-reduced gradients on every
     # rank, then the parameter checksums of all ranks are compared (a rank that reduced a different bucket would diverge)
@@ -375,7 +411,7 @@ def main():
         roof["frac"] = roof["achieved"] / roof["peak"]
         # the same launch priced against the OTHER roof as well: the fused kernels keep a graph's rows in LDS, so their HBM
         # traffic is far below the un-fused algorithmic bytes and the binding roof is the MFMA pipe of the arithmetic in use
-        launch_flops = (flops_fwd(n, B, hidden, num_layers) if dom in (8, 9)
+        launch_flops = (flops_fwd(n, batches[0]["graphs"], hidden, num_layers) if dom in (8, 9)
                         else 2.0 * n * (2 * hidden) * hidden * (hidden_layers / max(launches / args.steps, 1)) if dom == 2
                         else 4.0 * n * hidden * hidden)
         mfma_peak = MFMA_PEAK_TFLOPS[args.math]
@@ -434,19 +470,26 @@ def main():
             note("CPU baseline sweep (bounded: ~40 s)")
             cpu = cpu_baseline(ref, batches, B)
 
+        probe = None
+        if world == 1 and not args.no_collective_probe:
+            probe = collective_probe(dev, 4 * sum(p.numel() for p in plist if p.grad is not None))
+
         out = {
             "metric": "board-graphs/sec fwd+bwd", "value": value, "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "preheat_steps": preheat_steps, "ms_per_step": ms_per_step,
             "higher_is_better": True, "sustained": sustained,
-            "scaling": "weak", "vs_baseline": None,
+            "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.math == "fp32" else "f32 operands split into scaled f16 hi+lo (f16x3 MFMA, 22-bit products), f32 accumulate",
             "data": "synthetic",
             "config": {"workload": "%s, %s board graphs, %d graphs per GPU (N=%d nodes, E=%d directed edges)"
                                    % (label, "start-position" if args.data == "D0" else "random-playout",
-                                      B, batches[0]["n"], batches[0]["e"]),
-                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * world},
+                                      batches[0]["graphs"], batches[0]["n"], batches[0]["e"]),
+                       "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * gfactor,
+                       "graphs_per_gpu": batches[0]["graphs"]},
             "roofline": roof, "cpu_baseline": cpu, "split_precision_mode": split, "other_configs": others,
         }
+        if probe is not None:
+            out["config"]["collective"] = probe
         if world > 1:
             out["replicas_identical"] = replicas_identical
             out["config"]["collective"] = {"backend": "rccl" if args.backend == "nccl" else "gloo (rehearsal)",
@@ -511,13 +554,43 @@ def selfplay(args, num_layers, hidden, label, dev):
     return out
 
 
+def collective_probe(dev, nbytes, reps=50):
+    """N = 1 only: what ONE all-reduce of the step's gradient bucket costs on this GPU through the exact call the N-rank
+    path makes (a 1-rank RCCL group, in-place SUM on a flat fp32 buffer of the bucket's size): launch + kernel latency of the
+    collective without any wire time, i.e. the floor the per-step exchange adds when it is not overlapped.  Never raises."""
+    try:
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        try:
+            flat = torch.zeros(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
+            for _ in range(5):
+                dist.all_reduce(flat)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                dist.all_reduce(flat)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) / reps * 1e6
+        finally:
+            dist.destroy_process_group()
+        return {"backend": "rccl", "world": 1, "bucket_bytes": int(nbytes), "all_reduce_us_one_rank": us,
+                "note": "1-rank RCCL group on this GPU: launch + kernel latency of the per-step gradient all-reduce, no wire time"}
+    except Exception as exc:  # noqa: BLE001
+        return {"backend": "rccl", "world": 1, "error": "%s: %s" % (type(exc).__name__, exc)}
+
+
 def step_local(hip, batches, i):
     from gnn_hex_amd import ops as hexops
     bt = batches[i & 1]
     for p in hip.parameters():
         p.grad = None
     q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
-    hexops.backward(hexops.td_loss(q, bt["sel"], bt["tgt"])[0])
+    hexops.backward(hexops.td_loss(q, bt["sel"], bt["tgt"], bt.get("w"))[0])
 
 
 def _cpu_model():

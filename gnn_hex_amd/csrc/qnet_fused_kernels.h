@@ -317,9 +317,14 @@ __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ wha
             constexpr int c = decltype(cc)::value;
             static_for<0, 4>([&](auto jj) {
                 constexpr int j = decltype(jj)::value;
+                // the order inside a group is pinned (a scheduling barrier behind every MFMA): the NT accumulators rotate in
+                // tile order, so two MFMAs on one accumulator are exactly NT >= 3 slots apart, also across group boundaries
+                // (left to itself hipcc permutes a group, and the same tile can close one group and open the next)
 #pragma unroll
-                for (int t = 0; t < NT; ++t) acc[t] = mfma16x16x4(w[t][j], x[c][j], acc[t]);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int t = 0; t < NT; ++t) {
+                    acc[t] = mfma16x16x4(w[t][j], x[c][j], acc[t]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 if constexpr (NT < 3) mfma_drain();
                 keep_alive(x[c][j]);
 #pragma unroll

@@ -323,6 +323,24 @@ constexpr int kEll = 16;          // neighbour slots handled inside the self hal
 // behind one (chunk, tile) group of four MFMAs; a burst of loads instead would hold the wave -- and with it its MFMAs -- in
 // the CU's 64 B/clk vector-memory issue path), neighbour k lands in buffer k % kWin and is added kD gaps after its last
 // load, before the first load of neighbour k + kWin in the same buffer.  Gaps past the last MFMA group run behind the loop.
+// MFMA order of a K-half (NT >= 3): the NT*NT units (chunk c, tile t) of four dependent MFMAs each are issued in GROUPS of
+// three units round robin -- u0.j0 u1.j0 u2.j0 u0.j1 ... u2.j3 -- so that two MFMAs on the same accumulator are always at
+// least three slots (>= 96 cycles of matrix-pipe time) apart, more than the instruction's 40-cycle dependent latency (the
+// last group takes the NT*NT mod 3 = 1 leftover unit as a fourth member; across group boundaries the distance is >= 3 too:
+// units three apart never share a tile for NT > 3, and for NT = 3 the same tile returns exactly three slots later).  A
+// unit's four MFMAs issued back to back (the earlier order) each waited 8 cycles inside the pipe for their srcC, and an MFMA
+// that waits there reads srcC late: when hipcc let its accumulator move (vdst != srcC) and handed the dead srcC registers to
+// the next load, nothing interlocked the load's return against the pending read (the width-24 bug of
+// the fused kernels; tools/scan_mfma_war.py).  With every dependent pair >= 3 slots apart an MFMA's srcC is complete when
+// it issues.  Per accumulator the k order is unchanged (same fmaf chains, same bits).  Three weight fragments are live (four
+// in the last group) instead of one; a gap (filler slot) follows every four MFMAs, NT*NT gaps per half as before.
+template <int NT> struct MfmaSeq {
+    static constexpr int U = NT * NT;
+    static constexpr int kGroups = U / 3;                      // NT >= 3
+    static constexpr int group_size(int g) { return g + 1 < kGroups ? 3 : U - 3 * (kGroups - 1); }   // 3, or 4 at the end
+    static constexpr int kGaps = U;
+};
+
 template <int NT> struct GatherSched {
     static constexpr int W = kEll;
     static constexpr int G = NT * NT;
@@ -431,21 +449,55 @@ __device__ __forceinline__ void sage_layer_body(
     f32x4 acc[NT];
 #pragma unroll
     for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    static_for_<0, NT>([&](auto cc) {
-        constexpr int c = decltype(cc)::value;
-        static_for_<0, NT>([&](auto tt) {
-            constexpr int t = decltype(tt)::value;
-            const f32x4 b = wlds[((NT + c) * NT + t) * 64 + lane];
-            acc[t] = mfma16x16x4(b[0], xs[c][0], acc[t]);
-            acc[t] = mfma16x16x4(b[1], xs[c][1], acc[t]);
-            acc[t] = mfma16x16x4(b[2], xs[c][2], acc[t]);
-            acc[t] = mfma16x16x4(b[3], xs[c][3], acc[t]);
-            __builtin_amdgcn_sched_barrier(0);
-            filler(std::integral_constant<int, c * NT + t>{});
-            __builtin_amdgcn_sched_barrier(0);
+    // one K-half in the round-robin group order (MfmaSeq); `base` = first fragment of the half in LDS, `rows` = its row operand
+    auto contract_rr = [&](const f32x4* __restrict__ base, const f32x4 (&rows)[NT], auto&& fill) {
+        using MS = MfmaSeq<NT>;
+        f32x4 fr[4];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) fr[i] = base[i * 64 + lane];
+        static_for_<0, MS::kGroups>([&](auto gg) {
+            constexpr int gi = decltype(gg)::value, n = MS::group_size(gi), u0 = 3 * gi;
+            // the fourth member of the LAST group uses a register set of its own: requested a whole group ahead
+            if constexpr (gi + 2 == MS::kGroups && MS::group_size(gi + 1) == 4) fr[3] = base[(u0 + 6) * 64 + lane];
+            if constexpr (MS::kGroups == 1 && n == 4) fr[3] = base[3 * 64 + lane];
+            static_for_<0, 4 * n>([&](auto pp) {
+                constexpr int pos = decltype(pp)::value, j = pos / n, i = pos % n, u = u0 + i, c = u / NT, t = u % NT;
+                constexpr int sl = 4 * u0 + pos;                    // slot index within the half
+                acc[t] = mfma16x16x4(fr[i][j], rows[c][j], acc[t]);
+                // behind a unit's last MFMA its fragment registers take the same member of the next group (an MFMA reads its
+                // operands at issue); that member's first MFMA is n slots away, with a gap in between
+                if constexpr (j == 3 && gi + 1 < MS::kGroups && i < 3) fr[i] = base[(u0 + 3 + i) * 64 + lane];
+                __builtin_amdgcn_sched_barrier(0);
+                if constexpr (sl % 4 == 3) {
+                    fill(std::integral_constant<int, sl / 4>{});
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            });
         });
-    });
-    static_for_<NT * NT, GS::kGaps>([&](auto qq) { filler(qq); });     // (narrow layers: the schedule outlasts the MFMA groups)
+    };
+    if constexpr (NT >= 3) {
+        contract_rr(wlds + NT * NT * 64, xs, filler);
+        static_for_<MfmaSeq<NT>::kGaps, GS::kGaps>([&](auto qq) { filler(qq); });
+    } else {
+        // one or two tiles: too few accumulators to stagger; the dependent chain is waited out before anything is issued
+        // behind a unit (the fused kernels' mfma_drain, 2 x 40 cycles per link)
+        static_for_<0, NT>([&](auto cc) {
+            constexpr int c = decltype(cc)::value;
+            static_for_<0, NT>([&](auto tt) {
+                constexpr int t = decltype(tt)::value;
+                const f32x4 b = wlds[((NT + c) * NT + t) * 64 + lane];
+                acc[t] = mfma16x16x4(b[0], xs[c][0], acc[t]);
+                acc[t] = mfma16x16x4(b[1], xs[c][1], acc[t]);
+                acc[t] = mfma16x16x4(b[2], xs[c][2], acc[t]);
+                acc[t] = mfma16x16x4(b[3], xs[c][3], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+                filler(std::integral_constant<int, c * NT + t>{});
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        });
+        static_for_<NT * NT, GS::kGaps>([&](auto qq) { filler(qq); });     // (narrow layers: the schedule outlasts the MFMA groups)
+    }
     LSTAMP(K, 2);
     f32x4 ym[BWD ? NT : 1];
     if constexpr (BWD) {               // the mask rows land under the aggregate half
@@ -478,15 +530,21 @@ __device__ __forceinline__ void sage_layer_body(
             }
         }
     }
+    if constexpr (NT >= 3) {
+        contract_rr(wlds, ag, [](auto) {});
+    } else {
 #pragma unroll
-    for (int c = 0; c < NT; ++c) {
+        for (int c = 0; c < NT; ++c) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const f32x4 b = wlds[(c * NT + t) * 64 + lane];
-            acc[t] = mfma16x16x4(b[0], ag[c][0], acc[t]);
-            acc[t] = mfma16x16x4(b[1], ag[c][1], acc[t]);
-            acc[t] = mfma16x16x4(b[2], ag[c][2], acc[t]);
-            acc[t] = mfma16x16x4(b[3], ag[c][3], acc[t]);
+            for (int t = 0; t < NT; ++t) {
+                const f32x4 b = wlds[(c * NT + t) * 64 + lane];
+                acc[t] = mfma16x16x4(b[0], ag[c][0], acc[t]);
+                acc[t] = mfma16x16x4(b[1], ag[c][1], acc[t]);
+                acc[t] = mfma16x16x4(b[2], ag[c][2], acc[t]);
+                acc[t] = mfma16x16x4(b[3], ag[c][3], acc[t]);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+            }
         }
     }
     // epilogue.  Operands are swapped (a = packed W^T fragment, b = the row fragment), so the MFMA computes the

@@ -115,6 +115,74 @@ def test_flat_bucket_all_reduce_world2_gloo():
     assert sorted(res) == [(0, True), (1, True)]
 
 
+def _worker8(rank, world, port, q):
+    """The N = 8 leg (BASELINE config 4: 1024 envs sharded 8 ways) on CPU: one flat bucket through gloo with the same-set
+    check on, a strong-scaling partition of a ragged 256-graph batch known identically to every rank, and a rank that
+    trains the other side caught by the check."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gnn_hex_amd.dist import GradSync, balance_by_edges, shard_range
+    from gnn_hex_amd.models import get_pre_defined
+    torch.manual_seed(0)
+    model = get_pre_defined("modern_two_headed", model_args(3, 8))
+    sync = GradSync(model.parameters(), check=True)
+    active = [p for k, p in model.named_parameters() if not k.startswith("breaker_head")]
+    flat = torch.full((sum(p.numel() for p in active),), float(rank + 1))
+    for p, v in zip(active, torch._C._nn.unflatten_dense_tensors(flat, active)):
+        p.grad = v
+    n = sync.all_reduce()
+    ok = n == flat.numel() and torch.allclose(flat, torch.full_like(flat, (world + 1) / 2.0))
+    # strong scaling of ONE ragged batch: every rank computes the same partition and owns a disjoint part; loss weights
+    # k_r * world / B make the average of the per-rank means the global mean
+    sizes = [5 + (g % 9) for g in range(256)]
+    edges = [2 * (2 * s + (s - 2) * (s - 1) + s * (s - 1) + (s - 1) ** 2) for s in sizes]
+    parts = balance_by_edges(edges, world)
+    mine = parts[rank]
+    cnt = torch.tensor([float(len(mine)), float(sum(edges[i] for i in mine)), float(sum(mine))])
+    gathered = [torch.zeros(3) for _ in range(world)]
+    dist.all_gather(gathered, cnt)
+    tot = torch.stack(gathered).sum(0)
+    ok = ok and int(tot[0]) == 256 and int(tot[1]) == sum(edges) and int(tot[2]) == sum(range(256))
+    loads = torch.stack(gathered)[:, 1]
+    ok = ok and float(loads.max() - loads.min()) <= max(edges)
+    w = len(mine) * world / 256.0                    # this rank's loss weight
+    contrib = torch.tensor([w * 1.0])                # a per-rank mean of 1 -> global mean must be 1
+    dist.all_reduce(contrib)
+    ok = ok and abs(float(contrib) / world - 1.0) < 1e-6
+    ok = ok and shard_range(1024, rank, world) == (128 * rank, 128 * (rank + 1))
+    # rank 5 trains the other side: every rank must raise instead of reducing
+    for p in model.parameters():
+        p.grad = None
+    skip = "maker_head" if rank == 5 else "breaker_head"
+    for k, p in model.named_parameters():
+        if not k.startswith(skip):
+            p.grad = torch.ones(p.shape)
+    try:
+        sync.all_reduce()
+        ok = False
+    except RuntimeError as exc:
+        ok = ok and "different parameter sets" in str(exc)
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_eight_rank_gloo_rehearsal():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, 8, port, q)) for r in range(8)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(res) == [(r, True) for r in range(8)]
+
+
 def test_shard_range_and_edge_balance():
     from gnn_hex_amd.dist import balance_by_edges, shard_range
     assert [shard_range(1024, r, 8) for r in range(8)] == [(128 * r, 128 * (r + 1)) for r in range(8)]

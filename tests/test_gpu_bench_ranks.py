@@ -50,3 +50,24 @@ def test_bench_four_ranks_gloo_rehearsal():
     assert out["n_gpus"] == 4 and out["config"]["global_batch"] == 1024 and out["config"]["parallelism"] == "dp4"
     assert out["replicas_identical"] is True and out["scaling"] == "weak"
     assert abs(out["value"] - 1024 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.parametrize("config", ["S256", "MIX"])
+def test_bench_two_ranks_strong_scaling(config):
+    """`--scaling strong`: ONE global 256-graph batch per step split over the ranks by edge count (ragged MIX: the two
+    parts differ in graph count but not, beyond one graph, in edges), loss weights that make the averaged gradient the
+    global mean, value = 256 graphs per step time, the same-set check on the first step, identical replicas."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", config,
+           "--data", "D1", "--steps", "4", "--warmup", "1", "--preheat-ms", "10", "--sustain-s", "0", "--no-cpu-baseline",
+           "--no-split", "--scaling", "strong"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 256
+    assert 100 <= out["config"]["graphs_per_gpu"] <= 156
+    assert out["replicas_identical"] is True
+    assert abs(out["value"] - 256 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]

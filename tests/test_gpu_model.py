@@ -538,8 +538,11 @@ def test_td_loss_one_launch_form_is_bit_identical(loss_fn):
             loss.backward()
         torch.cuda.synchronize()
         outs.append((loss.detach().clone(), td.clone(), qh.grad.clone()))
-    for a, b in zip(outs[0], outs[1]):
-        assert torch.equal(a, b)
+    for name, a, b in zip(("loss", "td", "grad"), outs[0], outs[1]):
+        if not torch.equal(a, b):
+            bad = torch.nonzero((a != b).reshape(-1)).reshape(-1)[:8].tolist()
+            cnt = [(i, int((sel == i).sum())) for i in bad] if name == "grad" else bad
+            raise AssertionError("%s differs at %s: %s vs %s" % (name, cnt, a.reshape(-1)[bad].tolist(), b.reshape(-1)[bad].tolist()))
     # a scaled loss is not the root of the pass: ops.backward must fall through to autograd
     qh = q0.clone().cuda().requires_grad_(True)
     loss, _ = ops.td_loss(qh, sel.cuda(), tgt.cuda(), w.cuda(), loss_fn)

@@ -35,9 +35,34 @@ for ln in open(asm):
         if not mm: continue
         vd, vc = rng(mm.group(1)), rng(mm.group(2))
         if vd != vc and not (d[1] < vc[0] or d[0] > vc[1]):
-            hits.setdefault(cur, []).append((back + 1, prev, t))
+            # how many MFMAs earlier was this srcC produced?  (the MFMA waits inside the matrix pipe -- and reads srcC late,
+            # the only way the load can overtake it -- only when its producer is closer than the dependent latency:
+            # 40 cycles for v_mfma_f32_16x16x4_f32 at 32 cycles per issue, i.e. a distance of 1 or 2 slots)
+            idx = len(lines) - 2 - back
+            dist, k = None, 0
+            for pp in reversed(lines[:idx]):
+                m2 = re.match(r"v_mfma_\S+\s+(v\[\d+:\d+\]),", pp)
+                if m2:
+                    k += 1
+                    pd = rng(m2.group(1))
+                    if not (pd[1] < vc[0] or pd[0] > vc[1]):
+                        dist = k
+                        break
+                elif re.match(r"\S+\s+(v\[\d+:\d+\]|v\d+),", pp):
+                    wd = rng(re.match(r"\S+\s+(v\[\d+:\d+\]|v\d+),", pp).group(1))
+                    if wd and not (wd[1] < vc[0] or wd[0] > vc[1]):
+                        dist = 99           # srcC written by a non-MFMA instruction (initialisation / move): complete at issue
+                        break
+                if k > 12: break
+            hits.setdefault(cur, []).append((back + 1, prev, t, dist if dist is not None else 99))
+tot_close = 0
 for k, v in hits.items():
-    short = re.sub(r"^_ZN6hexgnn15", "", k)[:40]
-    print("%s: %d load(s) onto a moved accumulator's srcC within %d instructions; nearest %d" % (short, len(v), win, min(x[0] for x in v)))
-    print("    e.g.", v[0][1], " ...  ", v[0][2])
+    short = re.sub(r"^_ZN6hexgnn\d+", "", k)[:44]
+    close = [x for x in v if x[3] <= 2]
+    tot_close += len(close)
+    print("%s: %d load(s) onto a moved accumulator's srcC within %d instructions (nearest %d); %d of them behind an MFMA whose "
+          "srcC was produced <= 2 MFMA slots earlier" % (short, len(v), win, min(x[0] for x in v), len(close)))
+    ex = close[0] if close else v[0]
+    print("    e.g.", ex[1], " ...  ", ex[2], " (producer %s slots back)" % ex[3])
 if not hits: print("no such pattern within %d instructions" % win)
+print("TOTAL sites with a dependent distance <= 2 slots:", tot_close)
