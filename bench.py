@@ -291,12 +291,15 @@ def main():
             if world > 1:
                 sync.all_reduce()
 
-    init_group()
+    with _stdout_to_stderr():
+        init_group()
     # the first step of every run verifies with one tiny collective that all ranks reduce the SAME parameter set (same side to
     # move): ranks that disagree would otherwise hang or mix the two heads' gradients (GradSync check)
     sync.check = world > 1
     if world > 1:
-        step(0)
+        with _stdout_to_stderr():          # (the communicator is created lazily by the first collective)
+            step(0)
+            torch.cuda.synchronize()
         sync.check = False
 
     def barrier():
@@ -554,6 +557,23 @@ def selfplay(args, num_layers, hidden, label, dev):
     return out
 
 
+class _stdout_to_stderr:
+    """RCCL prints its version banner on STDOUT when a communicator is created: route file descriptor 1 to stderr for the
+    duration, so that rank 0's stdout carries the ONE JSON line and nothing else."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def collective_probe(dev, nbytes, reps=50):
     """N = 1 only: what ONE all-reduce of the step's gradient bucket costs on this GPU through the exact call the N-rank
     path makes (a 1-rank RCCL group, in-place SUM on a flat fp32 buffer of the bucket's size): launch + kernel latency of the
@@ -565,12 +585,14 @@ def collective_probe(dev, nbytes, reps=50):
         port = s.getsockname()[1]
         s.close()
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        with _stdout_to_stderr():
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
         try:
             flat = torch.zeros(max(nbytes // 4, 1), dtype=torch.float32, device=dev)
-            for _ in range(5):
-                dist.all_reduce(flat)
-            torch.cuda.synchronize()
+            with _stdout_to_stderr():
+                for _ in range(5):
+                    dist.all_reduce(flat)
+                torch.cuda.synchronize()
             t0 = time.perf_counter()
             for _ in range(reps):
                 dist.all_reduce(flat)

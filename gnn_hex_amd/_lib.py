@@ -58,6 +58,8 @@ _SIGS = {
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),
     "hexgnn_qnet_backward_staged": (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp,
                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, ci, vp]),
+    "hexgnn_qnet_backward_flat": (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp,
+                                       vp, vp, vp, vp, vp, sz, vp, ci, ci, ci, vp]),
     "hexgnn_env_create": (ci, [ci, ci, vp]),
     "hexgnn_env_destroy": (None, [vp]),
     "hexgnn_env_num_vertices": (ci, [vp]),

@@ -414,10 +414,11 @@ __global__ __launch_bounds__(256) void td_loss_fwd_kernel(int n, int k, const fl
 
 // One launch: every workgroup clears its 1024-entry range of dq, then accumulates the selected nodes that fall into it
 // (the zeroing memset used to be a launch of its own).  Bit-reproducible with duplicated selections (PER samples with
-// replacement): an LDS counter per node of the range says how many list entries name it (integer atomics: order-free).
-// A node named once or twice is accumulated with a float atomic into the zeroed word -- 0 + a (+ b) is the same bits in
-// either order, floating-point addition being commutative; only three or more addends depend on the order -- and a node
-// named three times or more (rare outside tiny batches) is summed in list order by its first entry and stored once.
+// replacement): an LDS counter per node of the range says how many entries of the current 1024-entry chunk name it (integer
+// atomics: order-free).  A node named once in the chunk gets one add (chunks are barrier-separated, so its adds arrive in
+// chunk order); a node named twice or more is summed in list order by its first entry and added once.  (Until round 3 two
+// entries went through two float atomics: order-free only onto a ZERO word, i.e. wrong from the second chunk on -- lists
+// above 1024 entries were not bit-reproducible; found by the 2300-entry test of the one-launch form.)
 __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const int64_t* __restrict__ sel,
                                                          const float* __restrict__ td, const float* __restrict__ w,
                                                          int loss_fn, const float* __restrict__ gloss,
@@ -446,7 +447,7 @@ __global__ __launch_bounds__(256) void td_loss_bwd_kernel(int n, int k, const in
         for (int j = threadIdx.x; j < kk; j += 256) {
             const int i = s_i[j];
             if (i < 0) continue;                       // not in this workgroup's range (most entries)
-            if (s_cnt[i - lo] <= 2) { atomicAdd(dq + i, s_g[j]); continue; }
+            if (s_cnt[i - lo] == 1) { atomicAdd(dq + i, s_g[j]); continue; }
             // three or more: is an earlier entry naming the same node? sum of the later ones, in list order
             bool first = true;
             float acc = s_g[j];
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(256) void td_loss_fused_kernel(int n, int k, const 
         for (int j = threadIdx.x; j < kk; j += 256) {
             const int i = s_i[j];
             if (i < 0) continue;
-            if (s_cnt[i - lo] <= 2) { atomicAdd(dq + i, s_g[j]); continue; }
+            if (s_cnt[i - lo] == 1) { atomicAdd(dq + i, s_g[j]); continue; }
             bool first = true;
             float acc = s_g[j];
             for (int q4 = 0; q4 < (kk + 3) / 4; ++q4) {

@@ -357,6 +357,27 @@ int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, i
                                        1, total_layers, stream_);
 }
 
+int hexgnn_qnet_backward_flat(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+                              const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                              const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                              const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
+                              const float* d_out_v, float* d_embeds, float* flat, const int64_t* offsets,
+                              void* workspace, size_t workspace_bytes, int* status, int stages, int layer_lo,
+                              int layer_hi, hexgnn_stream_t stream_) {
+    if (!flat || !offsets || total_layers < 1 || total_layers > kMaxLayers) return HEXGNN_EINVAL;
+    float* d_wl[kMaxLayers]; float* d_bl[kMaxLayers]; float* d_wr[kMaxLayers];
+    for (int l = 0; l < total_layers; ++l) {
+        d_wl[l] = flat + offsets[3 * l]; d_bl[l] = flat + offsets[3 * l + 1]; d_wr[l] = flat + offsets[3 * l + 2];
+    }
+    const int64_t* t = offsets + 3 * total_layers;      // lin_w, lin_b, v0_w, v0_b, v1_w, v1_b
+    const bool vh = mode != 2;
+    return hexgnn_qnet_backward_staged(n, b, c_in, hidden, total_layers, body_layers, mode, math, gptr, rowptr_t, col_t,
+                                       invdeg, x, x_stride, acts, saved, wpack, lin_w, v0_w, v1_w, dq, d_out_v, d_embeds,
+                                       d_wl, d_bl, d_wr, flat + t[0], flat + t[1], vh ? flat + t[2] : nullptr,
+                                       vh ? flat + t[3] : nullptr, vh ? flat + t[4] : nullptr, vh ? flat + t[5] : nullptr,
+                                       workspace, workspace_bytes, status, stages, layer_lo, layer_hi, stream_);
+}
+
 #ifdef HEXGNN_STAMPS
 // profiling builds only: copies the s_memtime stamps of the exact-fp32 fused kernels to `out` (host pointer)
 int hexgnn_debug_stamps(unsigned long long* out, int capacity) {

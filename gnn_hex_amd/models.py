@@ -408,6 +408,20 @@ class DuellingTwoHeaded(torch.nn.Module):
         self.final_conv_acts = None
         self.final_conv_grad = None
 
+    # final_conv_acts (GN0/models.py:553): the body's output.  The direct fused path stores the call record and builds the
+    # [n, hidden] view only when somebody reads the attribute (two view ops per step that Grad-CAM alone looks at).
+    @property
+    def final_conv_acts(self):
+        v = self.__dict__.get("_fca")
+        if isinstance(v, ops._QNetCall):
+            v = ops.qnet_embeds(v)
+            self.__dict__["_fca"] = v
+        return v
+
+    @final_conv_acts.setter
+    def final_conv_acts(self, value):
+        self.__dict__["_fca"] = value
+
     def grow_depth(self, additional_layers):
         self.gnn.grow_depth(additional_layers)
 
@@ -459,10 +473,14 @@ class DuellingTwoHeaded(torch.nn.Module):
             and max_nodes is not None and max_nodes <= 2048
         if grouped and ptr is not None and ptr.dtype == torch.int64 and ptr.is_cuda and ptr.is_contiguous():
             b = int(ptr.numel()) - 1            # the build reads the int64 ptr itself and emits the int32 copy
-            gptr = torch.empty(b + 1, dtype=torch.int32, device=x.device)
-            gs = ops.GraphStructure(edge_index, n, gptr, b, ptr64=ptr) if b > 0 else ops.GraphStructure(edge_index, n)
-            if b == 0:
-                gptr.zero_()
+            if b > 0 and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous() \
+                    and edge_index.is_cuda:
+                gs, gptr = ops.GraphStructure.grouped(edge_index, n, b, ptr)      # one allocation for all index arrays
+            else:
+                gptr = torch.empty(b + 1, dtype=torch.int32, device=x.device)
+                gs = ops.GraphStructure(edge_index, n, gptr, b, ptr64=ptr) if b > 0 else ops.GraphStructure(edge_index, n)
+                if b == 0:
+                    gptr.zero_()
         else:
             gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
             if gs is None or gs.n != n:
@@ -477,9 +495,38 @@ class DuellingTwoHeaded(torch.nn.Module):
         if max_nodes is not None and ops.qnet_fused_supported(self.gnn.in_channels, h, max_nodes) \
                 and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels and self.gnn.norms is None:
             params = self._fused_params(head)
-            if isinstance(head.linear, FactorizedNoisyLinear):      # effective weights are formed per forward
+            noisy = isinstance(head.linear, FactorizedNoisyLinear)
+            grad_on = torch.is_grad_enabled()
+            if ops._DIRECT_GRADS and not noisy:
+                # direct-gradient form (ops.QNetDirectFn): cached pointer arrays, one autograd input, gradients assigned to
+                # p.grad by the backward itself -- the eager step of an unmodified train.py
+                cache = self._fused_cache[id(head)][2]
+                if not cache.valid():
+                    cache.refresh()
+                if cache.direct_ok or not grad_on:
+                    fargs = (cache, x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs), len(head.gnn.convs),
+                             mode, grad_on)
+                    if grad_on:
+                        anchor = self.__dict__.get("_hex_anchor")
+                        if anchor is None or anchor.device != x.device:
+                            anchor = torch.zeros(1, device=x.device, requires_grad=True)
+                            self.__dict__["_hex_anchor"] = anchor
+                        holder = []
+                        outs = ops.QNetDirectFn.apply(anchor, holder, fargs)
+                        call = holder[0]
+                        call.sink = self.activations_hook
+                        q, out_v = outs if mode == 1 else (outs, None)
+                    else:
+                        q, out_v, call = ops.qnet_direct_forward(*fargs)
+                    self.__dict__["_fca"] = call
+                    if mode == 2:
+                        return q.view(-1, 1)
+                    if mode == 1:
+                        return out_v, q
+                    return q
+            if noisy:      # effective weights are formed per forward
                 params = params[:-6] + list(head._lin_params()) + params[-4:]
-            sink = self.activations_hook if torch.is_grad_enabled() else None
+            sink = self.activations_hook if grad_on else None
             outs = ops.QNetFusedFn.apply(x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs),
                                          len(head.gnn.convs), mode, sink, *params)
             self.final_conv_acts = outs[-1]
@@ -522,7 +569,10 @@ class DuellingTwoHeaded(torch.nn.Module):
             vh = head.value_head
             params += list(head._lin_params()) + [vh.layers[0].weight, vh.layers[0].bias,
                                                    vh.layers[1].weight, vh.layers[1].bias]
-            ent = (sig, params)
+            qcache = None
+            if not isinstance(head.linear, FactorizedNoisyLinear):
+                qcache = ops.QNetParamCache(params, len(self.gnn.convs) + len(head.gnn.convs))
+            ent = (sig, params, qcache)
             cache[key] = ent
         return ent[1]
 

@@ -140,6 +140,29 @@ class GraphStructure:
                                       _stream()), "hexgnn_csr_build")
 
     @classmethod
+    def grouped(cls, edge_index: torch.Tensor, num_nodes: int, b: int, ptr64: torch.Tensor):
+        """The one-launch build for a collated batch (edges grouped by graph, int64 ``ptr`` on the device) with ONE int32
+        allocation [rowptr | rowptr_t | col | col_t | gptr] + one for 1/deg instead of six: the eager hot path (a
+        ``torch.empty`` costs ~2.5 us of host time).  Returns ``(gs, gptr)``."""
+        self = cls.__new__(cls)
+        dev = edge_index.device
+        n, e = int(num_nodes), int(edge_index.shape[1])
+        self.n, self.e = n, e
+        e1 = max(e, 1)
+        ibuf = torch.empty(2 * (n + 1) + 2 * e1 + b + 1, dtype=torch.int32, device=dev)
+        o1, o2, o3, o4 = n + 1, 2 * (n + 1), 2 * (n + 1) + e1, 2 * (n + 1) + 2 * e1
+        self.rowptr, self.rowptr_t, self.col, self.col_t = ibuf[:o1], ibuf[o1:o2], ibuf[o2:o3], ibuf[o3:o4]
+        gptr = ibuf[o4:]
+        self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
+        self.status = sticky_status(dev)
+        base = ibuf.data_ptr()
+        src = edge_index.data_ptr()
+        _lib.check(_lib.lib().hexgnn_csr_build_grouped(
+            n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,
+            base + 4 * o3, self.invdeg.data_ptr(), self.status.data_ptr(), _stream()), "hexgnn_csr_build_grouped")
+        return self, gptr
+
+    @classmethod
     def from_csr(cls, n: int, e: int, rowptr, col, invdeg, rowptr_t=None, col_t=None) -> "GraphStructure":
         """Adopt an existing sorted CSR (the env builder emits one).  Without a transpose the graph is taken to be
         symmetric (board graphs are), i.e. its own transpose."""
@@ -647,6 +670,172 @@ class QNetFusedFn(torch.autograd.Function):
         return (None,) * 10 + tuple(cg) + tuple(tg)
 
 
+# ------------------------------------------------------------------------------------------------
+# direct-gradient form of the fused path: the eager step an unmodified train.py issues
+# ------------------------------------------------------------------------------------------------
+# QNetFusedFn hands 57 parameter tensors to autograd and receives 57 gradients back: ~0.45 ms of Python + autograd per step
+# (pointer arrays rebuilt, 66 AccumulateGrad nodes, six allocations), which left GNN-S host-bound at 0.8 M graphs/s against
+# 2 M replayed.  Here the parameters are NOT autograd inputs: the function has ONE differentiable input (a per-model
+# anchor), the forward call uses pointer arrays cached per (model, head) -- re-validated by data_ptr every call, 57 C-level
+# calls -- and the backward writes every gradient into ONE flat buffer (``hexgnn_qnet_backward_flat``: base pointer + cached
+# offset table) and assigns the views to ``p.grad`` itself (accumulating when a gradient is already there, like
+# AccumulateGrad).  Same kernels, same bits.  Not usable with ``torch.autograd.grad(loss, parameters)`` or tensor hooks on
+# parameters (the model falls back to QNetFusedFn when it finds hooks, frozen or non-leaf parameters);
+# ``set_direct_grads(False)`` switches it off.
+_DIRECT_GRADS = True
+
+
+def set_direct_grads(enabled: bool) -> None:
+    global _DIRECT_GRADS
+    _DIRECT_GRADS = bool(enabled)
+
+
+class QNetParamCache:
+    """Per (model, head): the parameter list of the fused call, its cached pointer arrays and the flat gradient layout."""
+    __slots__ = ("params", "ptrs", "wl", "bl", "wr", "tail", "flat_params", "offsets", "total", "direct_ok", "tot",
+                 "pack_bytes")
+
+    def __init__(self, params, tot):
+        self.params = params
+        self.tot = tot
+        self.ptrs = None
+        self.refresh()
+
+    def refresh(self):
+        params, tot = self.params, self.tot
+        self.ptrs = list(map(torch.Tensor.data_ptr, params))
+        vp = C.c_void_p * tot
+        pt = self.ptrs
+        self.wl, self.bl, self.wr = vp(*pt[0:3 * tot:3]), vp(*pt[1:3 * tot:3]), vp(*pt[2:3 * tot:3])
+        self.tail = tuple(pt[3 * tot:])
+        nconv = 3 * tot
+        order = list(range(nconv)) + [nconv + 2, nconv + 3, nconv + 4, nconv + 5, nconv + 0, nconv + 1]   # parameters() order
+        offs, o = [0] * len(params), 0
+        for i in order:
+            offs[i] = o
+            o += params[i].numel()
+        self.flat_params = [params[i] for i in order]
+        self.offsets = (C.c_int64 * len(params))(*offs)
+        self.total = o
+        self.direct_ok = all(p.is_leaf and p.requires_grad and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda
+                             and not p._backward_hooks for p in params)
+
+    def valid(self) -> bool:
+        """Pointers unchanged (parameters updated in place keep them; ``.to()`` / ``p.data = ...`` do not) and the flags
+        ``direct_ok`` was derived from still hold (a parameter frozen or given a tensor hook since)."""
+        ps = self.params
+        return list(map(torch.Tensor.data_ptr, ps)) == self.ptrs and \
+            self.direct_ok == all(p.requires_grad and not p._backward_hooks for p in ps)
+
+
+class _QNetCall:
+    """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "acts", "status")
+
+
+def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
+                        head_layers: int, mode: int, need_bwd: bool):
+    """Launch the fused forward with cached pointer arrays; returns (q, out_v, call) -- ``call`` feeds QNetDirectFn."""
+    L = _lib.lib()
+    dev = x.device
+    n = int(x.shape[0])
+    hp = padded_width(hidden)
+    tot = body_layers + head_layers
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        x = x.float().contiguous()
+    x_stride = x.stride(0) if n > 0 else c_in
+    # [acts | wpack | saved] in ONE allocation (256-byte aligned parts)
+    a_bytes = (4 * tot * n * hp + 255) & ~255
+    w_bytes = (L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot) + 255) & ~255
+    s_bytes = L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot)
+    buf = torch.empty(a_bytes + w_bytes + max(s_bytes, 16), dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    q = torch.empty(n, dtype=torch.float32, device=dev)
+    out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+    t = cache.tail
+    _lib.check(L.hexgnn_qnet_forward(
+        n, b, c_in, hidden, tot, mode, gptr.data_ptr(), gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
+        x.data_ptr(), x_stride, cache.wl, cache.bl, cache.wr, t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base,
+        base + a_bytes + w_bytes, int(need_bwd), body_layers - 1, _MATH, q.data_ptr(),
+        out_v.data_ptr() if out_v is not None else None, gs.status.data_ptr(), _stream()), "hexgnn_qnet_forward")
+    call = _QNetCall()
+    call.cache, call.gs, call.gptr, call.x = cache, gs, gptr, x
+    call.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes)
+    call.bufs, call.math, call.status = buf, _MATH, gs.status
+    call.sink = None
+    return q, out_v, call
+
+
+def qnet_embeds(call: _QNetCall) -> torch.Tensor:
+    """final_conv_acts of a direct forward: the body output as a [n, hidden] view of the activation slab."""
+    n, b, c_in, hidden, tot, body_layers, mode, hp = call.dims[:8]
+    acts = call.bufs[:4 * tot * n * hp].view(torch.float32).view(tot, n, hp)
+    return acts[body_layers - 1][:, :hidden]
+
+
+class QNetDirectFn(torch.autograd.Function):
+    """Autograd node of a direct forward: ONE differentiable input (the per-model anchor, whose gradient is never produced);
+    ``fargs`` = the arguments of ``qnet_direct_forward``, ``holder`` = a list that receives the call record.  The backward
+    runs the fused backward kernels and assigns the parameter gradients (see the section comment)."""
+
+    @staticmethod
+    def forward(ctx, anchor, holder, fargs):
+        ctx.set_materialize_grads(False)
+        q, out_v, call = qnet_direct_forward(*fargs)
+        ctx.call = call
+        holder.append(call)
+        if out_v is None:
+            return q
+        return q, out_v
+
+    @staticmethod
+    def backward(ctx, dq, d_v=None):
+        L = _lib.lib()
+        call = ctx.call
+        cache = call.cache
+        n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes = call.dims
+        dev = call.x.device
+        if mode == 1:
+            d_v = torch.zeros(b, dtype=torch.float32, device=dev) if d_v is None else d_v.float().contiguous()
+        else:
+            d_v = None
+        dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
+            (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
+        flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
+        ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if call.sink is not None else None
+        base = call.bufs.data_ptr()
+        gs, t = call.gs, cache.tail
+        common = (n, b, c_in, hidden, tot, body_layers, mode, call.math, call.gptr.data_ptr(), gs.rowptr_t.data_ptr(),
+                  gs.col_t.data_ptr(), gs.invdeg.data_ptr(), call.x.data_ptr(), x_stride, base, base + a_bytes + w_bytes,
+                  base + a_bytes, t[0], t[2], t[4], dq.data_ptr(), d_v.data_ptr() if d_v is not None else None,
+                  d_emb.data_ptr() if d_emb is not None else None, flat.data_ptr(), cache.offsets, ws.data_ptr(), ws_bytes,
+                  call.status.data_ptr())
+        hook = _GRAD_STAGE_HOOK
+        if hook is None or tot < 3 or mode == 2:
+            _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, 1, tot, _stream()), "hexgnn_qnet_backward_flat")
+        else:
+            mid = 1 + tot // 2
+            cut = int(cache.offsets[3 * mid])
+            _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, mid, tot, _stream()), "hexgnn_qnet_backward_flat")
+            hook(flat, cut, cache.total)
+            _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
+            hook(flat, 0, cut)
+        fp = cache.flat_params
+        views = torch._C._nn.unflatten_dense_tensors(flat, fp)
+        nskip = 4 if mode == 2 else 0          # advantages only: the value head (flat positions -6 .. -3) has no gradient
+        k_lo, k_hi = len(fp) - 6, len(fp) - 2
+        for k, (p, v) in enumerate(zip(fp, views)):
+            if nskip and k_lo <= k < k_hi:
+                continue
+            g = p.grad
+            p.grad = v if g is None else g + v
+        if call.sink is not None:
+            call.sink(d_emb[:, :hidden])
+        return None, None, None
+
+
 _UNIT_GRAD = False      # set by backward(): the loss itself is the root of the backward pass, i.e. grad_loss == 1
 _ONES = {}
 
@@ -663,13 +852,19 @@ class TdLossFn(torch.autograd.Function):
         L = _lib.lib()
         ctx.set_materialize_grads(False)
         dev = q.device
-        qf = q.reshape(-1)
+        qf = q if q.dim() == 1 else q.reshape(-1)
         if qf.dtype != torch.float32 or not qf.is_contiguous():
             qf = qf.float().contiguous()
-        sel = sel.to(device=dev, dtype=torch.long).contiguous()
-        tgt = target.to(device=dev, dtype=torch.float32).contiguous()
-        w = None if weights is None else weights.to(device=dev, dtype=torch.float32).contiguous()
-        k, n = int(sel.numel()), int(qf.numel())
+        # (.to() costs ~2 us even when nothing changes: the usual case -- device tensors of the right type -- skips it)
+        if sel.dtype != torch.long or sel.device != dev or not sel.is_contiguous():
+            sel = sel.to(device=dev, dtype=torch.long).contiguous()
+        tgt = target
+        if tgt.dtype != torch.float32 or tgt.device != dev or not tgt.is_contiguous():
+            tgt = tgt.to(device=dev, dtype=torch.float32).contiguous()
+        w = weights
+        if w is not None and (w.dtype != torch.float32 or w.device != dev or not w.is_contiguous()):
+            w = w.to(device=dev, dtype=torch.float32).contiguous()
+        k, n = sel.numel(), qf.numel()
         if tgt.numel() != k or (w is not None and w.numel() != k):
             raise ValueError("sel / target / weights must have the same length")
         loss = torch.empty((), dtype=torch.float32, device=dev)

@@ -232,6 +232,20 @@ int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_la
                                 void* workspace, size_t workspace_bytes, int* status,
                                 int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream);
 
+/* The staged call with ALL parameter gradients in ONE flat fp32 buffer (the layout the single RCCL all-reduce uses):
+ * gradient k lives at flat + offsets[k], offsets = HOST array of 3 * total_layers + 6 element offsets in the order
+ * (d_wl[l], d_bl[l], d_wr[l]) for l = 0 .. total_layers-1, then d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b.  One base
+ * pointer + a table the host caches per model instead of 3 * total_layers + 6 pointers rebuilt per step (the eager path
+ * of the Python mirror: GN0/models.py:537-584 driven by `loss.backward()`). */
+int hexgnn_qnet_backward_flat(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+                              const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                              const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                              const float* lin_w, const float* v0_w, const float* v1_w,
+                              const float* dq, const float* d_out_v, float* d_embeds,
+                              float* flat, const int64_t* offsets /* HOST */,
+                              void* workspace, size_t workspace_bytes, int* status,
+                              int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream);
+
 /* ---- batched board-graph builder: num_envs lock-stepped Hex / Shannon node-switching games on the device.
  *      Replaces Hex_game / Node_switching_game (graph_game/graph_tools_games.py:20-29,
  *      graph_game/shannon_node_switching_game.py:80-205, graph_game/hex_board_game.py:214-233) as driven by

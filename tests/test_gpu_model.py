@@ -554,6 +554,76 @@ def test_td_loss_one_launch_form_is_bit_identical(loss_fn):
     assert torch.equal(l2, outs[0][0]) and torch.equal(td2, outs[0][1])
 
 
+def test_direct_gradient_form_matches_the_autograd_form():
+    """The eager fast path (ops.QNetDirectFn: parameters are not autograd inputs, the backward assigns p.grad itself) against
+    the autograd form (ops.QNetFusedFn: 57 inputs / 57 returned gradients): Q and every gradient bit-identical, for all three
+    output modes; gradients ACCUMULATE when the caller did not clear them (a second backward, retain_graph); a frozen
+    parameter or a tensor hook on a parameter sends the model back to the autograd form."""
+    from gnn_hex_amd import ops
+    if not ops._FUSED_ENABLED:
+        pytest.skip("a test of the fused path")
+    hip, _ = make_pair(4, 35, seed=71)
+    x, ei, batch, ptr = batch_tensors("D1", [7, 6, 7, 5, 7], maker=True)
+    sel, tgt = sel_and_targets(ptr)
+    xd, eid = x.cuda(), ei.cuda()
+    ops.attach_hints(xd, True, int((ptr[1:] - ptr[:-1]).max()))
+    eid._hex_grouped = True
+    bv, pt, sd, td = batch.cuda(), ptr.cuda(), sel.cuda(), tgt.cuda()
+
+    def run(**kw):
+        hip.zero_grad(set_to_none=True)
+        out = hip(xd, eid, bv, pt, **kw)
+        if kw.get("seperate"):
+            loss = (out[0] ** 2).mean() + torch.nn.functional.mse_loss(out[1][sd], td)
+        else:
+            loss = torch.nn.functional.mse_loss(out.reshape(-1)[sd], td)
+        loss.backward()
+        outs = out if isinstance(out, tuple) else (out,)
+        return [o.detach().clone() for o in outs], {k: (None if p.grad is None else p.grad.clone()) for k, p in hip.named_parameters()}
+
+    for kw in ({}, {"seperate": True}, {"advantages_only": True}):
+        ops.set_direct_grads(True)
+        o1, g1 = run(**kw)
+        assert isinstance(hip.__dict__["_fca"], ops._QNetCall)             # the direct path ran
+        ops.set_direct_grads(False)
+        try:
+            o2, g2 = run(**kw)
+        finally:
+            ops.set_direct_grads(True)
+        for a, b_ in zip(o1, o2):
+            assert torch.equal(a, b_)
+        for k in g1:
+            assert (g1[k] is None) == (g2[k] is None), (kw, k)
+            if g1[k] is not None:
+                assert torch.equal(g1[k], g2[k]), (kw, k)
+    # final_conv_acts / final_conv_grads on the direct path
+    _, g = run()
+    assert hip.final_conv_acts.shape == (x.shape[0], 35) and hip.final_conv_grads.shape == (x.shape[0], 35)
+    # accumulation: backward twice through one graph without clearing -> twice the gradient
+    hip.zero_grad(set_to_none=True)
+    q = hip(xd, eid, bv, pt)
+    loss = torch.nn.functional.mse_loss(q[sd], td)
+    loss.backward(retain_graph=True)
+    loss.backward()
+    for k, p in hip.named_parameters():
+        if g[k] is not None:
+            assert torch.allclose(p.grad, 2 * g[k], rtol=1e-6, atol=1e-9), k
+    # a frozen parameter: the autograd form takes over and leaves that parameter without a gradient
+    hip.gnn.convs[1].lin_l.weight.requires_grad_(False)
+    try:
+        _, gf = run()
+        assert not isinstance(hip.__dict__.get("_fca"), ops._QNetCall)
+        assert gf["gnn.convs.1.lin_l.weight"] is None
+        assert torch.equal(gf["gnn.convs.0.lin_l.weight"], g["gnn.convs.0.lin_l.weight"])
+    finally:
+        hip.gnn.convs[1].lin_l.weight.requires_grad_(True)
+        hip.__dict__.pop("_fused_cache", None)
+    # inference under no_grad: direct forward without an autograd node
+    with torch.no_grad():
+        qn = hip(xd, eid, bv, pt)
+    assert torch.equal(qn, q.detach()) and not qn.requires_grad
+
+
 def test_randomised_configurations():
     """Seeded sweep over widths, depths, batch shapes, edge densities, directed / symmetric graphs, both CSR builds and both
     arithmetic modes of the fused kernels against the oracle (1e-4 on Q, 1e-4 relative to max(1, |g|max) on gradients)."""

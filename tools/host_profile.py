@@ -35,7 +35,7 @@ def main():
             p.grad = None
         q = hip(xd, eid, bvd, ptrd)
         loss, _ = ops.td_loss(q, seld, tgtd)
-        loss.backward()
+        ops.backward(loss)
 
     for _ in range(30):
         step()
