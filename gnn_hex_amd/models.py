@@ -475,7 +475,8 @@ class DuellingTwoHeaded(torch.nn.Module):
             b = int(ptr.numel()) - 1            # the build reads the int64 ptr itself and emits the int32 copy
             if b > 0 and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous() \
                     and edge_index.is_cuda:
-                gs, gptr = ops.GraphStructure.grouped(edge_index, n, b, ptr)      # one allocation for all index arrays
+                gs = ops.GraphStructure.grouped(edge_index, n, b, ptr)      # one allocation for all index arrays
+                gptr = None                                                 # (gs.gptr: a view made on demand)
             else:
                 gptr = torch.empty(b + 1, dtype=torch.int32, device=x.device)
                 gs = ops.GraphStructure(edge_index, n, gptr, b, ptr64=ptr) if b > 0 else ops.GraphStructure(edge_index, n)
@@ -485,27 +486,27 @@ class DuellingTwoHeaded(torch.nn.Module):
             gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
             if gs is None or gs.n != n:
                 gs = ops.GraphStructure(edge_index, n, gptr, b) if grouped else ops.GraphStructure(edge_index, n)
-        head = self.maker_head if is_maker else self.breaker_head
+        mods = self._modules
+        head = mods["maker_head"] if is_maker else mods["breaker_head"]
         mode = 2 if advantages_only else (1 if seperate else 0)
 
         # fused per-graph path (one launch per direction) when every graph fits a workgroup's LDS
         if max_nodes is None and ops._FUSED_ENABLED:
+            if gptr is None:
+                gptr = gs.gptr
             max_nodes = int((gptr[1:] - gptr[:-1]).max()) if b > 0 else 0     # host sync (no size hint given)
-        h = self.gnn.hidden_channels
-        if max_nodes is not None and ops.qnet_fused_supported(self.gnn.in_channels, h, max_nodes) \
-                and head.gnn.hidden_channels == h and x2.shape[1] == self.gnn.in_channels and self.gnn.norms is None:
-            params = self._fused_params(head)
-            noisy = isinstance(head.linear, FactorizedNoisyLinear)
+        ent = self._fused_entry(head)         # (sig, params, pointer cache, (c_in, hidden, body layers, head layers, fusable, noisy))
+        c_in, h, n_body, n_head, fusable, noisy = ent[3]
+        if fusable and max_nodes is not None and ops.qnet_fused_supported(c_in, h, max_nodes) and x2.shape[1] == c_in:
             grad_on = torch.is_grad_enabled()
             if ops._DIRECT_GRADS and not noisy:
                 # direct-gradient form (ops.QNetDirectFn): cached pointer arrays, one autograd input, gradients assigned to
                 # p.grad by the backward itself -- the eager step of an unmodified train.py
-                cache = self._fused_cache[id(head)][2]
+                cache = ent[2]
                 if not cache.valid():
                     cache.refresh()
                 if cache.direct_ok or not grad_on:
-                    fargs = (cache, x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs), len(head.gnn.convs),
-                             mode, grad_on)
+                    fargs = (cache, x2, gs, gptr, b, c_in, h, n_body, n_head, mode, grad_on)
                     if grad_on:
                         anchor = self.__dict__.get("_hex_anchor")
                         if anchor is None or anchor.device != x.device:
@@ -524,11 +525,13 @@ class DuellingTwoHeaded(torch.nn.Module):
                     if mode == 1:
                         return out_v, q
                     return q
+            params = ent[1]
             if noisy:      # effective weights are formed per forward
                 params = params[:-6] + list(head._lin_params()) + params[-4:]
             sink = self.activations_hook if grad_on else None
-            outs = ops.QNetFusedFn.apply(x2, gs, gptr, b, self.gnn.in_channels, h, len(self.gnn.convs),
-                                         len(head.gnn.convs), mode, sink, *params)
+            if gptr is None:
+                gptr = gs.gptr
+            outs = ops.QNetFusedFn.apply(x2, gs, gptr, b, c_in, h, n_body, n_head, mode, sink, *params)
             self.final_conv_acts = outs[-1]
             if mode == 2:
                 return outs[0].view(-1, 1)
@@ -536,6 +539,8 @@ class DuellingTwoHeaded(torch.nn.Module):
                 return outs[0].squeeze(), outs[1].squeeze()
             return outs[0].squeeze()
 
+        if gptr is None:
+            gptr = gs.gptr
         # general layer-major path (any graph size, hidden <= 128)
         embeds = self.gnn(x2, edge_index, set_cache=set_cache, _graph=gs)
         if self.after_embed_norm is not None:
@@ -553,15 +558,22 @@ class DuellingTwoHeaded(torch.nn.Module):
             return v.squeeze(), a.squeeze()
         return head._tail(hx, gptr, b, 0).squeeze()
 
-    def _fused_params(self, head):
-        """Parameter list of the fused call (body convs, head convs, head tail), cached per head; rebuilt when the
-        module tree changes (grow_*, parameter replacement by ``.to()`` / ``load_state_dict(assign=True)``)."""
+    def _fused_entry(self, head):
+        """Per head: the parameter list of the fused call (body convs, head convs, head tail), its pointer cache and the
+        shape constants; rebuilt when the module tree changes (grow_*, parameter replacement by ``.to()`` /
+        ``load_state_dict(assign=True)``).  The signature is read through the modules' own dictionaries: a chain of
+        ``nn.Module.__getattr__`` calls cost 17 us per forward here."""
         cache = self.__dict__.setdefault("_fused_cache", {})
         key = id(head)
         ent = cache.get(key)
-        lin0 = head.linear.weight_mu if isinstance(head.linear, FactorizedNoisyLinear) else head.linear.weight
-        sig = (len(self.gnn.convs), len(head.gnn.convs), id(self.gnn.convs[0].lin_l.weight),
-               id(lin0), id(self.gnn.convs[-1].lin_r.weight))
+        gnn = self._modules["gnn"]
+        convs = gnn._modules["convs"]._modules
+        hconvs = head._modules["gnn"]._modules["convs"]._modules
+        lin = head._modules["linear"]
+        lin0 = lin._parameters.get("weight_mu") if "weight_mu" in lin._parameters else lin._parameters.get("weight")
+        first = convs["0"]._modules["lin_l"]._parameters["weight"]
+        last = hconvs[str(len(hconvs) - 1)]._modules["lin_r"]._parameters["weight"] if len(hconvs) else first
+        sig = (len(convs), len(hconvs), id(first), id(lin0), id(last), gnn.hidden_channels, gnn.norms is None)
         if ent is None or ent[0] != sig:
             params = []
             for conv in list(self.gnn.convs) + list(head.gnn.convs):
@@ -569,12 +581,17 @@ class DuellingTwoHeaded(torch.nn.Module):
             vh = head.value_head
             params += list(head._lin_params()) + [vh.layers[0].weight, vh.layers[0].bias,
                                                    vh.layers[1].weight, vh.layers[1].bias]
-            qcache = None
-            if not isinstance(head.linear, FactorizedNoisyLinear):
-                qcache = ops.QNetParamCache(params, len(self.gnn.convs) + len(head.gnn.convs))
-            ent = (sig, params, qcache)
+            noisy = isinstance(head.linear, FactorizedNoisyLinear)
+            n_body, n_head = len(self.gnn.convs), len(head.gnn.convs)
+            qcache = None if noisy else ops.QNetParamCache(params, n_body + n_head)
+            h = self.gnn.hidden_channels
+            fusable = head.gnn.hidden_channels == h and self.gnn.norms is None and head.gnn.norms is None
+            ent = (sig, params, qcache, (self.gnn.in_channels, h, n_body, n_head, fusable, noisy))
             cache[key] = ent
-        return ent[1]
+        return ent
+
+    def _fused_params(self, head):
+        return self._fused_entry(head)[1]
 
     def _apply(self, fn, *args, **kwargs):
         self.__dict__.pop("_fused_cache", None)

@@ -89,7 +89,7 @@ class GraphStructure:
     Replaces the per-layer x[edge_index[0]] / scatter(edge_index[1]) indexing of the reference
     (GN0/models.py:276)."""
 
-    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status")
+    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status", "_ptrs")
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, gptr: Optional[torch.Tensor] = None, b: int = 0,
                  ptr64: Optional[torch.Tensor] = None):
@@ -107,6 +107,7 @@ class GraphStructure:
         n, e = int(num_nodes), int(edge_index.shape[1])
         L = _lib.lib()
         self.n, self.e = n, e
+        self._ptrs = None
         if gptr is not None and b > 0:
             ibuf = torch.empty(2 * (n + 1), dtype=torch.int32, device=dev)
             self.rowptr, self.rowptr_t = ibuf[:n + 1], ibuf[n + 1:2 * (n + 1)]
@@ -142,25 +143,28 @@ class GraphStructure:
     @classmethod
     def grouped(cls, edge_index: torch.Tensor, num_nodes: int, b: int, ptr64: torch.Tensor):
         """The one-launch build for a collated batch (edges grouped by graph, int64 ``ptr`` on the device) with ONE int32
-        allocation [rowptr | rowptr_t | col | col_t | gptr] + one for 1/deg instead of six: the eager hot path (a
-        ``torch.empty`` costs ~2.5 us of host time).  Returns ``(gs, gptr)``."""
-        self = cls.__new__(cls)
+        allocation [rowptr | rowptr_t | col | col_t | gptr] + one for 1/deg instead of six, and the raw pointers kept in
+        ``_ptrs`` = (rowptr, col, rowptr_t, col_t, invdeg, gptr, status) so that the fused calls need no ``data_ptr()``: the
+        eager hot path (a ``torch.empty`` costs ~2.5 us of host time, a slice ~1 us).  Returns ``(gs, gptr)``."""
+        self = _GroupedStructure.__new__(_GroupedStructure)
         dev = edge_index.device
         n, e = int(num_nodes), int(edge_index.shape[1])
         self.n, self.e = n, e
-        e1 = max(e, 1)
-        ibuf = torch.empty(2 * (n + 1) + 2 * e1 + b + 1, dtype=torch.int32, device=dev)
-        o1, o2, o3, o4 = n + 1, 2 * (n + 1), 2 * (n + 1) + e1, 2 * (n + 1) + 2 * e1
-        self.rowptr, self.rowptr_t, self.col, self.col_t = ibuf[:o1], ibuf[o1:o2], ibuf[o2:o3], ibuf[o3:o4]
-        gptr = ibuf[o4:]
-        self.invdeg = torch.empty(max(n, 1), dtype=torch.float32, device=dev)
-        self.status = sticky_status(dev)
+        e1 = e if e > 0 else 1
+        o1, o2 = n + 1, 2 * (n + 1)
+        o3, o4 = o2 + e1, o2 + 2 * e1
+        ibuf = torch.empty(o4 + b + 1, dtype=torch.int32, device=dev)
+        invdeg = torch.empty(n if n > 0 else 1, dtype=torch.float32, device=dev)
+        status = sticky_status(dev)
         base = ibuf.data_ptr()
         src = edge_index.data_ptr()
+        self._ibuf, self._offs = ibuf, (o1, o2, o3, o4)
+        self.invdeg, self.status = invdeg, status
+        self._ptrs = (base, base + 4 * o2, base + 4 * o1, base + 4 * o3, invdeg.data_ptr(), base + 4 * o4, status.data_ptr())
         _lib.check(_lib.lib().hexgnn_csr_build_grouped(
             n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,
-            base + 4 * o3, self.invdeg.data_ptr(), self.status.data_ptr(), _stream()), "hexgnn_csr_build_grouped")
-        return self, gptr
+            base + 4 * o3, self._ptrs[4], self._ptrs[6], _stream()), "hexgnn_csr_build_grouped")
+        return self
 
     @classmethod
     def from_csr(cls, n: int, e: int, rowptr, col, invdeg, rowptr_t=None, col_t=None) -> "GraphStructure":
@@ -172,6 +176,7 @@ class GraphStructure:
         self.rowptr_t = rowptr if rowptr_t is None else rowptr_t
         self.col_t = col if col_t is None else col_t
         self.status = sticky_status(rowptr.device)
+        self._ptrs = None
         return self
 
     def check(self) -> None:
@@ -186,6 +191,31 @@ class GraphStructure:
                              "not), 8 = graph above 2048 nodes in the grouped build.  This batch has n = %d; the word is shared "
                              "by every batch of this device since the last check(), so the error may stem from an EARLIER "
                              "batch (it is cleared now)" % (code, self.n))
+
+
+class _GroupedStructure(GraphStructure):
+    """GraphStructure.grouped(): the index arrays are views of ONE buffer, made when somebody asks for them."""
+    __slots__ = ("_ibuf", "_offs")
+
+    @property
+    def rowptr(self):
+        return self._ibuf[:self._offs[0]]
+
+    @property
+    def rowptr_t(self):
+        return self._ibuf[self._offs[0]:self._offs[1]]
+
+    @property
+    def col(self):
+        return self._ibuf[self._offs[1]:self._offs[2]]
+
+    @property
+    def col_t(self):
+        return self._ibuf[self._offs[2]:self._offs[3]]
+
+    @property
+    def gptr(self):
+        return self._ibuf[self._offs[3]:]
 
 
 def graph_ptr(graph_indices: Optional[torch.Tensor], ptr: Optional[torch.Tensor], n: int, device):
@@ -548,8 +578,19 @@ def set_grad_stage_hook(fn) -> None:
     _GRAD_STAGE_HOOK = fn
 
 
+_SUPPORTED = {}
+
+
 def qnet_fused_supported(c_in: int, hidden: int, max_nodes: int) -> bool:
-    return _FUSED_ENABLED and bool(_lib.lib().hexgnn_qnet_supported(int(c_in), int(hidden), int(max_nodes)))
+    if not _FUSED_ENABLED:
+        return False
+    key = (c_in, hidden, max_nodes)
+    ok = _SUPPORTED.get(key)
+    if ok is None:
+        if len(_SUPPORTED) > 4096:
+            _SUPPORTED.clear()
+        ok = _SUPPORTED[key] = bool(_lib.lib().hexgnn_qnet_supported(int(c_in), int(hidden), int(max_nodes)))
+    return ok
 
 
 class QNetFusedFn(torch.autograd.Function):
@@ -693,12 +734,13 @@ def set_direct_grads(enabled: bool) -> None:
 class QNetParamCache:
     """Per (model, head): the parameter list of the fused call, its cached pointer arrays and the flat gradient layout."""
     __slots__ = ("params", "ptrs", "wl", "bl", "wr", "tail", "flat_params", "offsets", "total", "direct_ok", "tot",
-                 "pack_bytes")
+                 "sizes", "cut")
 
     def __init__(self, params, tot):
         self.params = params
         self.tot = tot
         self.ptrs = None
+        self.sizes = {}          # (n, b) -> buffer sizes of the fused calls (three C queries per new batch shape)
         self.refresh()
 
     def refresh(self):
@@ -717,6 +759,7 @@ class QNetParamCache:
         self.flat_params = [params[i] for i in order]
         self.offsets = (C.c_int64 * len(params))(*offs)
         self.total = o
+        self.cut = offs[3 * (1 + tot // 2)] if tot >= 3 else 0      # flat position where the staged backward splits
         self.direct_ok = all(p.is_leaf and p.requires_grad and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda
                              and not p._backward_hooks for p in params)
 
@@ -730,38 +773,53 @@ class QNetParamCache:
 
 class _QNetCall:
     """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
-    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "acts", "status")
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp")
+
+
+_HP_CACHE = {}
 
 
 def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
                         head_layers: int, mode: int, need_bwd: bool):
-    """Launch the fused forward with cached pointer arrays; returns (q, out_v, call) -- ``call`` feeds QNetDirectFn."""
+    """Launch the fused forward with cached pointer arrays; returns (q, out_v, call) -- ``call`` feeds QNetDirectFn.
+    ``gptr`` may be None when ``gs`` comes from ``GraphStructure.grouped`` (it carries the pointer)."""
     L = _lib.lib()
     dev = x.device
-    n = int(x.shape[0])
-    hp = padded_width(hidden)
+    n = x.shape[0]
     tot = body_layers + head_layers
     if x.dtype != torch.float32 or x.stride(1) != 1:
         x = x.float().contiguous()
     x_stride = x.stride(0) if n > 0 else c_in
+    sizes = cache.sizes.get((n, b))
+    if sizes is None:
+        hp = padded_width(hidden)
+        a_bytes = (4 * tot * n * hp + 255) & ~255
+        w_bytes = (L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot) + 255) & ~255
+        s_bytes = L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot)
+        ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
+        if len(cache.sizes) > 64:
+            cache.sizes.clear()
+        sizes = cache.sizes[(n, b)] = (hp, a_bytes, w_bytes, max(s_bytes, 16), max(ws_bytes, 16))
+    hp, a_bytes, w_bytes, s_bytes, ws_bytes = sizes
     # [acts | wpack | saved] in ONE allocation (256-byte aligned parts)
-    a_bytes = (4 * tot * n * hp + 255) & ~255
-    w_bytes = (L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot) + 255) & ~255
-    s_bytes = L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot)
-    buf = torch.empty(a_bytes + w_bytes + max(s_bytes, 16), dtype=torch.uint8, device=dev)
+    buf = torch.empty(a_bytes + w_bytes + s_bytes, dtype=torch.uint8, device=dev)
     base = buf.data_ptr()
     q = torch.empty(n, dtype=torch.float32, device=dev)
     out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+    gp = gs._ptrs
+    if gp is None:
+        gp = (gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.invdeg.data_ptr(),
+              gptr.data_ptr(), gs.status.data_ptr())
     t = cache.tail
+    stream = _stream()
     _lib.check(L.hexgnn_qnet_forward(
-        n, b, c_in, hidden, tot, mode, gptr.data_ptr(), gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
-        x.data_ptr(), x_stride, cache.wl, cache.bl, cache.wr, t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base,
-        base + a_bytes + w_bytes, int(need_bwd), body_layers - 1, _MATH, q.data_ptr(),
-        out_v.data_ptr() if out_v is not None else None, gs.status.data_ptr(), _stream()), "hexgnn_qnet_forward")
+        n, b, c_in, hidden, tot, mode, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, cache.wl, cache.bl, cache.wr,
+        t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), body_layers - 1,
+        _MATH, q.data_ptr(), out_v.data_ptr() if out_v is not None else None, gp[6], stream), "hexgnn_qnet_forward")
     call = _QNetCall()
     call.cache, call.gs, call.gptr, call.x = cache, gs, gptr, x
-    call.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes)
-    call.bufs, call.math, call.status = buf, _MATH, gs.status
+    call.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes)
+    call.bufs, call.math, call.gp = buf, _MATH, gp
     call.sink = None
     return q, out_v, call
 
@@ -793,7 +851,7 @@ class QNetDirectFn(torch.autograd.Function):
         L = _lib.lib()
         call = ctx.call
         cache = call.cache
-        n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes = call.dims
+        n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes = call.dims
         dev = call.x.device
         if mode == 1:
             d_v = torch.zeros(b, dtype=torch.float32, device=dev) if d_v is None else d_v.float().contiguous()
@@ -802,22 +860,19 @@ class QNetDirectFn(torch.autograd.Function):
         dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
             (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
         flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
-        ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
-        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if call.sink is not None else None
         base = call.bufs.data_ptr()
-        gs, t = call.gs, cache.tail
-        common = (n, b, c_in, hidden, tot, body_layers, mode, call.math, call.gptr.data_ptr(), gs.rowptr_t.data_ptr(),
-                  gs.col_t.data_ptr(), gs.invdeg.data_ptr(), call.x.data_ptr(), x_stride, base, base + a_bytes + w_bytes,
-                  base + a_bytes, t[0], t[2], t[4], dq.data_ptr(), d_v.data_ptr() if d_v is not None else None,
-                  d_emb.data_ptr() if d_emb is not None else None, flat.data_ptr(), cache.offsets, ws.data_ptr(), ws_bytes,
-                  call.status.data_ptr())
+        gp, t = call.gp, cache.tail
+        common = (n, b, c_in, hidden, tot, body_layers, mode, call.math, gp[5], gp[2], gp[3], gp[4], call.x.data_ptr(),
+                  x_stride, base, base + a_bytes + w_bytes, base + a_bytes, t[0], t[2], t[4], dq.data_ptr(),
+                  d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
+                  flat.data_ptr(), cache.offsets, ws.data_ptr(), ws_bytes, gp[6])
         hook = _GRAD_STAGE_HOOK
         if hook is None or tot < 3 or mode == 2:
             _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, 1, tot, _stream()), "hexgnn_qnet_backward_flat")
         else:
-            mid = 1 + tot // 2
-            cut = int(cache.offsets[3 * mid])
+            mid, cut = 1 + tot // 2, cache.cut
             _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, mid, tot, _stream()), "hexgnn_qnet_backward_flat")
             hook(flat, cut, cache.total)
             _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
