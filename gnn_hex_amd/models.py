@@ -517,6 +517,8 @@ class DuellingTwoHeaded(torch.nn.Module):
                         call = holder[0]
                         call.sink = self.activations_hook
                         q, out_v = outs if mode == 1 else (outs, None)
+                        if mode == 0:
+                            q._hex_call = call          # lets ops.td_loss / ops.backward run this backward directly
                     else:
                         q, out_v, call = ops.qnet_direct_forward(*fargs)
                     self.__dict__["_fca"] = call

@@ -773,7 +773,7 @@ class QNetParamCache:
 
 class _QNetCall:
     """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
-    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp")
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done")
 
 
 _HP_CACHE = {}
@@ -821,6 +821,7 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     call.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes)
     call.bufs, call.math, call.gp = buf, _MATH, gp
     call.sink = None
+    call.done = False
     return q, out_v, call
 
 
@@ -848,49 +849,59 @@ class QNetDirectFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dq, d_v=None):
-        L = _lib.lib()
-        call = ctx.call
-        cache = call.cache
-        n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes = call.dims
-        dev = call.x.device
-        if mode == 1:
-            d_v = torch.zeros(b, dtype=torch.float32, device=dev) if d_v is None else d_v.float().contiguous()
-        else:
-            d_v = None
-        dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
-            (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
-        flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if call.sink is not None else None
-        base = call.bufs.data_ptr()
-        gp, t = call.gp, cache.tail
-        common = (n, b, c_in, hidden, tot, body_layers, mode, call.math, gp[5], gp[2], gp[3], gp[4], call.x.data_ptr(),
-                  x_stride, base, base + a_bytes + w_bytes, base + a_bytes, t[0], t[2], t[4], dq.data_ptr(),
-                  d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
-                  flat.data_ptr(), cache.offsets, ws.data_ptr(), ws_bytes, gp[6])
-        hook = _GRAD_STAGE_HOOK
-        if hook is None or tot < 3 or mode == 2:
-            _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, 1, tot, _stream()), "hexgnn_qnet_backward_flat")
-        else:
-            mid, cut = 1 + tot // 2, cache.cut
-            _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, mid, tot, _stream()), "hexgnn_qnet_backward_flat")
-            hook(flat, cut, cache.total)
-            _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
-            hook(flat, 0, cut)
-        fp = cache.flat_params
-        views = torch._C._nn.unflatten_dense_tensors(flat, fp)
-        nskip = 4 if mode == 2 else 0          # advantages only: the value head (flat positions -6 .. -3) has no gradient
-        k_lo, k_hi = len(fp) - 6, len(fp) - 2
-        for k, (p, v) in enumerate(zip(fp, views)):
-            if nskip and k_lo <= k < k_hi:
-                continue
-            g = p.grad
-            p.grad = v if g is None else g + v
-        if call.sink is not None:
-            call.sink(d_emb[:, :hidden])
+        qnet_direct_backward(ctx.call, dq, d_v)
         return None, None, None
 
 
+def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
+    """The fused backward of a direct forward: every parameter gradient into ONE flat buffer, views assigned to ``p.grad``
+    (accumulated when a gradient is already there).  Called by autograd (QNetDirectFn.backward, on the engine's device
+    thread) or straight from ``ops.backward(loss)`` on the caller's thread."""
+    if call.done:
+        raise RuntimeError("this forward's backward already ran through ops.backward(loss) (its graph is spent, as after "
+                           "loss.backward() without retain_graph)")
+    L = _lib.lib()
+    cache = call.cache
+    n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes = call.dims
+    dev = call.x.device
+    if mode == 1:
+        d_v = torch.zeros(b, dtype=torch.float32, device=dev) if d_v is None else d_v.float().contiguous()
+    else:
+        d_v = None
+    dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
+        (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
+    flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if call.sink is not None else None
+    base = call.bufs.data_ptr()
+    gp, t = call.gp, cache.tail
+    common = (n, b, c_in, hidden, tot, body_layers, mode, call.math, gp[5], gp[2], gp[3], gp[4], call.x.data_ptr(),
+              x_stride, base, base + a_bytes + w_bytes, base + a_bytes, t[0], t[2], t[4], dq.data_ptr(),
+              d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
+              flat.data_ptr(), cache.offsets, ws.data_ptr(), ws_bytes, gp[6])
+    hook = _GRAD_STAGE_HOOK
+    if hook is None or tot < 3 or mode == 2:
+        _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, 1, tot, _stream()), "hexgnn_qnet_backward_flat")
+    else:
+        mid, cut = 1 + tot // 2, cache.cut
+        _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, mid, tot, _stream()), "hexgnn_qnet_backward_flat")
+        hook(flat, cut, cache.total)
+        _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
+        hook(flat, 0, cut)
+    fp = cache.flat_params
+    views = torch._C._nn.unflatten_dense_tensors(flat, fp)
+    nskip = 4 if mode == 2 else 0          # advantages only: the value head (flat positions -6 .. -3) has no gradient
+    k_lo, k_hi = len(fp) - 6, len(fp) - 2
+    for k, (p, v) in enumerate(zip(fp, views)):
+        if nskip and k_lo <= k < k_hi:
+            continue
+        g = p.grad
+        p.grad = v if g is None else g + v
+    if call.sink is not None:
+        call.sink(d_emb[:, :hidden])
+
+
+_LAST_TD = [None]        # d loss / d q of the TdLossFn forward that just ran (picked up by td_loss())
 _UNIT_GRAD = False      # set by backward(): the loss itself is the root of the backward pass, i.e. grad_loss == 1
 _ONES = {}
 
@@ -937,6 +948,7 @@ class TdLossFn(torch.autograd.Function):
                                                 td.data_ptr(), _stream()), "hexgnn_td_loss_forward")
         ctx.save_for_backward(sel, td, w if w is not None else td)
         ctx.dq = dq
+        _LAST_TD[0] = dq
         ctx.has_w, ctx.loss_fn, ctx.shape = w is not None, loss_fn, q.shape
         ctx.mark_non_differentiable(td)
         return loss, td
@@ -968,8 +980,16 @@ def td_loss(q: torch.Tensor, sel: torch.Tensor, target: torch.Tensor, weights: O
     ``weights`` is None."""
     if q.device.type != "cuda":
         raise _lib.HexGnnError("td_loss runs only on the MI355X HIP path (no CPU fallback)")
+    _LAST_TD[0] = None
     out = TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])
-    out[0]._hex_td_root = True
+    loss = out[0]
+    loss._hex_td_root = True
+    call = getattr(q, "_hex_call", None)
+    if call is not None and _LAST_TD[0] is not None and q.dim() == 1 and q.dtype == torch.float32 and q.is_contiguous():
+        # q is the fused network's own output and d loss / d q exists already: ops.backward(loss) can run the network's
+        # backward directly on this thread (no autograd engine, no hop to its device thread and back: ~100 us of host time)
+        loss._hex_direct = (call, _LAST_TD[0])
+    _LAST_TD[0] = None
     return out
 
 
@@ -981,6 +1001,12 @@ def backward(loss: torch.Tensor) -> None:
     global _UNIT_GRAD
     if not getattr(loss, "_hex_td_root", False) or not loss.is_cuda:
         loss.backward()
+        return
+    direct = loss.__dict__.pop("_hex_direct", None) if _GRAD_STAGE_HOOK is None else None
+    if direct is not None and not direct[0].done:
+        call, dq = direct
+        qnet_direct_backward(call, dq, None)
+        call.done = True            # like autograd without retain_graph: a second backward through this forward is an error
         return
     key = (loss.device.type, loss.device.index)
     one = _ONES.get(key)

@@ -618,6 +618,26 @@ def test_direct_gradient_form_matches_the_autograd_form():
     finally:
         hip.gnn.convs[1].lin_l.weight.requires_grad_(True)
         hip.__dict__.pop("_fused_cache", None)
+    # ops.td_loss + ops.backward: the network's backward runs on the caller's thread, without the autograd engine; same bits
+    # as loss.backward() through autograd, and the spent graph refuses a second pass
+    outs = []
+    for direct in (False, True):
+        hip.zero_grad(set_to_none=True)
+        qq = hip(xd, eid, bv, pt)
+        loss, _ = ops.td_loss(qq, sd, td)
+        assert hasattr(loss, "_hex_direct")
+        if direct:
+            ops.backward(loss)
+            with pytest.raises(RuntimeError, match="spent"):
+                loss.backward()
+        else:
+            loss.backward()
+        outs.append({k: (None if p.grad is None else p.grad.clone()) for k, p in hip.named_parameters()})
+    for k in outs[0]:
+        assert (outs[0][k] is None) == (outs[1][k] is None), k
+        if outs[0][k] is not None:
+            assert torch.equal(outs[0][k], outs[1][k]), k
+    assert hip.final_conv_acts.shape == (x.shape[0], 35)
     # inference under no_grad: direct forward without an autograd node
     with torch.no_grad():
         qn = hip(xd, eid, bv, pt)
