@@ -217,6 +217,19 @@ class GraphSAGE(torch.nn.Module):
         return SAGEConv(in_channels, out_channels, **kwargs)
 
 
+def _widened_norm(norm, new_width: int, old_width: int, device):
+    """A norm of the same class at ``new_width`` whose first ``old_width`` affine parameters are the old ones (the rest keep
+    their initial values): what grow_width does to every norm (GN0/models.py:226-235, 499-508)."""
+    new_norm = norm.__class__(new_width).to(device)
+    new_norm.weight.data[:old_width] = norm.weight.data
+    new_norm.bias.data[:old_width] = norm.bias.data
+    if hasattr(norm, "mean_scale"):
+        new_norm.mean_scale.data[:old_width] = norm.mean_scale.data
+    if hasattr(norm, "eps"):
+        new_norm.eps = norm.eps
+    return new_norm
+
+
 def cachify_gnn(gnn):
     """GN0/models.py:144-295.  Only GraphSAGE is accelerated."""
     if gnn is not GraphSAGE:
@@ -248,8 +261,6 @@ def cachify_gnn(gnn):
         def grow_depth(self, additional_layers):
             """GN0/models.py:166-185: append identity layers (lin_l = 0, lin_r = I)."""
             assert not self.has_output
-            if self.norms is not None:
-                raise NotImplementedError("grow_depth with --norm=True")
             self.num_layers += additional_layers
             device = self.convs[0].lin_l.weight.device
             for _ in range(additional_layers):
@@ -258,13 +269,16 @@ def cachify_gnn(gnn):
                 conv.lin_l.bias.data[:] = 0
                 conv.lin_r.weight.data[:] = torch.eye(self.hidden_channels)
                 self.convs.append(conv)
+                if self.norms is not None:       # GN0/models.py:180-183: a fresh norm of the same class per new layer
+                    new_norm = self.norms[0].__class__(self.hidden_channels).to(device)
+                    if hasattr(new_norm, "mean_scale"):          # CachedGraphNorm: start without mean subtraction
+                        new_norm.mean_scale.data[:] = 0
+                    self.norms.append(new_norm)
             self.has_cache = False
 
         def grow_width(self, new_width, new_in_channels=None):
             """GN0/models.py:187-238: widen every layer, old weights in the top-left block, new input
             columns zero, new output rows freshly initialised."""
-            if self.norms is not None:
-                raise NotImplementedError("grow_width with --norm=True")
             device = self.convs[0].lin_l.weight.device
             old_convs = self.convs
             old_in_channels = self.in_channels
@@ -291,6 +305,11 @@ def cachify_gnn(gnn):
                     conv.lin_l.weight.data[:h, h:] = 0
                     conv.lin_r.weight.data[:h, h:] = 0
                 conv.lin_l.bias.data[:h] = old.lin_l.bias.data
+            if self.norms is not None:           # GN0/models.py:226-235: wider norms, old affine parameters in front
+                new_norms = ModuleList()
+                for i in range(self.num_layers):
+                    new_norms.append(_widened_norm(self.norms[i], new_width, h, device))
+                self.norms = new_norms
             self.has_cache = False
             self.hidden_channels = new_width
             self.out_channels = new_width
@@ -426,9 +445,14 @@ class DuellingTwoHeaded(torch.nn.Module):
         self.gnn.grow_depth(additional_layers)
 
     def grow_width(self, new_width):
+        """GN0/models.py:497-508."""
+        old_width = self.gnn.hidden_channels
         self.gnn.grow_width(new_width)
         self.maker_head.grow_width(new_width, new_in_channels=new_width)
         self.breaker_head.grow_width(new_width, new_in_channels=new_width)
+        if self.after_embed_norm is not None:
+            self.after_embed_norm = _widened_norm(self.after_embed_norm, new_width, old_width,
+                                                  self.after_embed_norm.weight.device)
 
     def export_norm_cache(self, *args):
         cache_list = []

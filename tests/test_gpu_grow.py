@@ -131,3 +131,46 @@ def test_checkpoint_of_a_grown_model_loads_and_runs(tmp_path):
     for k in g_a:
         assert (g_a[k] is None) == (g_b[k] is None) and (g_a[k] is None or torch.equal(g_a[k], g_b[k])), k
     _parity(fresh, _oracle_like(fresh, 4, 40), data)
+
+
+def test_grow_depth_and_width_with_norms():
+    """--grow together with --norm=True (GN0/models.py:180-183, 226-235, 499-508): grow_depth appends a fresh norm per new
+    layer, grow_width widens every norm (body, both heads, after_embed_norm) with the old affine parameters in front.  The
+    whole-batch LayerNorm's statistics change with the width, so the FUNCTION is not preserved (in the reference neither);
+    what must hold is parity with an oracle network built at the grown shape and loaded with the grown state dict."""
+    from argparse import Namespace
+    from gnn_hex_amd import ops
+    from gnn_hex_amd.models import get_pre_defined
+    from oracle.model_ref import get_pre_defined_ref
+    if ops._FUSED_ENABLED and ops.get_math() != "fp32":
+        pytest.skip("norm models run on the layer-major kernels whatever the switches say: once is enough")
+
+    def nargs(layers, hidden):
+        return Namespace(num_layers=layers, hidden_channels=hidden, norm=True, noisy_dqn=False, noisy_sigma0=0.5,
+                         num_head_layers=2)
+
+    torch.manual_seed(44)
+    hip = get_pre_defined("modern_two_headed", nargs(3, 24))
+    with torch.no_grad():
+        for k, p in hip.named_parameters():
+            if "norm" in k:
+                p.add_(torch.randn(p.shape) * 0.2)
+    hip = hip.cuda()
+
+    def oracle(layers, hidden):
+        ref = get_pre_defined_ref("modern_two_headed", nargs(layers, hidden))
+        missing = ref.load_state_dict({k: v.cpu() for k, v in hip.state_dict().items()})
+        assert not missing.missing_keys and not missing.unexpected_keys
+        return ref
+
+    data = _data([7, 5, 9, 6], True)
+    _parity(hip, oracle(3, 24), data)
+    hip.grow_depth(2)
+    assert len(hip.gnn.convs) == 5 and len(hip.gnn.norms) == 5
+    _parity(hip, oracle(5, 24), data)
+    old_w = hip.gnn.norms[1].weight.detach().clone()
+    hip.grow_width(40)
+    assert hip.gnn.norms[1].weight.shape == (40,) and torch.equal(hip.gnn.norms[1].weight[:24], old_w)
+    assert hip.after_embed_norm.weight.shape == (40,) and hip.maker_head.gnn.norms[0].weight.shape == (40,)
+    assert torch.all(hip.gnn.norms[1].weight[24:] == 1) and torch.all(hip.gnn.norms[1].bias[24:] == 0)
+    _parity(hip, oracle(5, 40), data)

@@ -30,8 +30,10 @@ NAMES = {0: "layer top", 1: "phase S done", 3: "before barrier 1", 4: "barrier 1
 
 def main():
     dev = torch.device("cuda", 0)
-    hip, _ = make_pair(15, 110, seed=0, device=dev)
-    x, ei, bv, ptr = batch_tensors("D0", [11] * 256, maker=True)
+    cfg = sys.argv[1] if len(sys.argv) > 1 else "L256"          # L256 (GNN-L Hex-11) or S256 (GNN-S Hex-7)
+    layers_, hidden_, size_ = (15, 110, 11) if cfg == "L256" else (10, 35, 7)
+    hip, _ = make_pair(layers_, hidden_, seed=0, device=dev)
+    x, ei, bv, ptr = batch_tensors("D0", [size_] * 256, maker=True)
     sel, tgt = sel_and_targets(ptr)
     xd, eid, bvd, ptrd, seld, tgtd = (t.to(dev) for t in (x, ei, bv, ptr, sel, tgt))
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
@@ -52,7 +54,7 @@ def main():
     rc = fn(buf.ctypes.data, total)
     assert rc == total, rc
     st = buf.reshape(2, KMAXL + 2, POINTS, 8).astype(np.float64)
-    L = 17
+    L = layers_ + 2
     for k, kname in enumerate(["qnet_fwd_kernel", "qnet_bwd_kernel"]):
         s = st[k]
         t0 = s[0, 0].min()
