@@ -413,9 +413,36 @@ __device__ __forceinline__ void gather_read(const char* base, unsigned off, f32x
 template <int MATH> __device__ __forceinline__ void load_guard() {
     if constexpr (MATH == 1) asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
 }
-template <int NT, int Q, int G, int MATH>
-__device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb, f32x4 (&ag)[NT], f32x4 (&tb)[NT]) {
+// Landing buffers of the gather: one at the wide widths (the kernels sit at the register ceiling there), three in rotation
+// at 33..64 columns with exact fp32 math, where registers are plentiful and a phase is short: neighbour k is read in gap k and
+// added in gap k + 2, two MFMA groups later.  (With one buffer and only 4 NT = 12 gaps for 32 micro-ops a neighbour's read and
+// its first add fell into the SAME gap: the LDS round trip was exposed eight times per layer -- phase S of GNN-S took 3.4 k
+// ticks against 1.7 k for phase A, tools/stamps.py S256.)  The sums keep their ascending neighbour order: same bits.
+template <int NT, int MATH> struct GatherLand {
+    static constexpr int value = (MATH == 0 && (NT == 3 || NT == 4)) ? 3 : 1;
+};
+template <int NT, int Q, int G, int MATH, int KL>
+__device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb, f32x4 (&ag)[NT], f32x4 (&tbs)[KL][NT]) {
     const char* base = reinterpret_cast<const char*>(rows);
+    if constexpr (KL == 3) {
+        static_assert(G >= 10, "eight reads + two gaps of distance");
+        if constexpr (Q >= 2 && Q < 10) {
+            constexpr int k = Q - 2;
+            if (k < nb.wmax) {       // wave-uniform
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ag[c] += tbs[k % 3][c];
+            }
+        }
+        if constexpr (Q < 8) {
+            constexpr int k = Q;
+            if (k < nb.wmax) {
+                const unsigned o = nb.off[k >> 1];
+                gather_read<NT>(base, (k & 1) ? (o >> 16) : (o & 0xffffu), tbs[k % 3]);
+            }
+        }
+        return;
+    }
+    f32x4 (&tb)[NT] = tbs[0];
     static_for<0, 32>([&](auto mm) {
         constexpr int m = decltype(mm)::value;
         // 28 gaps (width 97..112, the GNN-L case): shifted by 4/32 so that a neighbour's read and its first add never share
@@ -610,7 +637,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[t] = acc[t]; }
         float rs = 1.f, rinv = 1.f, mx = 0.f;
         const bool fastg = csr_lds && wactive;
-        f32x4 tb[NT];
+        f32x4 tb[GatherLand<NT, MATH>::value][NT];
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(xs, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
         const __amdgpu_buffer_rsrc_t yprev = slab_rsrc(a.acts + slab * (l - 1));
@@ -1095,7 +1122,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[t] = acc[t]; }
         float rs = 1.f, rinv = 1.f, mx = 0.f;
         const bool fastg = csr_lds && wactive;
-        f32x4 tb[NT];
+        f32x4 tb[GatherLand<NT, MATH>::value][NT];
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(gx, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
         const __amdgpu_buffer_rsrc_t gcur = slab_rsrc(a.G + slab * l);
