@@ -501,6 +501,19 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const bool rvalid = lrow < cnt;
     const bool wactive = wave * 16 < cnt;           // wave-uniform
     const int grow = r0 + lrow;
+    // values the prologue needs two or three barriers further down are requested NOW, with the CSR: every global round trip
+    // left on the chain gptr -> rowptr -> columns -> ... costs ~0.8 us at kernel start (GNN-S: 12.5 k ticks of prologue)
+    const float idg = rvalid ? a.invdeg[grow] : 0.f;                 // hidden layers: 1 / deg of this lane's row
+    const float sc0 = tid < cnt ? a.invdeg[r0 + tid] : 0.f;          // raw first layer: thread tid sums row tid
+    // (the first layer's bias row too, at the narrow widths: at 97..112 columns its 28 registers cost the layer loop's
+    // allocation 1.4 us, measured, and the bias is then read where it is used)
+    constexpr bool kBiasAhead = NT <= 4;
+    f32x4 b0v[kBiasAhead ? NT : 1];
+    if constexpr (kBiasAhead) {
+        const f32x4* b0 = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[0]);
+#pragma unroll
+        for (int t = 0; t < NT; ++t) b0v[t] = b0[4 * t + g];
+    }
     const int e0 = a.rowptr[r0], ne = a.rowptr[r1] - e0;
     const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
     float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
@@ -545,9 +558,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
                         for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] += xr[qq];
                     }
                 }
-                const float sc = a.invdeg[row];
 #pragma unroll
-                for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] *= sc;
+                for (int qq = 0; qq < kSmallCin; ++qq) ag0[qq] *= sc0;
                 if (a.need_backward) {
                     f32x4* ao = reinterpret_cast<f32x4*>(reinterpret_cast<float*>(a.saved + a.agg_off[0]) + (size_t)row * kSmallCin);
                     ao[0] = f32x4{ag0[0], ag0[1], ag0[2], ag0[3]};
@@ -563,13 +575,14 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     // ---- layer 0 (raw features): every lane produces its own row chunks, already in the chained layout ----
     f32x4 xs[NT];
     {
-        const float* b0 = reinterpret_cast<const float*>(a.wpack + a.bias_off[0]);
         float f[16];
 #pragma unroll
         for (int qq = 0; qq < 16; ++qq) f[qq] = s_f[lrow * 16 + qq];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            f32x4 v = reinterpret_cast<const f32x4*>(b0)[4 * t + g];
+            f32x4 v;
+            if constexpr (kBiasAhead) v = b0v[t];
+            else v = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[0])[4 * t + g];
 #pragma unroll
             for (int q4 = 0; q4 < 4; ++q4) {
                 const int o = 16 * t + 4 * g + q4;
@@ -598,7 +611,6 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     // ---- hidden layers ----
     const size_t slab = (size_t)a.n * HP;
     const float validf = rvalid ? 1.f : 0.f;
-    const float idg = rvalid ? a.invdeg[grow] : 0.f;
     QSTAMP(0, 0, 1);
     // Per layer two phases, each a K-half contraction that carries the layer's other work as fillers between its MFMAs:
     //   phase S: self half (W_r, half B) on the rows kept in registers; fillers = the LDS gather of the aggregate, the
@@ -897,6 +909,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         if (tid < H2) { z_t = a.z[(size_t)gi * H2 + tid]; v1w_t = a.v1_w[tid]; }
         if (tid < H) { ax_t = a.amax[(size_t)gi * H + tid]; an_t = a.amin[(size_t)gi * H + tid]; }
     }
+    const float idg = rvalid ? a.invdeg[grow] : 0.f;     // (used from the first layer on: requested with everything else)
     f32x4 ytop[NT];      // y rows of the top layer: operand of the advantage-linear gradient and of the first ReLU mask
     {
         const f32x4* yr = reinterpret_cast<const f32x4*>(a.acts + slab * (L - 1) + (size_t)grow * HP) + g;
@@ -1048,7 +1061,6 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     //   dL/dy_{l-1} = [ T(G_l / deg) | G_l ] [W_l ; W_r]   (T = gather over the transposed CSR; linear, so the gather is
     //   moved in front of the contraction): per layer  gather from LDS -> K-half over the W_l part -> barrier ->
     //   K-half over the W_r part with G_l from registers -> mask by y_{l-1} -> publish G_{l-1} (global + LDS) -> barrier.
-    const float idg = rvalid ? a.invdeg[grow] : 0.f;
     // gx = dL/dy_l, yv = this lane's y_l chunks  ->  G_l = gx * [y_l > 0]; (l >= 1) G_l / deg goes to this lane's LDS row
     // for the neighbours' gathers.  The y rows are loaded by the caller a whole layer ahead into iteration-local
     // registers (a loop-carried prefetch made hipcc wait for the load in place).  store_G() then writes G_l for the
