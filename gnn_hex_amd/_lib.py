@@ -36,6 +36,8 @@ _SIGS = {
     "hexgnn_sage_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "hexgnn_sage_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
                                         vp, vp, vp, vp, sz, ci, vp]),
+    "hexgnn_sage_stack_backward_tap": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
+                                            vp, vp, vp, vp, sz, ci, ci, vp, vp]),
     "hexgnn_sage_norm_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp,
                                             vp, vp, sz, ci, vp]),
     "hexgnn_sage_norm_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),

@@ -1259,6 +1259,17 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
                                const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
                                float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
                                hexgnn_stream_t stream_) {
+    return hexgnn_sage_stack_backward_tap(n, c_in, hidden, num_layers, rowptr, col, rowptr_t, col_t, invdeg, x, x_stride, acts,
+                                          saved, wpack, dy, dx, d_wl, d_bl, d_wr, workspace, workspace_bytes, flags, -1,
+                                          nullptr, stream_);
+}
+
+int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                   const int* rowptr_t, const int* col_t, const float* invdeg, const float* x,
+                                   int x_stride, const float* acts, const void* saved, const void* wpack,
+                                   const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
+                                   float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
+                                   int tap_layer, float* tap_out, hexgnn_stream_t stream_) {
     (void)rowptr; (void)col;
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
@@ -1301,10 +1312,18 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers, cons
         sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, dy, nullptr, relu_top ? acts + slab * (p.L - 1) : nullptr,
                                                    G + slab * (p.L - 1));
     }
+    if (tap_out && (tap_layer < 0 || tap_layer >= p.L - 1)) return HEXGNN_EINVAL;
     for (int l = p.L - 1; l >= first_hidden; --l) {
         float* out = l >= 1 ? G + slab * (l - 1) : dx;
         if (!out) break;                                   // l == 0 and nobody asked for the input gradient
         const float* ymask = l >= 1 ? acts + slab * (l - 1) : nullptr;
+        if (tap_out && l - 1 == tap_layer) {
+            // the gradient w.r.t. layer tap_layer's OUTPUT (before its ReLU mask) is wanted as well: unmasked launch into the
+            // tap, then the mask as its own step
+            HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], nullptr, tap_out, st)));
+            sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, tap_out, nullptr, ymask, out);
+            continue;
+        }
         HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st)));
     }
 

@@ -521,7 +521,11 @@ class DuellingTwoHeaded(torch.nn.Module):
             max_nodes = int((gptr[1:] - gptr[:-1]).max()) if b > 0 else 0     # host sync (no size hint given)
         ent = self._fused_entry(head)         # (sig, params, pointer cache, (c_in, hidden, body layers, head layers, fusable, noisy))
         c_in, h, n_body, n_head, fusable, noisy = ent[3]
-        if fusable and max_nodes is not None and ops.qnet_fused_supported(c_in, h, max_nodes) and x2.shape[1] == c_in:
+        fused = fusable and max_nodes is not None and ops.qnet_fused_supported(c_in, h, max_nodes) and x2.shape[1] == c_in
+        # graphs above 128 nodes / hidden 113..128: the same network on the layer-major kernels, as ONE stack + head tail
+        layered = (not fused) and fusable and not noisy and ops._DIRECT_GRADS and c_in <= 8 and c_in != h \
+            and x2.shape[1] == c_in and n_body >= 1
+        if fused or layered:
             grad_on = torch.is_grad_enabled()
             if ops._DIRECT_GRADS and not noisy:
                 # direct-gradient form (ops.QNetDirectFn): cached pointer arrays, one autograd input, gradients assigned to
@@ -530,7 +534,7 @@ class DuellingTwoHeaded(torch.nn.Module):
                 if not cache.valid():
                     cache.refresh()
                 if cache.direct_ok or not grad_on:
-                    fargs = (cache, x2, gs, gptr, b, c_in, h, n_body, n_head, mode, grad_on)
+                    fargs = (cache, x2, gs, gptr, b, c_in, h, n_body, n_head, mode, grad_on, layered)
                     if grad_on:
                         anchor = self.__dict__.get("_hex_anchor")
                         if anchor is None or anchor.device != x.device:
@@ -551,6 +555,10 @@ class DuellingTwoHeaded(torch.nn.Module):
                     if mode == 1:
                         return out_v, q
                     return q
+            if layered:
+                fused = False       # (frozen / hooked parameters: the per-module composition below)
+        if fused:
+            grad_on = torch.is_grad_enabled()
             params = ent[1]
             if noisy:      # effective weights are formed per forward
                 params = params[:-6] + list(head._lin_params()) + params[-4:]

@@ -773,16 +773,20 @@ class QNetParamCache:
 
 class _QNetCall:
     """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
-    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done")
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered")
 
 
 _HP_CACHE = {}
 
 
 def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
-                        head_layers: int, mode: int, need_bwd: bool):
+                        head_layers: int, mode: int, need_bwd: bool, layered: bool = False):
     """Launch the fused forward with cached pointer arrays; returns (q, out_v, call) -- ``call`` feeds QNetDirectFn.
-    ``gptr`` may be None when ``gs`` comes from ``GraphStructure.grouped`` (it carries the pointer)."""
+    ``gptr`` may be None when ``gs`` comes from ``GraphStructure.grouped`` (it carries the pointer).  ``layered``: the same
+    network on the layer-major kernels (graphs above 128 nodes, hidden 113..128): body and head SAGE layers as ONE stack +
+    the head-tail kernels, see ``qnet_layered_forward``."""
+    if layered:
+        return qnet_layered_forward(cache, x, gs, gptr, b, c_in, hidden, body_layers, head_layers, mode, need_bwd)
     L = _lib.lib()
     dev = x.device
     n = x.shape[0]
@@ -822,7 +826,113 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     call.bufs, call.math, call.gp = buf, _MATH, gp
     call.sink = None
     call.done = False
+    call.layered = False
     return q, out_v, call
+
+
+def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
+                         head_layers: int, mode: int, need_bwd: bool):
+    """DuellingTwoHeaded.forward on the layer-major kernels with the direct-gradient bookkeeping: body + head SAGE layers run
+    as ONE stack of body_layers + head_layers layers (``hexgnn_sage_stack_forward``; the head's gnn is just more SAGE layers
+    with ReLU), then the head tail (``hexgnn_head_forward``).  Against the per-module composition (body stack, head stack,
+    head tail as three autograd functions) the backward has ONE batched weight-gradient GEMM + ONE slab reduce over all 16
+    hidden layers instead of two of each, no stack-boundary combine, and ~1 ms less Python per step."""
+    L = _lib.lib()
+    dev = x.device
+    n = x.shape[0]
+    tot = body_layers + head_layers
+    if x.dtype != torch.float32 or x.stride(1) != 1:
+        x = x.float().contiguous()
+    x_stride = x.stride(0) if n > 0 else c_in
+    sizes = cache.sizes.get(("L", n, b))
+    if sizes is None:
+        hp = padded_width(hidden)
+        al = lambda v: (max(int(v), 16) + 255) & ~255
+        sizes = cache.sizes[("L", n, b)] = (
+            hp, al(4 * tot * n * hp), al(L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot)),
+            al(L.hexgnn_sage_stack_saved_bytes(n, c_in, hidden, tot)), al(L.hexgnn_head_saved_bytes(n, b, hidden)),
+            al(L.hexgnn_sage_stack_backward_workspace_bytes(n, c_in, hidden, tot)),
+            al(L.hexgnn_head_backward_workspace_bytes(n, b, hidden)))
+    hp, a_bytes, w_bytes, s_bytes, hs_bytes, ws_bytes, hws_bytes = sizes
+    buf = torch.empty(a_bytes + w_bytes + s_bytes + hs_bytes, dtype=torch.uint8, device=dev)
+    base = buf.data_ptr()
+    q = torch.empty(n, dtype=torch.float32, device=dev)
+    out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+    gp = gs._ptrs
+    if gp is None:
+        gp = (gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.invdeg.data_ptr(),
+              gptr.data_ptr(), gs.status.data_ptr())
+    t = cache.tail
+    stream = _stream()
+    _lib.check(L.hexgnn_sage_stack_forward(n, c_in, hidden, tot, gp[0], gp[1], gp[4], x.data_ptr(), x_stride, cache.wl, cache.bl,
+                                           cache.wr, base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), 0, stream),
+               "hexgnn_sage_stack_forward")
+    h_top = base + 4 * (tot - 1) * n * hp
+    _lib.check(L.hexgnn_head_forward(n, b, hidden, mode, gp[5], h_top, t[0], t[1], t[2], t[3], t[4], t[5], q.data_ptr(),
+                                     out_v.data_ptr() if out_v is not None else None, base + a_bytes + w_bytes + s_bytes,
+                                     stream), "hexgnn_head_forward")
+    call = _QNetCall()
+    call.cache, call.gs, call.gptr, call.x = cache, gs, gptr, x
+    call.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, (s_bytes, ws_bytes, hws_bytes))
+    call.bufs, call.math, call.gp = buf, 0, gp
+    call.sink = None
+    call.done = False
+    call.layered = True
+    return q, out_v, call
+
+
+def _assign_flat_grads(cache: QNetParamCache, flat: torch.Tensor, mode: int) -> None:
+    """Views of the flat gradient buffer -> ``p.grad`` (accumulating into a gradient that is already there)."""
+    fp = cache.flat_params
+    views = torch._C._nn.unflatten_dense_tensors(flat, fp)
+    skip = mode == 2          # advantages only: the value head (flat positions -6 .. -3) has no gradient
+    k_lo, k_hi = len(fp) - 6, len(fp) - 2
+    for k, (p, v) in enumerate(zip(fp, views)):
+        if skip and k_lo <= k < k_hi:
+            continue
+        g = p.grad
+        p.grad = v if g is None else g + v
+
+
+def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
+    L = _lib.lib()
+    cache = call.cache
+    n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, (s_bytes, ws_bytes, hws_bytes) = call.dims
+    dev = call.x.device
+    if mode == 1:
+        d_v = torch.zeros(b, dtype=torch.float32, device=dev) if d_v is None else d_v.float().contiguous()
+    else:
+        d_v = None
+    dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
+        (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
+    flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
+    ws = torch.empty(ws_bytes + hws_bytes, dtype=torch.uint8, device=dev)
+    dh = torch.empty((n, hp), dtype=torch.float32, device=dev)
+    d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if (call.sink is not None and body_layers < tot) else None
+    base, gp, t = call.bufs.data_ptr(), call.gp, cache.tail
+    fb = flat.data_ptr()
+    offs = cache.offsets
+    tp = [fb + 4 * offs[3 * tot + k] for k in range(6)]          # d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b
+    vh = mode != 2
+    stream = _stream()
+    h_top = base + 4 * (tot - 1) * n * hp
+    _lib.check(L.hexgnn_head_backward(n, b, hidden, mode, gp[5], h_top, t[0], t[2], t[4], base + a_bytes + w_bytes + s_bytes,
+                                      dq.data_ptr(), d_v.data_ptr() if d_v is not None else None, dh.data_ptr(), tp[0], tp[1],
+                                      tp[2] if vh else None, tp[3] if vh else None, tp[4] if vh else None,
+                                      tp[5] if vh else None, ws.data_ptr() + ws_bytes, hws_bytes, stream),
+               "hexgnn_head_backward")
+    vp = C.c_void_p * tot
+    d_wl = vp(*[fb + 4 * offs[3 * l] for l in range(tot)])
+    d_bl = vp(*[fb + 4 * offs[3 * l + 1] for l in range(tot)])
+    d_wr = vp(*[fb + 4 * offs[3 * l + 2] for l in range(tot)])
+    _lib.check(L.hexgnn_sage_stack_backward_tap(
+        n, c_in, hidden, tot, gp[0], gp[1], gp[2], gp[3], gp[4], call.x.data_ptr(), x_stride, base, base + a_bytes + w_bytes,
+        base + a_bytes, dh.data_ptr(), None, d_wl, d_bl, d_wr, ws.data_ptr(), ws_bytes, 0,
+        body_layers - 1 if d_emb is not None else -1, d_emb.data_ptr() if d_emb is not None else None, stream),
+        "hexgnn_sage_stack_backward_tap")
+    _assign_flat_grads(cache, flat, mode)
+    if call.sink is not None:
+        call.sink((d_emb if d_emb is not None else dh)[:, :hidden])
 
 
 def qnet_embeds(call: _QNetCall) -> torch.Tensor:
@@ -860,6 +970,8 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
     if call.done:
         raise RuntimeError("this forward's backward already ran through ops.backward(loss) (its graph is spent, as after "
                            "loss.backward() without retain_graph)")
+    if call.layered:
+        return qnet_layered_backward(call, dq, d_v)
     L = _lib.lib()
     cache = call.cache
     n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes = call.dims
@@ -888,15 +1000,7 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
         hook(flat, cut, cache.total)
         _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
         hook(flat, 0, cut)
-    fp = cache.flat_params
-    views = torch._C._nn.unflatten_dense_tensors(flat, fp)
-    nskip = 4 if mode == 2 else 0          # advantages only: the value head (flat positions -6 .. -3) has no gradient
-    k_lo, k_hi = len(fp) - 6, len(fp) - 2
-    for k, (p, v) in enumerate(zip(fp, views)):
-        if nskip and k_lo <= k < k_hi:
-            continue
-        g = p.grad
-        p.grad = v if g is None else g + v
+    _assign_flat_grads(cache, flat, mode)
     if call.sink is not None:
         call.sink(d_emb[:, :hidden])
 

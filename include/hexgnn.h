@@ -108,6 +108,19 @@ int hexgnn_sage_stack_backward(int n, int c_in, int hidden, int num_layers,
                                void* workspace, size_t workspace_bytes, int flags /* as in the forward call */,
                                hexgnn_stream_t stream);
 
+/* The same call with a TAP: tap_out [n][HP] (may be NULL) receives the gradient w.r.t. the OUTPUT of layer tap_layer
+ * (0 <= tap_layer < num_layers - 1) -- DuellingTwoHeaded's final_conv_grads when body and head layers run as one stack
+ * (GN0/models.py:553-554: embeds.register_hook). */
+int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers,
+                                   const int* rowptr, const int* col,
+                                   const int* rowptr_t, const int* col_t, const float* invdeg,
+                                   const float* x, int x_stride,
+                                   const float* acts, const void* saved, const void* wpack,
+                                   const float* dy, float* dx,
+                                   float* const* d_wl, float* const* d_bl, float* const* d_wr,
+                                   void* workspace, size_t workspace_bytes, int flags,
+                                   int tap_layer, float* tap_out, hexgnn_stream_t stream);
+
 /* ---- head tail: HeadNetwork.forward after its gnn (GN0/models.py:374-384), MLP value head
  *      (GN0/models.py:36-82: Linear(4H,H/2) -> relu -> Linear(H/2,1)) and the dueling combine of
  *      DuellingTwoHeaded.forward (GN0/models.py:567-584).
