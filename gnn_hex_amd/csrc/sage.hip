@@ -319,10 +319,6 @@ __device__ unsigned long long g_lstamps[2][8][8];
 //   3. rows with more than sixteen neighbours finish their sum from the CSR, then the aggregate half, epilogue.
 constexpr int kEll = 16;          // neighbour slots handled inside the self half (longer rows finish from the CSR)
 
-// Gather schedule of the self half: the W * NT 16-byte neighbour loads of a lane are issued kP per gap (a gap = the slot
-// behind one (chunk, tile) group of four MFMAs; a burst of loads instead would hold the wave -- and with it its MFMAs -- in
-// the CU's 64 B/clk vector-memory issue path), neighbour k lands in buffer k % kWin and is added kD gaps after its last
-// load, before the first load of neighbour k + kWin in the same buffer.  Gaps past the last MFMA group run behind the loop.
 // MFMA order of a K-half (NT >= 3): the NT*NT units (chunk c, tile t) of four dependent MFMAs each are issued in GROUPS of
 // three units round robin -- u0.j0 u1.j0 u2.j0 u0.j1 ... u2.j3 -- so that two MFMAs on the same accumulator are always at
 // least three slots (>= 96 cycles of matrix-pipe time) apart, more than the instruction's 40-cycle dependent latency (the
@@ -341,6 +337,11 @@ template <int NT> struct MfmaSeq {
     static constexpr int kGaps = U;
 };
 
+// Gather schedule of the self half, neighbours fetched from GLOBAL memory (hidden 113..128, where the row copy below does
+// not fit beside the weights): the W * NT 16-byte neighbour loads of a lane are issued kP per gap (a gap = the slot behind
+// four MFMAs; a burst of loads instead would hold the wave -- and with it its MFMAs -- in the CU's 64 B/clk vector-memory
+// issue path), neighbour k lands in buffer k % kWin and is added kD gaps after its last load, before the first load of
+// neighbour k + kWin in the same buffer.  Gaps past the last MFMA group run behind the loop.
 template <int NT> struct GatherSched {
     static constexpr int W = kEll;
     static constexpr int G = NT * NT;
@@ -360,6 +361,31 @@ template <int NT> struct GatherSched {
         return true;
     }
     static_assert(ok(), "a landing buffer would be reloaded before it is consumed");
+};
+
+// Up to hidden 112 the block's OWN 128 rows are kept in LDS beside the weights (98 KB + 129 x 464 B = 157 KB at NT = 7; row
+// 128 is all zero): a board graph's neighbours sit within a few dozen rows of the node, so most of a block's neighbour reads
+// stay inside the block and become LDS reads; only rows near a block boundary (and the two terminal rows of a graph cut by
+// it) still fetch from global memory.  Round 2's kernels read EVERY neighbour row through L1/L2: 16 slots x NT loads per
+// lane, the self half took 21-30 k ticks against 12.5 k of MFMAs (profiles/r02/layer_stamps_MIX.txt).
+//   slot k: LDS read in gap k * stride (out-of-block lanes read the zero row), added one gap later;
+//           global load in the same gap for the lanes that need it -- skipped wave-uniformly (a 16-bit mask of ballots) when
+//           no lane of the wave does -- into a ring of two landing buffers, added kGd gaps later (the ring of four of the
+//           all-global schedule would not fit the registers beside the second offset table).
+template <int NT> struct RowsLds {
+    static constexpr bool on = NT >= 4 && NT <= 7;       // (narrower: hipcc spills the second offset table; wider: no LDS left)
+    static constexpr int XS = 16 * NT + 4;                   // floats per row: an odd number of 16-byte slots
+    static constexpr int bytes = on ? 129 * XS * 4 : 0;
+    static_assert(!on || 129 * XS * 4 <= 65536, "row offsets are kept as u16");
+};
+template <int NT> struct GatherLds {
+    static constexpr int G = NT * NT;
+    static constexpr int stride = (G - 3) / kEll > 0 ? (G - 3) / kEll : 1;
+    static constexpr int kGd = 2 * stride < 4 ? 2 * stride : 4;          // adds run before the loads of a gap: a ring of TWO is safe
+    static constexpr int rd_gap(int k) { return k * stride; }
+    static constexpr int add_gap(int k) { return k * stride + 1; }
+    static constexpr int gadd_gap(int k) { return k * stride + kGd; }
+    static constexpr int kGaps = gadd_gap(kEll - 1) + 1 > G ? gadd_gap(kEll - 1) + 1 : G;
 };
 
 template <int NT, bool BWD>
@@ -395,6 +421,14 @@ __device__ __forceinline__ void sage_layer_body(
         e1 = rowptr[row + 1];
         if constexpr (!BWD) sc = invdeg[row];
     }
+    using RL = RowsLds<NT>;
+    float* rowsl = reinterpret_cast<float*>(wlds + 2 * NT * NT * 64);      // [129][XS] behind the weights (NT <= 7)
+    if constexpr (RL::on) {
+        f32x4* mine = reinterpret_cast<f32x4*>(rowsl + (wave * 16 + r) * RL::XS) + g;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) mine[4 * c] = xs[c];                   // (rows past n are zeros)
+        if (tid < RL::XS / 4) reinterpret_cast<f32x4*>(rowsl + 128 * RL::XS)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     wait_vmem();
     LSTAMP(K, 1);
     __syncthreads();
@@ -418,15 +452,74 @@ __device__ __forceinline__ void sage_layer_body(
             ns[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, k < deg ? (unsigned)nid[k] * 4u : kOob, 0, 0));
     }
     using GS = GatherSched<NT>;
-    unsigned noff[kEll];             // byte offset of neighbour k's row slot (out of range: no such neighbour -> zeros)
+    using GL = GatherLds<NT>;
+    constexpr int kFillGaps = RL::on ? GL::kGaps : GS::kGaps;
+    unsigned noff[kEll];             // GLOBAL byte offset of neighbour k's row slot (out of range: nothing to fetch -> zeros)
+    unsigned loff[RL::on ? kEll / 2 : 1];       // LDS byte offsets of the slots, two u16 per register (zero row: not in the block)
+    unsigned gneed = 0;              // wave-uniform: bit k = some lane of the wave fetches slot k from global memory
+    if constexpr (RL::on) {
+        const unsigned blk0 = blockIdx.x * 128u;
 #pragma unroll
-    for (int k = 0; k < kEll; ++k) noff[k] = k < deg ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
+        for (int k = 0; k < kEll / 2; ++k) loff[k] = 0u;
+#pragma unroll
+        for (int k = 0; k < kEll; ++k) {
+            const unsigned loc = (unsigned)nid[k] - blk0;
+            const bool have = k < deg, inb = have && loc < 128u;
+            loff[k >> 1] |= ((inb ? loc : 128u) * (unsigned)(RL::XS * 4) + 16u * g) << (16 * (k & 1));
+            noff[k] = (have && !inb) ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
+            gneed |= (__ballot(have && !inb) != 0ull ? 1u : 0u) << k;
+        }
+        gneed = __builtin_amdgcn_readfirstlane(gneed);
+    } else {
+#pragma unroll
+        for (int k = 0; k < kEll; ++k) noff[k] = k < deg ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
+    }
     int wmax = deg < kEll ? deg : kEll;          // wave-uniform number of neighbour slots anybody in the wave uses
 #pragma unroll
     for (int o = 32; o >= 1; o >>= 1) wmax = max(wmax, __shfl_xor(wmax, o));
     wmax = __builtin_amdgcn_readfirstlane(wmax);
-    f32x4 tb[GS::kWin][NT];
-    auto filler = [&](auto qq) {
+    f32x4 tb[RL::on ? 3 : GS::kWin][NT];         // LDS path: [0..1] global landing ring, [2] LDS landing buffer
+    auto filler_lds = [&](auto qq) {
+        constexpr int Q = decltype(qq)::value;
+        const char* lbase = reinterpret_cast<const char*>(rowsl);
+        static_for_<0, kEll>([&](auto kk) {       // adds first (a gap's adds precede its loads: the rings rely on it)
+            constexpr int k = decltype(kk)::value;
+            if constexpr (GL::add_gap(k) == Q) {
+                if (k < wmax) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        if constexpr (BWD) ag[c] += tb[2][c] * ns[k];
+                        else ag[c] += tb[2][c];
+                    }
+                }
+            }
+            if constexpr (GL::gadd_gap(k) == Q) {
+                if (gneed & (1u << k)) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        if constexpr (BWD) ag[c] += tb[k % 2][c] * ns[k];
+                        else ag[c] += tb[k % 2][c];
+                    }
+                }
+            }
+        });
+        static_for_<0, kEll>([&](auto kk) {
+            constexpr int k = decltype(kk)::value;
+            if constexpr (GL::rd_gap(k) == Q) {
+                if (k < wmax) {
+                    const unsigned lo = (k & 1) ? (loff[k >> 1] >> 16) : (loff[k >> 1] & 0xffffu);
+                    const f32x4* lr = reinterpret_cast<const f32x4*>(lbase + lo);
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) tb[2][c] = lr[4 * c];
+                }
+                if (gneed & (1u << k)) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) tb[k % 2][c] = buf_load(xr_, noff[k] + 64 * c);
+                }
+            }
+        });
+    };
+    auto filler_glb = [&](auto qq) {
         constexpr int Q = decltype(qq)::value;            // gap index behind the (c, t) group c * NT + t of the self half
         static_for_<0, kEll>([&](auto kk) {
             constexpr int k = decltype(kk)::value;
@@ -444,6 +537,10 @@ __device__ __forceinline__ void sage_layer_body(
             constexpr int i = decltype(ii)::value, k = i / NT, c = i % NT;
             if (k < wmax) tb[k % GS::kWin][c] = buf_load(xr_, noff[k] + 64 * c);
         });
+    };
+    auto filler = [&](auto qq) {
+        if constexpr (RL::on) filler_lds(qq);
+        else filler_glb(qq);
     };
 
     f32x4 acc[NT];
@@ -476,8 +573,14 @@ __device__ __forceinline__ void sage_layer_body(
         });
     };
     if constexpr (NT >= 3) {
+        // (tried in round 3, 1.038 -> 1.075 ms on MIX: waves 4-7 gathering FIRST, loads and adds only under their partners'
+        // MFMA streams, then both K-halves as one MFMA stream -- a wave's non-MFMA work crawls under its partner's MFMAs)
         contract_rr(wlds + NT * NT * 64, xs, filler);
-        static_for_<MfmaSeq<NT>::kGaps, GS::kGaps>([&](auto qq) { filler(qq); });
+        static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
+    } else {
+            contract_rr(wlds + NT * NT * 64, xs, filler);
+            static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
+        }
     } else {
         // one or two tiles: too few accumulators to stagger; the dependent chain is waited out before anything is issued
         // behind a unit (the fused kernels' mfma_drain, 2 x 40 cycles per link)
@@ -496,7 +599,7 @@ __device__ __forceinline__ void sage_layer_body(
                 __builtin_amdgcn_sched_barrier(0);
             });
         });
-        static_for_<NT * NT, GS::kGaps>([&](auto qq) { filler(qq); });     // (narrow layers: the schedule outlasts the MFMA groups)
+        static_for_<NT * NT, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });     // (narrow layers: the schedule outlasts the MFMA groups)
     }
     LSTAMP(K, 2);
     f32x4 ym[BWD ? NT : 1];
@@ -1022,12 +1125,12 @@ static void launch_fwd(int n, const int* rowptr, const int* col, const float* in
                        const void* wp, const float* bias, float* y, float* agg, int relu, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_fwd_kernel<NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
         return true;
     }();
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
-    sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
+    sage_hidden_fwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(
         n, rowptr, col, invdeg, x, (const f32x4*)wp, bias, y, agg, relu);
 }
 
@@ -1036,12 +1139,12 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
                        const float* g_in, const void* wpb, const float* ymask, float* out, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_bwd_kernel<NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
         return true;
     }();
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
-    sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024, st>>>(
+    sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(
         n, rowptr_t, col_t, invdeg, g_in, (const f32x4*)wpb, ymask, out);
 }
 

@@ -22,7 +22,8 @@ positions AND mid-game boards, 256 graphs) and every kernel path:
     (measured: S256-D1 6.0e-4 on BOTH exact-fp32 kernel paths, which share their fmaf chains, against 7e-6 for the fp32
     oracle and 2.3e-5 for the f16x3 path, whose roundings flip other elements; L256-D1 1.5e-4 vs 2.9e-5); tensors without
     a flip sit at 1e-6..7e-5, within 3x the fp32 oracle's own distance;
-* Q itself: max |Q - Q_64| <= max(3 x the fp32 oracle's, 2e-6), and on the sharpened state additionally the structural
+* Q itself: max |Q - Q_64| <= max(3 x the fp32 oracle's, 5e-6) (|Q| up to 2: 5e-6 is ~20 ulp after 17 layers; measured
+  1e-7..2.4e-6), and on the sharpened state additionally the structural
   identities of GN0/models.py:571-584 on the device result (per-graph mean of Q == tanh(value)).
 
 Also here: run-to-run bit reproducibility of the LAYER-MAJOR kernels (MIX, Hex-12+, --norm and hidden 113-128 all run
@@ -121,7 +122,7 @@ def test_relative_parity_against_float64_oracle(name, state, path):
 
     eq = (q.cpu().double() - o["q64"]).abs().max().item()
     eq32 = (o["q32"].double() - o["q64"]).abs().max().item()
-    assert eq <= max(3.0 * eq32, 8e-6 if split else 2e-6), "%s/%s: |Q - Q64| %g (fp32 oracle %g)" % (name, state, eq, eq32)
+    assert eq <= max(3.0 * eq32, 8e-6 if split else 5e-6), "%s/%s: |Q - Q64| %g (fp32 oracle %g)" % (name, state, eq, eq32)
 
     worst = (0.0, 0.0, "")
     for k, g64 in o["g64"].items():
