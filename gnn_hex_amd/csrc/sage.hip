@@ -578,10 +578,6 @@ __device__ __forceinline__ void sage_layer_body(
         contract_rr(wlds + NT * NT * 64, xs, filler);
         static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
     } else {
-            contract_rr(wlds + NT * NT * 64, xs, filler);
-            static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
-        }
-    } else {
         // one or two tiles: too few accumulators to stagger; the dependent chain is waited out before anything is issued
         // behind a unit (the fused kernels' mfma_drain, 2 x 40 cycles per link)
         static_for_<0, NT>([&](auto cc) {
