@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
 _lib = None
-ABI_VERSION = 2          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
+ABI_VERSION = 3          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
 
 vp = C.c_void_p
 ci = C.c_int

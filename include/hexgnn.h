@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HEXGNN_ABI_VERSION 2
+#define HEXGNN_ABI_VERSION 3
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
