@@ -9,7 +9,7 @@ O=$R/gpurun_out/${PROFILE_TAG:-p_r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L > $O/counters_available.txt 2>&1 || true
-B="$R/bench.py --no-cpu-baseline --no-split --no-other-configs"
+B="$R/bench.py --no-cpu-baseline --no-split --no-other-configs --no-collective-probe"
 for m in ${PROFILE_MODES:-fp32}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o s -- python3 $B --math $m --steps 20 --warmup 5 > $O/stats_$m.log 2>&1
   echo "stats $m done"
