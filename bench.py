@@ -39,13 +39,11 @@ CONFIGS = {
     "MIX": (15, 110, lambda b: [5 + (g % 9) for g in range(b)], "GNN-L mixed Hex-5..13 ragged batch=256"),
 }
 
-WORLD_FOR_WEIGHTS = [1]      # world size seen by make_batches' strong-scaling loss weights
-
 KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel",
           8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
 
 
-def make_batches(config, data, B, dev, rank=0, subset=None):
+def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
     """The two resident batches (maker to move / breaker to move) of a configuration.  Weak scaling: every rank holds its own
     B graphs (D1 graphs differ per rank).  Strong scaling (`subset` = this rank's graph indices of ONE global B-graph batch,
     gnn_hex_amd.dist.balance_by_edges): the rank holds only those graphs; D1 seeds are the global graph indices."""
@@ -72,7 +70,7 @@ def make_batches(config, data, B, dev, rank=0, subset=None):
         sel, tgt = sel_and_targets(ptr, seed=1 + rank)       # every rank regresses on its own targets
         # strong scaling: the loss is the mean over the GLOBAL batch -- a rank's mean over its k graphs times k * world / B,
         # so that the gradient average over the ranks is the global mean even when the edge-balanced parts differ in count
-        wts = None if subset is None else torch.full((len(graphs),), float(len(graphs)) * WORLD_FOR_WEIGHTS[0] / B)
+        wts = None if subset is None else torch.full((len(graphs),), float(len(graphs)) * world / B)
         xd = x.to(dev)
         xd._hex_is_maker = maker          # side to move known to the host (env / replay metadata)
         xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
@@ -253,8 +251,7 @@ def main():
             return 2 * (2 * nn + (nn - 2) * (nn - 1) + nn * (nn - 1) + (nn - 1) ** 2)
         parts = balance_by_edges([edges_of(sz) for sz in sizes_fn(B)], world)
         subset = parts[rank]
-        WORLD_FOR_WEIGHTS[0] = world
-    batches = make_batches(args.config, args.data, B, dev, rank, subset)
+    batches = make_batches(args.config, args.data, B, dev, rank, subset, world)
     gfactor = 1 if strong else world          # graphs per step over all ranks = B * gfactor
 
     plist = list(hip.parameters())
