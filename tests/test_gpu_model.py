@@ -382,6 +382,25 @@ def test_arbitrary_graphs_directed_duplicates_isolated(directed):
     _compare(hip, ref, x, ei, batch, ptr)
 
 
+@pytest.mark.parametrize("hidden", [64, 80, 96, 110, 128])
+def test_big_random_graphs_on_the_layer_major_path(hidden):
+    """Graphs of several hundred nodes with edges ALL OVER the graph (not board-like): on the layer-major kernels most
+    neighbours of a row then live in another 128-row block -- the global-memory side of the mixed LDS / global gather of round 3
+    (hidden 49..112; 128 keeps the all-global schedule) carries most of the load, every neighbour slot, the wave-uniform skip
+    mask and rows with more than sixteen in-edges (the CSR tail path) are exercised, directed edges make the transposed
+    gather of the backward differ from the forward's.  Q and every gradient against the oracle."""
+    from gnn_hex_amd import ops
+    if ops._FUSED_ENABLED and ops.get_math() != "fp32":
+        pytest.skip("graphs above 128 nodes run layer-major whatever the switches say: once per switch state is enough")
+    hip, ref = make_pair(3, hidden, seed=27)
+    x, ei, batch, ptr = _random_batch([300, 40, 517, 129, 7], seed=hidden, directed=True, p_edge=0.02)
+    deg = torch.bincount(ei[1], minlength=x.shape[0])
+    assert int(deg.max()) > 16 and int((deg == 0).sum()) > 0           # the tail path and empty rows are both present
+    _compare(hip, ref, x, ei, batch, ptr)
+    x, ei, batch, ptr = _random_batch([260, 260], seed=hidden + 1, directed=False, p_edge=0.012)
+    _compare(hip, ref, x, ei, batch, ptr)
+
+
 def test_graph_size_boundary_128_129():
     """128 nodes still fits a workgroup's LDS (fused path); one 129-node graph sends the batch down the layered path."""
     hip, ref = make_pair(3, 35, seed=22)
