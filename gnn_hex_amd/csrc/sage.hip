@@ -575,6 +575,9 @@ __device__ __forceinline__ void sage_layer_body(
     if constexpr (NT >= 3) {
         // (tried in round 3, 1.038 -> 1.075 ms on MIX: waves 4-7 gathering FIRST, loads and adds only under their partners'
         // MFMA streams, then both K-halves as one MFMA stream -- a wave's non-MFMA work crawls under its partner's MFMAs)
+        // (also tried, 1.037 -> 1.089 ms: EVERY wave gathering first -- no MFMA stream anywhere on the CU to crawl under -- and
+        // both K-halves as pure MFMA streams afterwards: back to back the sixteen slots expose one LDS / L2 round trip each,
+        // ~9 k ticks that the MFMA groups otherwise cover)
         contract_rr(wlds + NT * NT * 64, xs, filler);
         static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
     } else {
