@@ -214,7 +214,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const float* __restrict__ adv_raw, const int* __restrict__ amax, const int* __restrict__ amin,
     const float* __restrict__ z, const float* __restrict__ vraw, const float* __restrict__ dq,
     const float* __restrict__ d_out_v, float* __restrict__ dh, float* __restrict__ dadv, float* __restrict__ dz,
-    float* __restrict__ dvr, float* __restrict__ lin_part /*[b][hp+1]*/) {
+    float* __restrict__ dvr, float* __restrict__ lin_part /*[b][hp+1]*/, int mask_dh) {
     __shared__ float s_dp[4 * 128];
     __shared__ float s_dz[64];
     __shared__ int s_ax[128], s_an[128];
@@ -289,6 +289,11 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
                             }
                         }
                         v[j] = t;
+                    }
+                    if (mask_dh) {      // dh * [h > 0]: the gradient the ReLU layer underneath receives
+                        const f32x4 hv = reinterpret_cast<const f32x4*>(h + (size_t)row * hp)[q];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = hv[j] > 0.f ? v[j] : 0.f;
                     }
                     dr[q] = v;
                 }
@@ -657,6 +662,8 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
     hipStream_t st = (hipStream_t)stream_;
     const int hp = padded_width(hidden);
     if (hp < 0 || hidden < 2) return HEXGNN_EUNSUPPORTED;
+    const int mask_dh = (mode & HEXGNN_HEAD_MASK_DH) ? 1 : 0;
+    mode &= ~HEXGNN_HEAD_MASK_DH;
     if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
     if (!gptr || !lin_w || !saved || !d_lin_w || !d_lin_b) return HEXGNN_EINVAL;
     if (mode != 2 && mode != 4 && (!v0_w || !v1_w || !d_v0_w || !d_v0_b || !d_v1_w || !d_v1_b)) return HEXGNN_EINVAL;
@@ -676,7 +683,7 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
         head_bwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, h, lin_w, v0_w, v1_w, (const float*)(sv + s.adv_off),
                                            (const int*)(sv + s.amax_off), (const int*)(sv + s.amin_off),
                                            (const float*)(sv + s.z_off), (const float*)(sv + s.v_off), dq, d_out_v,
-                                           dh, dadv, dz, dvr, part);
+                                           dh, dadv, dz, dvr, part, mask_dh);
     launch_head_param_grads(b, hidden, mode, dz, dvr, (const float*)(sv + s.pooled_off), (const float*)(sv + s.z_off),
                             part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b, st);
     return check_launch();

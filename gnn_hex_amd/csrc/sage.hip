@@ -664,6 +664,12 @@ __device__ __forceinline__ void sage_layer_body(
                 yr[4 * t] = v;
             }
         } else {
+            // (backward: agg_out, when given, is the TAP -- the same rows BEFORE the mask, final_conv_grads of the model)
+            if (agg_out) {
+                f32x4* tr = reinterpret_cast<f32x4*>(agg_out + (size_t)row * HP) + g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) tr[4 * t] = acc[t];
+            }
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 v = acc[t];
@@ -692,9 +698,9 @@ template <int NT>
 __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
     int n, const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
     const float* __restrict__ invdeg, const float* __restrict__ g_in, const f32x4* __restrict__ wpackb,
-    const float* __restrict__ ymask, float* __restrict__ out) {
+    const float* __restrict__ ymask, float* __restrict__ out, float* __restrict__ tap) {
     extern __shared__ f32x4 wlds[];  // [2][NT][NT][64]: W_l part, W_r part
-    sage_layer_body<NT, true>(n, rowptr_t, col_t, invdeg, g_in, wpackb, nullptr, ymask, out, nullptr, 1, wlds);
+    sage_layer_body<NT, true>(n, rowptr_t, col_t, invdeg, g_in, wpackb, nullptr, ymask, out, tap, 1, wlds);
 }
 
 // ---- out = dxs + sum_{j in T(i)} dagg_j, optionally masked by y>0 (stack-input gradient / G of a raw first layer) ----
@@ -1135,7 +1141,8 @@ static void launch_fwd(int n, const int* rowptr, const int* col, const float* in
 
 template <int NT>
 static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float* invdeg,
-                       const float* g_in, const void* wpb, const float* ymask, float* out, hipStream_t st) {
+                       const float* g_in, const void* wpb, const float* ymask, float* out, hipStream_t st,
+                       float* tap = nullptr) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_hidden_bwd_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
@@ -1144,7 +1151,7 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
     sage_hidden_bwd_kernel<NT><<<(n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(
-        n, rowptr_t, col_t, invdeg, g_in, (const f32x4*)wpb, ymask, out);
+        n, rowptr_t, col_t, invdeg, g_in, (const f32x4*)wpb, ymask, out, tap);
 }
 
 template <int NT>
@@ -1375,7 +1382,8 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
     (void)rowptr; (void)col;
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
-    if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
+    if (n < 0 || (flags & ~(HEXGNN_SAGE_LINEAR_LAST | HEXGNN_SAGE_DY_IN_PLACE))) return HEXGNN_EINVAL;
+    if ((flags & HEXGNN_SAGE_DY_IN_PLACE) && (flags & HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     BwdPlan b;
@@ -1408,7 +1416,11 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
     const int first_hidden = p.small_first ? 1 : 0;
     const int q4 = p.hp / 4;
     const unsigned cgrid = (unsigned)(((int64_t)n * q4 + 255) / 256);
-    {
+    if (flags & HEXGNN_SAGE_DY_IN_PLACE) {
+        // the caller's producer (hexgnn_head_backward with HEXGNN_HEAD_MASK_DH) wrote G_{L-1} = dy * [y_{L-1} > 0] straight
+        // into its slab of the workspace: nothing to combine
+        if (dy != G + slab * (p.L - 1)) return HEXGNN_EINVAL;
+    } else {
         KernelTimer kt(HEXGNN_K_COMBINE, st);
         const bool relu_top = !(flags & HEXGNN_SAGE_LINEAR_LAST);
         sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, dy, nullptr, relu_top ? acts + slab * (p.L - 1) : nullptr,
@@ -1419,14 +1431,10 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
         float* out = l >= 1 ? G + slab * (l - 1) : dx;
         if (!out) break;                                   // l == 0 and nobody asked for the input gradient
         const float* ymask = l >= 1 ? acts + slab * (l - 1) : nullptr;
-        if (tap_out && l - 1 == tap_layer) {
-            // the gradient w.r.t. layer tap_layer's OUTPUT (before its ReLU mask) is wanted as well: unmasked launch into the
-            // tap, then the mask as its own step
-            HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], nullptr, tap_out, st)));
-            sage_combine_kernel<<<cgrid, 256, 0, st>>>(n, p.hp, rowptr_t, col_t, tap_out, nullptr, ymask, out);
-            continue;
-        }
-        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st)));
+        // (the gradient w.r.t. layer tap_layer's OUTPUT, before its ReLU mask, leaves the same launch: the epilogue stores
+        // the rows twice)
+        float* tap = (tap_out && l - 1 == tap_layer) ? tap_out : nullptr;
+        HEXGNN_NT_SWITCH(p.nt, (launch_bwd<NT_>(n, rowptr_t, col_t, invdeg, G + slab * l, wp + p.bwd_off[l], ymask, out, st, tap)));
     }
 
     rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);

@@ -907,7 +907,9 @@ def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
         (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
     flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
     ws = torch.empty(ws_bytes + hws_bytes, dtype=torch.uint8, device=dev)
-    dh = torch.empty((n, hp), dtype=torch.float32, device=dev)
+    # the head tail writes dh * [h > 0] = G of the top layer straight into its slab of the stack's workspace
+    # (HEXGNN_HEAD_MASK_DH / HEXGNN_SAGE_DY_IN_PLACE: no masked copy in between)
+    dh_ptr = ws.data_ptr() + 4 * (tot - 1) * n * hp
     d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if (call.sink is not None and body_layers < tot) else None
     base, gp, t = call.bufs.data_ptr(), call.gp, cache.tail
     fb = flat.data_ptr()
@@ -916,8 +918,8 @@ def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
     vh = mode != 2
     stream = _stream()
     h_top = base + 4 * (tot - 1) * n * hp
-    _lib.check(L.hexgnn_head_backward(n, b, hidden, mode, gp[5], h_top, t[0], t[2], t[4], base + a_bytes + w_bytes + s_bytes,
-                                      dq.data_ptr(), d_v.data_ptr() if d_v is not None else None, dh.data_ptr(), tp[0], tp[1],
+    _lib.check(L.hexgnn_head_backward(n, b, hidden, mode | 8, gp[5], h_top, t[0], t[2], t[4], base + a_bytes + w_bytes + s_bytes,
+                                      dq.data_ptr(), d_v.data_ptr() if d_v is not None else None, dh_ptr, tp[0], tp[1],
                                       tp[2] if vh else None, tp[3] if vh else None, tp[4] if vh else None,
                                       tp[5] if vh else None, ws.data_ptr() + ws_bytes, hws_bytes, stream),
                "hexgnn_head_backward")
@@ -927,12 +929,12 @@ def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
     d_wr = vp(*[fb + 4 * offs[3 * l + 2] for l in range(tot)])
     _lib.check(L.hexgnn_sage_stack_backward_tap(
         n, c_in, hidden, tot, gp[0], gp[1], gp[2], gp[3], gp[4], call.x.data_ptr(), x_stride, base, base + a_bytes + w_bytes,
-        base + a_bytes, dh.data_ptr(), None, d_wl, d_bl, d_wr, ws.data_ptr(), ws_bytes, 0,
+        base + a_bytes, dh_ptr, None, d_wl, d_bl, d_wr, ws.data_ptr(), ws_bytes, 2,
         body_layers - 1 if d_emb is not None else -1, d_emb.data_ptr() if d_emb is not None else None, stream),
         "hexgnn_sage_stack_backward_tap")
     _assign_flat_grads(cache, flat, mode)
-    if call.sink is not None:
-        call.sink((d_emb if d_emb is not None else dh)[:, :hidden])
+    if call.sink is not None and d_emb is not None:
+        call.sink(d_emb[:, :hidden])
 
 
 def qnet_embeds(call: _QNetCall) -> torch.Tensor:

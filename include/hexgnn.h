@@ -80,6 +80,10 @@ int hexgnn_graph_ptr(int n, int b, const int64_t* batch, int* gptr /*[b+1]*/, he
  *      flags: HEXGNN_SAGE_LINEAR_LAST = no ReLU after the LAST layer of the stack; a 1-layer stack with it is a bare
  *      SAGEConv.forward (torch_geometric SAGEConv as restated at GN0/torch_script_models.py:52-73). */
 #define HEXGNN_SAGE_LINEAR_LAST 1
+/* backward only: dy already IS G_{L-1} = dy * [y_{L-1} > 0], written by its producer at
+ * (float*)workspace + (size_t)(num_layers - 1) * n * HP (hexgnn_head_backward with HEXGNN_HEAD_MASK_DH does): the stack's
+ * first step, a masked copy of dy into that slab, is skipped. */
+#define HEXGNN_SAGE_DY_IN_PLACE 2
 size_t hexgnn_sage_stack_pack_bytes(int c_in, int hidden, int num_layers);
 size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers);
 /* acts:  [num_layers][n][HP] outputs of every layer (post-ReLU); the last slab is the result.
@@ -140,6 +144,9 @@ int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, con
                         float* q /*[n]*/, float* out_v /*[b] (modes 1, 3) or NULL*/,
                         void* saved, hexgnn_stream_t stream);
 size_t hexgnn_head_backward_workspace_bytes(int n, int b, int hidden);
+/* mode | HEXGNN_HEAD_MASK_DH (backward only): dh is written masked by [h > 0] -- h is the output of a ReLU layer, and the
+ * gradient handed to that layer's backward is dh * [h > 0] anyway (saves the stack's masked copy, HEXGNN_SAGE_DY_IN_PLACE). */
+#define HEXGNN_HEAD_MASK_DH 8
 /* dq: gradient of q [n]; d_out_v: gradient of out_v [b] (modes 1, 3) or NULL.
  * dh: [n][HP] gradient w.r.t. h (padded layout, written).  Parameter gradients written. */
 int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, const float* h,
