@@ -55,7 +55,6 @@ _SIGS = {
     "hexgnn_qnet_saved_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_forward": (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,
                                  vp, vp, vp, ci, ci, ci, vp, vp, vp, vp]),
-    "hexgnn_qnet_pack": (ci, [ci, ci, ci, vp, vp, vp, vp, vp]),
     "hexgnn_qnet_backward_workspace_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_backward": (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp,
                                   vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, vp]),

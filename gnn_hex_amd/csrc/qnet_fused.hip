@@ -205,17 +205,9 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts || !q)) return HEXGNN_EINVAL;
     if (x_stride < c_in) return HEXGNN_EINVAL;
     // math 1 + backward: the pack's scale kernel also zeroes the per-layer maxima (xmax | gmax) kept behind the saved tensors
-    // need_backward bit 1 (HEXGNN_QNET_PREPACKED): wpack was filled by hexgnn_qnet_pack for these weights -- e.g. on a second
-    // stream, beside the CSR build of this batch
-    const bool prepacked = (need_backward & HEXGNN_QNET_PREPACKED) != 0;
-    need_backward &= 1;
     unsigned* maxima = (math == 1 && need_backward) ? (unsigned*)((char*)saved + qp.xmax_off) : nullptr;
-    if (!prepacked) {
-        rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st, math, maxima);
-        if (rc != HEXGNN_OK) return rc;
-    } else if (math == 1) {
-        return HEXGNN_EUNSUPPORTED;      // (the split-precision pack also zeroes the per-layer maxima kept in `saved`)
-    }
+    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, st, math, maxima);
+    if (rc != HEXGNN_OK) return rc;
     if (b == 0) return check_launch();
     QFwdArgs a;
     a.n = n; a.b = b; a.c_in = c_in; a.H = hidden; a.L = total_layers; a.mode = mode; a.x_stride = x_stride;
@@ -239,17 +231,6 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
         rc = launch_qfwd_math(qp.sp.nt, math, a, st);
         if (rc != HEXGNN_OK) return rc;
     }
-    return check_launch();
-}
-
-int hexgnn_qnet_pack(int c_in, int hidden, int total_layers, const float* const* wl, const float* const* bl,
-                     const float* const* wr, void* wpack, hexgnn_stream_t stream_) {
-    QPlan qp;
-    int rc = make_qplan(0, 0, c_in, hidden, total_layers, &qp);
-    if (rc != HEXGNN_OK) return rc;
-    if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
-    rc = launch_pack(qp.sp, c_in, hidden, wl, bl, wr, wpack, (hipStream_t)stream_, 0, nullptr);
-    if (rc != HEXGNN_OK) return rc;
     return check_launch();
 }
 

@@ -491,20 +491,7 @@ class DuellingTwoHeaded(torch.nn.Module):
         n = x.shape[0]
         x2 = x[:, :2]
 
-        mods = self._modules
-        head = mods["maker_head"] if is_maker else mods["breaker_head"]
-        ent = self._fused_entry(head)         # (sig, params, pointer cache, (c_in, hidden, body layers, head layers, fusable, noisy))
-        c_in, h, n_body, n_head, fusable, noisy = ent[3]
         gs = getattr(edge_index, "_hex_csr", None)          # CSR emitted by the env builder, if any
-        # captured step (GraphedStep): the weight pack runs on a second stream beside the CSR build (parallel graph branches)
-        pre = None
-        if gs is None and ptr is not None and max_nodes is not None and fusable and not noisy and ops._DIRECT_GRADS \
-                and ops._MATH == 0 and ops._PARALLEL_PACK and torch.cuda.is_current_stream_capturing() \
-                and ops.qnet_fused_supported(c_in, h, max_nodes) and x2.shape[1] == c_in:
-            cache = ent[2]
-            if not cache.valid():
-                cache.refresh()
-            pre = ops.qnet_prepack(cache, n, int(ptr.numel()) - 1, c_in, h, n_body + n_head, x.device)
         # edge_index CSR-sorted once per batch; collated batches (edges grouped by graph) take the one-launch build
         grouped = (gs is None or gs.n != n) and getattr(edge_index, "_hex_grouped", False) \
             and max_nodes is not None and max_nodes <= 2048
@@ -523,8 +510,8 @@ class DuellingTwoHeaded(torch.nn.Module):
             gptr, b = ops.graph_ptr(graph_indices, ptr, n, x.device)
             if gs is None or gs.n != n:
                 gs = ops.GraphStructure(edge_index, n, gptr, b) if grouped else ops.GraphStructure(edge_index, n)
-        if pre is not None:
-            ops.qnet_prepack_join(pre)
+        mods = self._modules
+        head = mods["maker_head"] if is_maker else mods["breaker_head"]
         mode = 2 if advantages_only else (1 if seperate else 0)
 
         # fused per-graph path (one launch per direction) when every graph fits a workgroup's LDS
@@ -532,6 +519,8 @@ class DuellingTwoHeaded(torch.nn.Module):
             if gptr is None:
                 gptr = gs.gptr
             max_nodes = int((gptr[1:] - gptr[:-1]).max()) if b > 0 else 0     # host sync (no size hint given)
+        ent = self._fused_entry(head)         # (sig, params, pointer cache, (c_in, hidden, body layers, head layers, fusable, noisy))
+        c_in, h, n_body, n_head, fusable, noisy = ent[3]
         fused = fusable and max_nodes is not None and ops.qnet_fused_supported(c_in, h, max_nodes) and x2.shape[1] == c_in
         # graphs above 128 nodes / hidden 113..128: the same network on the layer-major kernels, as ONE stack + head tail
         layered = (not fused) and fusable and not noisy and ops._DIRECT_GRADS and c_in <= 8 and c_in != h \
@@ -545,8 +534,7 @@ class DuellingTwoHeaded(torch.nn.Module):
                 if not cache.valid():
                     cache.refresh()
                 if cache.direct_ok or not grad_on:
-                    fargs = (cache, x2, gs, gptr, b, c_in, h, n_body, n_head, mode, grad_on, layered,
-                             pre if (pre is not None and not layered) else None)
+                    fargs = (cache, x2, gs, gptr, b, c_in, h, n_body, n_head, mode, grad_on, layered)
                     if grad_on:
                         anchor = self.__dict__.get("_hex_anchor")
                         if anchor is None or anchor.device != x.device:

@@ -7,7 +7,6 @@ runs in the hand-written kernels under gnn_hex_amd/csrc; there is no eager/PyTor
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -780,50 +779,8 @@ class _QNetCall:
 _HP_CACHE = {}
 
 
-_SIDE_STREAMS = {}
-_PARALLEL_PACK = os.environ.get("HEXGNN_NO_PARALLEL_PACK", "0") != "1"     # (switch for A/B runs)
-
-
-def qnet_sizes(cache: QNetParamCache, n: int, b: int, c_in: int, hidden: int, tot: int):
-    """(hp, acts bytes, pack bytes, saved bytes, backward workspace bytes) of the fused calls, cached per batch shape."""
-    sizes = cache.sizes.get((n, b))
-    if sizes is None:
-        L = _lib.lib()
-        hp = padded_width(hidden)
-        a_bytes = (4 * tot * n * hp + 255) & ~255
-        w_bytes = (L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot) + 255) & ~255
-        s_bytes = L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot)
-        ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
-        if len(cache.sizes) > 64:
-            cache.sizes.clear()
-        sizes = cache.sizes[(n, b)] = (hp, a_bytes, w_bytes, max(s_bytes, 16), max(ws_bytes, 16))
-    return sizes
-
-
-def qnet_prepack(cache: QNetParamCache, n: int, b: int, c_in: int, hidden: int, tot: int, device):
-    """Under a HIP-graph capture: allocate the forward's [acts | wpack | saved] buffer NOW and run the weight pack on a second
-    stream, forked from the current one -- the caller issues the batch's CSR build on the current stream meanwhile and joins
-    with ``qnet_prepack_join`` (the two become parallel branches of the captured step: the 5-us pack hides behind the 12-us
-    CSR build).  Exact fp32 math only.  Returns the handle ``qnet_direct_forward`` takes as ``pre``."""
-    hp, a_bytes, w_bytes, s_bytes, ws_bytes = qnet_sizes(cache, n, b, c_in, hidden, tot)
-    buf = torch.empty(a_bytes + w_bytes + s_bytes, dtype=torch.uint8, device=device)
-    key = (device.type, device.index)
-    side = _SIDE_STREAMS.get(key)
-    if side is None:
-        side = _SIDE_STREAMS[key] = torch.cuda.Stream(device=device)
-    cur = torch.cuda.current_stream(device)
-    side.wait_stream(cur)
-    _lib.check(_lib.lib().hexgnn_qnet_pack(c_in, hidden, tot, cache.wl, cache.bl, cache.wr, buf.data_ptr() + a_bytes,
-                                           side.cuda_stream), "hexgnn_qnet_pack")
-    return buf, side
-
-
-def qnet_prepack_join(pre) -> None:
-    torch.cuda.current_stream(pre[0].device).wait_stream(pre[1])
-
-
 def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: int, c_in: int, hidden: int, body_layers: int,
-                        head_layers: int, mode: int, need_bwd: bool, layered: bool = False, pre=None):
+                        head_layers: int, mode: int, need_bwd: bool, layered: bool = False):
     """Launch the fused forward with cached pointer arrays; returns (q, out_v, call) -- ``call`` feeds QNetDirectFn.
     ``gptr`` may be None when ``gs`` comes from ``GraphStructure.grouped`` (it carries the pointer).  ``layered``: the same
     network on the layer-major kernels (graphs above 128 nodes, hidden 113..128): body and head SAGE layers as ONE stack +
@@ -837,9 +794,19 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     if x.dtype != torch.float32 or x.stride(1) != 1:
         x = x.float().contiguous()
     x_stride = x.stride(0) if n > 0 else c_in
-    hp, a_bytes, w_bytes, s_bytes, ws_bytes = qnet_sizes(cache, n, b, c_in, hidden, tot)
-    # [acts | wpack | saved] in ONE allocation (256-byte aligned parts); `pre`: allocated and packed by qnet_prepack
-    buf = pre[0] if pre is not None else torch.empty(a_bytes + w_bytes + s_bytes, dtype=torch.uint8, device=dev)
+    sizes = cache.sizes.get((n, b))
+    if sizes is None:
+        hp = padded_width(hidden)
+        a_bytes = (4 * tot * n * hp + 255) & ~255
+        w_bytes = (L.hexgnn_sage_stack_pack_bytes(c_in, hidden, tot) + 255) & ~255
+        s_bytes = L.hexgnn_qnet_saved_bytes(n, b, c_in, hidden, tot)
+        ws_bytes = L.hexgnn_qnet_backward_workspace_bytes(n, b, c_in, hidden, tot)
+        if len(cache.sizes) > 64:
+            cache.sizes.clear()
+        sizes = cache.sizes[(n, b)] = (hp, a_bytes, w_bytes, max(s_bytes, 16), max(ws_bytes, 16))
+    hp, a_bytes, w_bytes, s_bytes, ws_bytes = sizes
+    # [acts | wpack | saved] in ONE allocation (256-byte aligned parts)
+    buf = torch.empty(a_bytes + w_bytes + s_bytes, dtype=torch.uint8, device=dev)
     base = buf.data_ptr()
     q = torch.empty(n, dtype=torch.float32, device=dev)
     out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
@@ -851,8 +818,7 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     stream = _stream()
     _lib.check(L.hexgnn_qnet_forward(
         n, b, c_in, hidden, tot, mode, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, cache.wl, cache.bl, cache.wr,
-        t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes,
-        int(need_bwd) | (2 if pre is not None else 0), body_layers - 1,
+        t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), body_layers - 1,
         _MATH, q.data_ptr(), out_v.data_ptr() if out_v is not None else None, gp[6], stream), "hexgnn_qnet_forward")
     call = _QNetCall()
     call.cache, call.gs, call.gptr, call.x = cache, gs, gptr, x

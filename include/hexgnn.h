@@ -220,12 +220,6 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
                         int math,
                         float* q /*[n]*/, float* out_v /*[b] (mode 1) or NULL*/, int* status /*[1], caller-zeroed*/,
                         hexgnn_stream_t stream);
-/* The weight pack of hexgnn_qnet_forward as a call of its own (exact fp32 math only), so that a host can run it on a second
- * stream beside the CSR build of the same batch (parallel branches of a captured step); the forward call is then given
- * need_backward | HEXGNN_QNET_PREPACKED and the same wpack. */
-#define HEXGNN_QNET_PREPACKED 2
-int hexgnn_qnet_pack(int c_in, int hidden, int total_layers, const float* const* wl, const float* const* bl,
-                     const float* const* wr, void* wpack, hexgnn_stream_t stream);
 size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, int total_layers);
 /* d_embeds: optional [n][HP] gradient w.r.t. the output of body layer body_layers-1 (final_conv_grads). */
 int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
