@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
 _lib = None
-ABI_VERSION = 3          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
+ABI_VERSION = 4          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
 
 vp = C.c_void_p
 ci = C.c_int
@@ -51,6 +51,13 @@ _SIGS = {
     "hexgnn_graph_layernorm_workspace_bytes": (sz, [ci]),
     "hexgnn_graph_layernorm_forward": (ci, [ci, ci, vp, vp, vp, C.c_float, ci, vp, vp, vp, sz, vp]),
     "hexgnn_graph_layernorm_backward": (ci, [ci, ci, vp, vp, vp, vp, vp, C.c_float, ci, vp, vp, vp, vp, sz, vp]),
+    "hexgnn_graph_colnorm_workspace_bytes": (sz, [ci]),
+    "hexgnn_graph_colnorm_forward": (ci, [ci, ci, vp, vp, vp, vp, C.c_float, ci, ci, vp, vp, vp, sz, vp]),
+    "hexgnn_graph_colnorm_backward": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, C.c_float, ci, ci, vp, vp, vp, vp, vp, sz, vp]),
+    "hexgnn_head_linear_saved_bytes": (sz, [ci, ci]),
+    "hexgnn_head_linear_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_head_linear_backward_workspace_bytes": (sz, [ci, ci, ci]),
+    "hexgnn_head_linear_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "hexgnn_qnet_supported": (ci, [ci, ci, ci]),
     "hexgnn_qnet_saved_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_forward": (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,

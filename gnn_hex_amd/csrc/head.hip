@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
     const int g = blockIdx.x;
     const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
     const int tid = threadIdx.x;
-    const int H2 = H / 2, H4 = 4 * H;
+    const int H2 = H / 2;
     __shared__ float s_lw[128];
     if (tid < 128) s_lw[tid] = tid < H ? lin_w[tid] : 0.f;      // visible after the barrier in front of the row loops
 
@@ -384,6 +384,165 @@ __global__ __launch_bounds__(64) void head_lin_grad_reduce_kernel(int b, int hp,
     for (int g = lane; g < b; g += 64) s += part[(size_t)g * (hp + 1) + src];
     s = wave_sum(s);
     if (lane == 0) { if (c < H) d_lin_w[c] = s; else d_lin_b[0] = s; }
+}
+
+// ---- head tail of the two_headed family (GN0/models.py:901-918): value_head_type="linear" over value_aggr_types=("mean",),
+// i.e. value_g = Linear(H,1)(mean_{i in g} h_i) = mean_i(val_w . h_i) + val_b (HeadNetwork.forward, GN0/models.py:374-384),
+// same advantage linear and the same dueling combine / modes as the MLP tail above.  One workgroup per graph, four lanes
+// per row; saved = adv_raw [n] | vraw [b].
+struct HeadLinSaved { size_t adv_off, v_off, total; };
+static HeadLinSaved head_lin_saved_plan(int n, int b) {
+    HeadLinSaved s;
+    size_t off = 0;
+    s.adv_off = off; off += align_up(sizeof(float) * (size_t)n, 256);
+    s.v_off = off; off += align_up(sizeof(float) * (size_t)b, 256);
+    s.total = off;
+    return s;
+}
+struct HeadLinWs { size_t dvr_off, lpart_off, vpart_off, total; };
+static HeadLinWs head_lin_ws_plan(int b, int hidden) {
+    HeadLinWs w;
+    const int hp = padded_width(hidden);
+    size_t off = 0;
+    w.dvr_off = off; off += align_up(sizeof(float) * (size_t)(b > 0 ? b : 1), 256);
+    w.lpart_off = off; off += align_up(sizeof(float) * (size_t)(b > 0 ? b : 1) * (hp + 1), 256);
+    w.vpart_off = off; off += align_up(sizeof(float) * (size_t)(b > 0 ? b : 1) * (hp + 1), 256);
+    w.total = off;
+    return w;
+}
+
+__global__ __launch_bounds__(256) void head_linear_fwd_kernel(
+    int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ h, const float* __restrict__ lin_w,
+    const float* __restrict__ lin_b, const float* __restrict__ val_w, const float* __restrict__ val_b,
+    float* __restrict__ q, float* __restrict__ out_v, float* __restrict__ adv_raw, float* __restrict__ vraw) {
+    __shared__ __attribute__((aligned(16))) float s_w[128], s_vw[128];
+    __shared__ float s_red[4];
+    const int g = blockIdx.x;
+    const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
+    const int tid = threadIdx.x;
+    const bool has_value = mode != 2 && mode != 4;
+    if (tid < 128) { s_w[tid] = tid < H ? lin_w[tid] : 0.f; s_vw[tid] = (has_value && tid < H) ? val_w[tid] : 0.f; }
+    __syncthreads();
+    const float lb = lin_b[0];
+    float tsum = 0.f, usum = 0.f;
+    const int sub = tid & 3, q4n = hp / 4;
+    for (int row = r0 + (tid >> 2); row < r1; row += 64) {
+        const f32x4* hr = reinterpret_cast<const f32x4*>(h + (size_t)row * hp);
+        float a = 0.f, u = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int c = sub + 4 * k;
+            if (c < q4n) {
+                const f32x4 hv = hr[c], ww = reinterpret_cast<const f32x4*>(s_w)[c], vw = reinterpret_cast<const f32x4*>(s_vw)[c];
+                a += hv[0] * ww[0] + hv[1] * ww[1] + hv[2] * ww[2] + hv[3] * ww[3];
+                u += hv[0] * vw[0] + hv[1] * vw[1] + hv[2] * vw[2] + hv[3] * vw[3];
+            }
+        }
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+        u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
+        if (sub == 0) {
+            a += lb;
+            adv_raw[row] = a;
+            const float t = 2.f * tanhf(a);
+            tsum += t;
+            usum += u;
+            if (mode == 2) q[row] = t;
+            if (mode >= 3) q[row] = a;
+        }
+    }
+    if (!has_value) return;
+    const float adv_total = block_sum_256(tsum, s_red);
+    const float u_total = block_sum_256(usum, s_red);
+    const float v = u_total / (float)max(cnt, 1) + val_b[0];       // (an empty graph pools to zeros)
+    if (tid == 0) vraw[g] = v;
+    const float V = mode == 3 ? v : tanhf(v);
+    if ((mode == 1 || mode == 3) && tid == 0) out_v[g] = V;
+    if (mode == 3) return;
+    const float mean_adv = adv_total / (float)max(cnt, 1);
+    if (sub == 0) {
+        for (int row = r0 + (tid >> 2); row < r1; row += 64) {
+            const float t = 2.f * tanhf(adv_raw[row]);
+            q[row] = (mode == 0 ? V : 0.f) + t - mean_adv;
+        }
+    }
+}
+
+// dh = dar * lin_w + (dv / cnt) * val_w;  per-graph partials lpart[g] = (sum_rows dar h | sum dar),
+// vpart[g] = ((dv / cnt) sum_rows h | dv)
+__global__ __launch_bounds__(256) void head_linear_bwd_kernel(
+    int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ h, const float* __restrict__ lin_w,
+    const float* __restrict__ val_w, const float* __restrict__ adv_raw, const float* __restrict__ vraw,
+    const float* __restrict__ dq, const float* __restrict__ d_out_v, float* __restrict__ dh, float* __restrict__ dvr,
+    float* __restrict__ lpart, float* __restrict__ vpart, int mask_dh) {
+    __shared__ float s_lw[128], s_vw[128];
+    __shared__ float s_red[4];
+    __shared__ float s_acc[2][129];
+    const int g = blockIdx.x;
+    const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
+    const int tid = threadIdx.x;
+    const bool has_value = mode != 2 && mode != 4, raw = mode >= 3;
+    if (tid < 128) { s_lw[tid] = tid < H ? lin_w[tid] : 0.f; s_vw[tid] = (has_value && tid < H) ? val_w[tid] : 0.f; }
+    const float inv_cnt = 1.f / (float)max(cnt, 1);
+    float mean_dq = 0.f, dvn = 0.f, dv = 0.f;
+    if (has_value) {
+        float ps = 0.f;
+        for (int row = r0 + tid; row < r1; row += 256) ps += dq[row];
+        const float sdq = block_sum_256(ps, s_red);
+        mean_dq = raw ? 0.f : sdq * inv_cnt;
+        const float dV = mode == 0 ? sdq : d_out_v[g];
+        dv = raw ? dV : dV * sech2f(vraw[g]);
+        if (tid == 0) dvr[g] = dv;
+        dvn = cnt > 0 ? dv * inv_cnt : 0.f;
+    }
+    __syncthreads();
+    {
+        const int sub = tid & 3, q4n = hp / 4;
+        for (int row = r0 + (tid >> 2); row < r1; row += 64) {
+            const float dar = raw ? dq[row] : (dq[row] - mean_dq) * 2.f * sech2f(adv_raw[row]);
+            f32x4* dr = reinterpret_cast<f32x4*>(dh + (size_t)row * hp);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int qq = sub + 4 * k;
+                if (qq < q4n) {
+                    f32x4 v;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = 4 * qq + j;
+                        v[j] = c < H ? dar * s_lw[c] + dvn * s_vw[c] : 0.f;
+                    }
+                    if (mask_dh) {
+                        const f32x4 hv = reinterpret_cast<const f32x4*>(h + (size_t)row * hp)[qq];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = hv[j] > 0.f ? v[j] : 0.f;
+                    }
+                    dr[qq] = v;
+                }
+            }
+        }
+    }
+    {   // column c = tid & 127, two row phases, fixed order
+        const int c = tid & 127, ph = tid >> 7;
+        float acc = 0.f, accb = 0.f, hs = 0.f;
+        for (int row = r0 + ph; row < r1; row += 2) {
+            const float dar = raw ? dq[row] : (dq[row] - mean_dq) * 2.f * sech2f(adv_raw[row]);
+            const float hv = c < hp ? h[(size_t)row * hp + c] : 0.f;
+            acc += dar * hv;
+            hs += hv;
+            accb += dar;
+        }
+        if (ph == 1) { s_acc[0][c] = acc; s_acc[1][c] = hs; if (c == 0) s_acc[0][128] = accb; }
+        __syncthreads();
+        if (ph == 0) {
+            if (c < hp) {
+                lpart[(size_t)g * (hp + 1) + c] = acc + s_acc[0][c];
+                vpart[(size_t)g * (hp + 1) + c] = dvn * (hs + s_acc[1][c]);
+            }
+            if (c == 0) {
+                lpart[(size_t)g * (hp + 1) + hp] = accb + s_acc[0][128];
+                vpart[(size_t)g * (hp + 1) + hp] = dv;
+            }
+        }
+    }
 }
 
 int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const float* dvr, const float* pooled,
@@ -695,6 +854,65 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
                                            dh, dadv, dz, dvr, part, mask_dh);
     launch_head_param_grads(b, hidden, mode, dz, dvr, (const float*)(sv + s.pooled_off), (const float*)(sv + s.z_off),
                             part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b, st);
+    return check_launch();
+}
+
+size_t hexgnn_head_linear_saved_bytes(int n, int b) {
+    if (n < 0 || b < 0) return 0;
+    return head_lin_saved_plan(n, b).total;
+}
+
+int hexgnn_head_linear_forward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
+                               const float* lin_b, const float* val_w, const float* val_b, float* q, float* out_v,
+                               void* saved, hexgnn_stream_t stream_) {
+    const int hp = padded_width(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
+    if (!gptr || !lin_w || !lin_b || !saved) return HEXGNN_EINVAL;
+    if (mode != 2 && mode != 4 && (!val_w || !val_b)) return HEXGNN_EINVAL;
+    if ((mode == 1 || mode == 3) && !out_v) return HEXGNN_EINVAL;
+    if (n > 0 && (!h || !q)) return HEXGNN_EINVAL;
+    if (b == 0) return HEXGNN_OK;
+    const HeadLinSaved s = head_lin_saved_plan(n, b);
+    char* sv = (char*)saved;
+    head_linear_fwd_kernel<<<b, 256, 0, (hipStream_t)stream_>>>(hidden, hp, mode, gptr, h, lin_w, lin_b, val_w, val_b, q, out_v,
+                                                               (float*)(sv + s.adv_off), (float*)(sv + s.v_off));
+    return check_launch();
+}
+
+size_t hexgnn_head_linear_backward_workspace_bytes(int n, int b, int hidden) {
+    if (n < 0 || b < 0 || padded_width(hidden) < 0) return 0;
+    return head_lin_ws_plan(b, hidden).total;
+}
+
+int hexgnn_head_linear_backward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
+                                const float* val_w, const void* saved, const float* dq, const float* d_out_v, float* dh,
+                                float* d_lin_w, float* d_lin_b, float* d_val_w, float* d_val_b, void* workspace,
+                                size_t workspace_bytes, hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    const int hp = padded_width(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    const int mask_dh = (mode & HEXGNN_HEAD_MASK_DH) ? 1 : 0;
+    mode &= ~HEXGNN_HEAD_MASK_DH;
+    if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
+    if (!gptr || !lin_w || !saved || !d_lin_w || !d_lin_b) return HEXGNN_EINVAL;
+    const bool has_value = mode != 2 && mode != 4;
+    if (has_value && (!val_w || !d_val_w || !d_val_b)) return HEXGNN_EINVAL;
+    if ((mode == 1 || mode == 3) && !d_out_v) return HEXGNN_EINVAL;
+    if (n > 0 && (!h || !dq || !dh)) return HEXGNN_EINVAL;
+    const HeadLinWs w = head_lin_ws_plan(b, hidden);
+    if (!workspace || workspace_bytes < w.total) return HEXGNN_EWORKSPACE;
+    const HeadLinSaved s = head_lin_saved_plan(n, b);
+    const char* sv = (const char*)saved;
+    char* ws = (char*)workspace;
+    float* lpart = (float*)(ws + w.lpart_off);
+    float* vpart = (float*)(ws + w.vpart_off);
+    if (b > 0)
+        head_linear_bwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, h, lin_w, val_w, (const float*)(sv + s.adv_off),
+                                                  (const float*)(sv + s.v_off), dq, d_out_v, dh, (float*)(ws + w.dvr_off),
+                                                  lpart, vpart, mask_dh);
+    head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, lpart, d_lin_w, d_lin_b);
+    if (has_value) head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, vpart, d_val_w, d_val_b);
     return check_launch();
 }
 

@@ -13,8 +13,12 @@ kernels like a plain Linear; autograd carries the kernel's gradient back to ``mu
 ``--norm=True`` (torch_geometric LayerNorm, which the model calls in its whole-batch "graph" form, GN0/models.py:286-287,
 550-551,935,945) runs on the layer-major kernels: one SAGE layer without ReLU, then the ``hexgnn_graph_layernorm`` kernels
 with the ReLU fused; a batch-global statistic rules the per-graph fused kernels out.
-Out of scope here (raise NotImplementedError): CachedGraphNorm (``cached_norm=True``, never set by this factory) and the
-other model families of the reference factory; all BASELINE configs run ``--norm=False --noisy_dqn=False`` (README.md:5,7).
+``get_pre_defined("two_headed")`` (GN0/models.py:901-918: CachedGraphNorm with ``cached_norm=True``, linear value head over
+mean pooling) runs on the same layer-major kernels, one SAGE layer + one ``hexgnn_graph_colnorm`` call per layer, with the
+statistics cache of the reference (``set_cache`` / ``export_norm_cache`` / ``import_norm_cache``).
+Out of scope here (raise NotImplementedError): the other model families of the reference factory (CNN, PNA, Unet, Gao, the
+single-headed Duelling / ActionValue / PolicyValue variants); all BASELINE configs run ``modern_two_headed`` with
+``--norm=False --noisy_dqn=False`` (README.md:5,7).
 """
 from __future__ import annotations
 
@@ -154,6 +158,49 @@ class LayerNorm(torch.nn.Module):
         return "%s(%d, mode=%s)" % (self.__class__.__name__, self.in_channels, self.mode)
 
 
+class CachedGraphNorm(torch.nn.Module):
+    """GN0/models.py:644-670: torch_geometric GraphNorm (weight, bias, mean_scale; eps added to the VARIANCE) plus a cache of
+    the statistics.  The model calls it without a batch vector (GN0/models.py:282-283, 550-551), i.e. the whole batch is one
+    graph: per-channel mean and variance over all nodes.  ``set_cache`` stores the statistics of this call
+    (``mean_cache`` / ``var_cache``, shape [1, C] as scatter_mean returns them); ``use_cache and not set_cache`` normalises
+    with the stored ones.  Evaluated by the ``hexgnn_graph_colnorm_*`` kernels; ``_relu`` fuses CachifiedGNN's activation."""
+
+    supports_cache = True
+
+    def __init__(self, in_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.in_channels = in_channels
+        self.eps = eps
+        self.weight = torch.nn.Parameter(torch.ones(in_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = torch.nn.Parameter(torch.ones(in_channels))
+        self.mean_cache = None
+        self.var_cache = None
+
+    def reset_parameters(self):
+        torch.nn.init.ones_(self.weight)
+        torch.nn.init.zeros_(self.bias)
+        torch.nn.init.ones_(self.mean_scale)
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, set_cache=False, use_cache=False,
+                _relu: bool = False) -> Tensor:
+        if batch is not None:
+            raise NotImplementedError("CachedGraphNorm with a batch vector is not on the model's path (GN0/models.py:283)")
+        cache = None
+        if use_cache and not set_cache:
+            if self.mean_cache is None or self.var_cache is None:
+                raise RuntimeError("CachedGraphNorm: use_cache without a cache (run a set_cache forward or import_norm_cache)")
+            cache = torch.cat([self.mean_cache.reshape(1, -1), self.var_cache.reshape(1, -1)]).detach()
+        y, stats = ops.graph_colnorm(x, self.weight, self.bias, self.mean_scale, self.eps, _relu, cache)
+        if set_cache:
+            self.mean_cache = stats[0:1].clone()
+            self.var_cache = stats[1:2].clone()
+        return y
+
+    def __repr__(self):
+        return "%s(%d)" % (self.__class__.__name__, self.in_channels)
+
+
 class SAGEConv(torch.nn.Module):
     """Parameter holder for pyg SAGEConv(aggr='mean', root_weight=True, bias=True): ``lin_l`` (with bias)
     acts on the neighbour mean, ``lin_r`` (no bias) on the root (GN0/torch_script_models.py:52-73)."""
@@ -186,8 +233,9 @@ class GraphSAGE(torch.nn.Module):
     def __init__(self, in_channels: int, hidden_channels: int, num_layers: int, out_channels: Optional[int] = None,
                  dropout: float = 0.0, act="relu", norm=None, jk=None, **kwargs):
         super().__init__()
-        if norm is not None and not isinstance(norm, LayerNorm):
-            raise NotImplementedError("only norm=None or the LayerNorm of --norm=True (GN0/models.py:935,945)")
+        if norm is not None and not isinstance(norm, (LayerNorm, CachedGraphNorm)):
+            raise NotImplementedError("only norm=None, the LayerNorm of modern_two_headed --norm=True (GN0/models.py:935,945) "
+                                      "or the CachedGraphNorm of two_headed (GN0/models.py:908,916)")
         if act != "relu" or jk is not None or dropout != 0.0:
             raise NotImplementedError("only act='relu', jk=None, dropout=0 (the modern_two_headed configuration)")
         self.in_channels = in_channels
@@ -253,8 +301,9 @@ def cachify_gnn(gnn):
             self.has_cache = False
             if self.has_output:
                 raise NotImplementedError("out_channels != None (linear last layer) is not on the hot path")
-            if cached_norm:
-                raise NotImplementedError("cached_norm=True (CachedGraphNorm) is not used by modern_two_headed")
+            if cached_norm and self.norms is not None and not isinstance(self.norms[0] if len(self.norms) else kwargs["norm"],
+                                                                         CachedGraphNorm):
+                raise NotImplementedError("cached_norm=True needs a CachedGraphNorm (GN0/models.py:282-283)")
             if self.norms is not None:      # final norm after the last hidden layer (GN0/models.py:158-162)
                 self.norms.append(copy.deepcopy(self.norms[0] if len(self.norms) > 0 else kwargs["norm"]))
 
@@ -315,22 +364,42 @@ def cachify_gnn(gnn):
             self.out_channels = new_width
 
         def export_norm_cache(self):
+            """GN0/models.py:165-174: (stack of mean caches, stack of var caches), [layers, 1, C] each."""
             if self.norms is None:
                 return
-            assert self.has_cache       # as the reference: only a cached norm (never built here) ever sets it
-            raise NotImplementedError
+            assert self.has_cache
+            return (torch.stack([norm.mean_cache for norm in self.norms]),
+                    torch.stack([norm.var_cache for norm in self.norms]))
 
         def import_norm_cache(self, mean_cache, var_cache):
+            """GN0/models.py:176-182."""
             if self.norms is None or not self.cached_norm:
                 return
-            raise NotImplementedError
+            self.has_cache = True
+            for i, norm in enumerate(self.norms):
+                norm.mean_cache = mean_cache[i].to(norm.weight.device)
+                norm.var_cache = var_cache[i].to(norm.weight.device)
 
         def forward(self, x: Tensor, edge_index, *, edge_weight=None, edge_attr=None, set_cache: bool = False,
                     _graph: Optional[ops.GraphStructure] = None) -> Tensor:
             """conv -> [norm] -> relu for every layer (GN0/models.py:261-294 with has_output False)."""
             gs = _graph if _graph is not None else ops.GraphStructure(edge_index, x.shape[0])
+            if set_cache and self.cached_norm:
+                self.has_cache = True
             if self.norms is None:
                 return ops.sage_stack(x, gs, self.in_channels, self.hidden_channels, self.convs)
+            if isinstance(self.norms[0], CachedGraphNorm):
+                # two_headed family: conv -> CachedGraphNorm -> relu per layer (GN0/models.py:261-294), one SAGE layer without
+                # ReLU + one per-channel norm call with the ReLU fused; the cache flags exactly as the reference passes them
+                use_cache = self.has_cache and not self.training
+                for i in range(self.num_layers):
+                    c_in = self.in_channels if i == 0 else self.hidden_channels
+                    x = ops.sage_stack(x, gs, c_in, self.hidden_channels, [self.convs[i]], linear_last=True)
+                    if self.cached_norm:
+                        x = self.norms[i](x, set_cache=set_cache, use_cache=use_cache, _relu=True)
+                    else:
+                        x = self.norms[i](x, _relu=True)
+                return x
             # --norm=True: the whole-batch statistics sit between a layer's contraction and its activation: SAGE layer
             # without ReLU, then LayerNorm with the ReLU fused, layer by layer inside one call per direction
             # (convs[i](x, edge_index) and norms[i](x) on their own remain available as modules)
@@ -345,13 +414,20 @@ class HeadNetwork(torch.nn.Module):
     def __init__(self, in_channels, hidden_channels, out_channels, GNN, value_head_type="linear",
                  value_aggr_types=("mean",), noisy_dqn=True, noise_sigma=0, **gnn_kwargs):
         super().__init__()
-        if value_head_type != "mlp" or tuple(value_aggr_types) != ("sum", "max", "min", "mean") or out_channels != 1:
-            raise NotImplementedError("head kernel implements value_head_type='mlp' over (sum,max,min,mean), out=1")
+        value_aggr_types = tuple(value_aggr_types)
+        mlp4 = value_head_type == "mlp" and value_aggr_types == ("sum", "max", "min", "mean")     # modern_two_headed
+        lin1 = value_head_type == "linear" and value_aggr_types == ("mean",)                       # two_headed
+        if not (mlp4 or lin1) or out_channels != 1:
+            raise NotImplementedError("head kernels implement value_head_type='mlp' over (sum,max,min,mean) and "
+                                      "value_head_type='linear' over (mean,), out=1")
         self.gnn = GNN(in_channels=in_channels, hidden_channels=hidden_channels, **gnn_kwargs)
         self.supports_cache = hasattr(self.gnn, "supports_cache") and self.gnn.supports_cache
         self.value_head_type = value_head_type
         self.hidden_channels = hidden_channels
-        self.value_head = MLP(self.hidden_channels // 2, 1, self.hidden_channels * len(value_aggr_types), 1)
+        if value_head_type == "linear":
+            self.value_head = Linear(self.hidden_channels * len(value_aggr_types), 1)
+        else:
+            self.value_head = MLP(self.hidden_channels // 2, 1, self.hidden_channels * len(value_aggr_types), 1)
         self.out_channels = out_channels
         self.value_aggr_types = value_aggr_types
         if noisy_dqn:
@@ -374,7 +450,14 @@ class HeadNetwork(torch.nn.Module):
         self.linear.weight.data.fill_(0)
         self.linear.weight.data[:, :self.hidden_channels] = old.weight.data
         self.linear.bias.data[:] = old.bias.data[:]
-        self.value_head.grow_input_width(new_width * len(self.value_aggr_types), new_width // 2)
+        if self.value_head_type == "linear":       # GN0/models.py:348-353
+            old_head = self.value_head
+            self.value_head = Linear(new_width, self.out_channels).to(old_head.weight.device)
+            self.value_head.weight.data.fill_(0)
+            self.value_head.weight.data[:, :self.hidden_channels] = old_head.weight.data
+            self.value_head.bias.data[:] = old_head.bias.data[:]
+        else:
+            self.value_head.grow_input_width(new_width * len(self.value_aggr_types), new_width // 2)
         self.hidden_channels = new_width
 
     def grow_depth(self, additional_layers):
@@ -389,6 +472,8 @@ class HeadNetwork(torch.nn.Module):
     def _tail(self, x, gptr, b, mode):
         vh = self.value_head
         lin_w, lin_b = self._lin_params()
+        if self.value_head_type == "linear":
+            return ops.HeadLinearTailFn.apply(x, gptr, b, self.hidden_channels, mode, lin_w, lin_b, vh.weight, vh.bias)
         return ops.HeadTailFn.apply(x, gptr, b, self.hidden_channels, mode, lin_w, lin_b,
                                     vh.layers[0].weight, vh.layers[0].bias, vh.layers[1].weight, vh.layers[1].bias)
 
@@ -608,6 +693,11 @@ class DuellingTwoHeaded(torch.nn.Module):
         first = convs["0"]._modules["lin_l"]._parameters["weight"]
         last = hconvs[str(len(hconvs) - 1)]._modules["lin_r"]._parameters["weight"] if len(hconvs) else first
         sig = (len(convs), len(hconvs), id(first), id(lin0), id(last), gnn.hidden_channels, gnn.norms is None)
+        if (ent is None or ent[0] != sig) and head.value_head_type != "mlp":
+            # two_headed family (linear value head): per-module composition on the layer-major kernels only
+            ent = (sig, [], None, (self.gnn.in_channels, self.gnn.hidden_channels, len(self.gnn.convs), len(head.gnn.convs),
+                                   False, isinstance(head.linear, FactorizedNoisyLinear)))
+            cache[key] = ent
         if ent is None or ent[0] != sig:
             params = []
             for conv in list(self.gnn.convs) + list(head.gnn.convs):
@@ -638,7 +728,18 @@ class DuellingTwoHeaded(torch.nn.Module):
 
 
 def get_pre_defined(name, args: Optional[Namespace] = None) -> torch.nn.Module:
-    """GN0/models.py:892-980.  Only ``modern_two_headed`` (the RainbowDQN GNN of README.md:5,7) is built."""
+    """GN0/models.py:892-980: ``modern_two_headed`` (the RainbowDQN GNN of README.md:5,7) and its predecessor ``two_headed``
+    (CachedGraphNorm with the statistics cache, linear value head over mean pooling)."""
+    if name == "two_headed":
+        use_norm = bool(getattr(args, "norm", False))
+        return DuellingTwoHeaded(
+            cachify_gnn(GraphSAGE), HeadNetwork,
+            gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
+                            cached_norm=True, norm=CachedGraphNorm(args.hidden_channels) if use_norm else None, act="relu"),
+            head_kwargs=dict(GNN=cachify_gnn(GraphSAGE),
+                             num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2,
+                             noisy_dqn=args.noisy_dqn, noise_sigma=args.noisy_sigma0, cached_norm=True,
+                             norm=CachedGraphNorm(args.hidden_channels) if use_norm else None, act="relu"))
     if name == "modern_two_headed":
         use_norm = bool(getattr(args, "norm", False))
         return DuellingTwoHeaded(
@@ -651,4 +752,4 @@ def get_pre_defined(name, args: Optional[Namespace] = None) -> torch.nn.Module:
                              noisy_dqn=args.noisy_dqn, noise_sigma=args.noisy_sigma0, cached_norm=False,
                              norm=LayerNorm(args.hidden_channels) if use_norm else None, act="relu"))
     raise NotImplementedError(
-        "%r: only 'modern_two_headed' is part of the MI355X hot path (SURVEY.md section 8)" % (name,))
+        "%r: only 'modern_two_headed' and 'two_headed' are part of the MI355X hot path (SURVEY.md section 8)" % (name,))

@@ -479,6 +479,66 @@ def graph_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, e
     return out
 
 
+class GraphColNormFn(torch.autograd.Function):
+    """CachedGraphNorm (GN0/models.py:644-670) without a batch vector: per-channel mean / variance over ALL nodes of the
+    batch, ``weight * (x - mean * mean_scale) / sqrt(var + eps) + bias``, optional fused ReLU.  ``cache`` = None: fresh
+    statistics (returned as the second output, [2, hidden] = mean | var, not differentiable); ``cache`` = a [2, hidden]
+    tensor: the cached statistics are constants.  C ABI ``hexgnn_graph_colnorm_*``."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, mean_scale, eps: float, relu: bool, cache):
+        L = _lib.lib()
+        hidden = int(x.shape[1])
+        hp = padded_width(hidden)
+        n = int(x.shape[0])
+        xp = as_padded(x, hidden, trust_pads=False)
+        ps = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous()
+              for p in (weight, bias, mean_scale)]
+        y = torch.empty((n, hp), dtype=torch.float32, device=x.device)
+        stats = torch.zeros((2, hp), dtype=torch.float32, device=x.device)
+        use_cache = cache is not None
+        if use_cache:
+            stats[:, :hidden] = cache.reshape(2, hidden).to(device=x.device, dtype=torch.float32)
+        ws_bytes = L.hexgnn_graph_colnorm_workspace_bytes(hidden)
+        ws = _bytes(ws_bytes, x.device)
+        _lib.check(L.hexgnn_graph_colnorm_forward(n, hidden, xp.data_ptr(), ps[0].data_ptr(), ps[1].data_ptr(),
+                                                  ps[2].data_ptr(), float(eps), int(relu), int(use_cache), y.data_ptr(),
+                                                  stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                   "hexgnn_graph_colnorm_forward")
+        ctx.dims = (n, hidden, hp, float(eps), bool(relu), use_cache)
+        ctx.bufs = (xp, y, ps[0], ps[2], stats)
+        out_stats = stats[:, :hidden]
+        ctx.mark_non_differentiable(out_stats)
+        return _logical(y, hidden), out_stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        L = _lib.lib()
+        n, hidden, hp, eps, relu, use_cache = ctx.dims
+        xp, y, w, ms, stats = ctx.bufs
+        dyp = as_padded(dy, hidden, trust_pads=True)
+        dx = torch.empty((n, hp), dtype=torch.float32, device=xp.device)
+        dw = torch.empty(hidden, dtype=torch.float32, device=xp.device)
+        db = torch.empty(hidden, dtype=torch.float32, device=xp.device)
+        dms = torch.empty(hidden, dtype=torch.float32, device=xp.device)
+        ws_bytes = L.hexgnn_graph_colnorm_workspace_bytes(hidden)
+        ws = _bytes(ws_bytes, xp.device)
+        _lib.check(L.hexgnn_graph_colnorm_backward(n, hidden, xp.data_ptr(), y.data_ptr(), w.data_ptr(), ms.data_ptr(),
+                                                   stats.data_ptr(), dyp.data_ptr(), eps, int(relu), int(use_cache),
+                                                   dx.data_ptr(), dw.data_ptr(), db.data_ptr(), dms.data_ptr(),
+                                                   ws.data_ptr(), ws_bytes, _stream()), "hexgnn_graph_colnorm_backward")
+        return _logical(dx, hidden), dw, db, dms, None, None, None
+
+
+def graph_colnorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, mean_scale: torch.Tensor, eps: float = 1e-5,
+                  relu: bool = False, cache: Optional[torch.Tensor] = None):
+    """-> (y [n, hidden], stats [2, hidden] = mean | var as used)."""
+    _require_cuda(x, "x")
+    out, stats = GraphColNormFn.apply(x, weight, bias, mean_scale, eps, relu, cache)
+    out._hexgnn_hp = padded_width(int(x.shape[1]))
+    return out, stats
+
+
 # ------------------------------------------------------------------------------------------------
 # head tail (advantage linear + pooling + value MLP + dueling combine)
 # ------------------------------------------------------------------------------------------------
@@ -537,6 +597,62 @@ class HeadTailFn(torch.autograd.Function):
             g[5].data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "hexgnn_head_backward")
         if mode in (2, 4):   # value path unused: no gradient for the value head (reference: grads stay None)
             g[2] = g[3] = g[4] = g[5] = None
+        return (_logical(dh, hidden), None, None, None, None) + tuple(g)
+
+
+class HeadLinearTailFn(torch.autograd.Function):
+    """The head tail of the ``two_headed`` family: value_head_type="linear" over ("mean",) pooling (GN0/models.py:319-330,
+    374-384), same modes as HeadTailFn.  C ABI ``hexgnn_head_linear_*``."""
+
+    @staticmethod
+    def forward(ctx, h, gptr, b: int, hidden: int, mode: int, lin_w, lin_b, val_w, val_b):
+        L = _lib.lib()
+        dev = h.device
+        n = int(h.shape[0])
+        hp = padded_width(hidden)
+        hpad = as_padded(h, hidden, trust_pads=False)
+        ps = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous()
+              for p in (lin_w, lin_b, val_w, val_b)]
+        q = torch.empty(n, dtype=torch.float32, device=dev)
+        out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode in (1, 3) else None
+        saved = _bytes(L.hexgnn_head_linear_saved_bytes(n, b), dev)
+        _lib.check(L.hexgnn_head_linear_forward(
+            n, b, hidden, mode, gptr.data_ptr(), hpad.data_ptr(), ps[0].data_ptr(), ps[1].data_ptr(), ps[2].data_ptr(),
+            ps[3].data_ptr(), q.data_ptr(), out_v.data_ptr() if out_v is not None else None, saved.data_ptr(), _stream()),
+            "hexgnn_head_linear_forward")
+        ctx.dims = (n, b, hidden, mode, hp)
+        ctx.bufs = (hpad, gptr, saved, ps)
+        if mode in (1, 3):
+            return out_v, q
+        return q
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        L = _lib.lib()
+        n, b, hidden, mode, hp = ctx.dims
+        hpad, gptr, saved, ps = ctx.bufs
+        dev = hpad.device
+        if mode in (1, 3):
+            d_v, dq = gouts
+            if d_v is None:
+                d_v = torch.zeros(b, dtype=torch.float32, device=dev)
+            if dq is None:
+                dq = torch.zeros(n, dtype=torch.float32, device=dev)
+            d_v = d_v.float().contiguous()
+        else:
+            (dq,) = gouts
+            d_v = None
+        dq = dq.float().contiguous()
+        dh = torch.empty((n, hp), dtype=torch.float32, device=dev)
+        g = [torch.empty_like(p) for p in ps]
+        ws_bytes = L.hexgnn_head_linear_backward_workspace_bytes(n, b, hidden)
+        ws = _bytes(ws_bytes, dev)
+        _lib.check(L.hexgnn_head_linear_backward(
+            n, b, hidden, mode, gptr.data_ptr(), hpad.data_ptr(), ps[0].data_ptr(), ps[2].data_ptr(), saved.data_ptr(),
+            dq.data_ptr(), d_v.data_ptr() if d_v is not None else None, dh.data_ptr(), g[0].data_ptr(), g[1].data_ptr(),
+            g[2].data_ptr(), g[3].data_ptr(), ws.data_ptr(), ws_bytes, _stream()), "hexgnn_head_linear_backward")
+        if mode in (2, 4):
+            g[2] = g[3] = None
         return (_logical(dh, hidden), None, None, None, None) + tuple(g)
 
 

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HEXGNN_ABI_VERSION 3
+#define HEXGNN_ABI_VERSION 4
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
@@ -156,6 +156,22 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
                          float* d_v0_w, float* d_v0_b, float* d_v1_w, float* d_v1_b,
                          void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
 
+/* ---- head tail of the `two_headed` family (get_pre_defined("two_headed"), GN0/models.py:901-918): HeadNetwork with
+ *      value_head_type="linear" over value_aggr_types=("mean",) (GN0/models.py:319-330,374-384): value_g = val_w . mean_{i in g} h_i
+ *      + val_b; advantage linear, dueling combine and modes 0..4 exactly as hexgnn_head_forward / _backward above. ---- */
+size_t hexgnn_head_linear_saved_bytes(int n, int b);
+int hexgnn_head_linear_forward(int n, int b, int hidden, int mode, const int* gptr, const float* h /*[n][HP]*/,
+                               const float* lin_w /*[hidden]*/, const float* lin_b /*[1]*/,
+                               const float* val_w /*[hidden]*/, const float* val_b /*[1]*/,
+                               float* q /*[n]*/, float* out_v /*[b] (modes 1, 3) or NULL*/,
+                               void* saved, hexgnn_stream_t stream);
+size_t hexgnn_head_linear_backward_workspace_bytes(int n, int b, int hidden);
+int hexgnn_head_linear_backward(int n, int b, int hidden, int mode /* | HEXGNN_HEAD_MASK_DH */, const int* gptr,
+                                const float* h, const float* lin_w, const float* val_w, const void* saved,
+                                const float* dq, const float* d_out_v, float* dh,
+                                float* d_lin_w, float* d_lin_b, float* d_val_w, float* d_val_b,
+                                void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+
 /* ---- whole-batch LayerNorm (--norm=True): torch_geometric 2.2.0 LayerNorm(hidden, mode="graph") as
  *      CachifiedGNN.forward / DuellingTwoHeaded.forward call it, WITHOUT a batch vector (GN0/models.py:8,286-287,550-551,
  *      935,945): mean and biased std over ALL n x hidden elements, y = (x - mean) / (std + eps) * weight + bias, then the
@@ -170,6 +186,22 @@ int hexgnn_graph_layernorm_backward(int n, int hidden, const float* x, const flo
                                     const float* stats, const float* dy, float eps, int relu, float* dx,
                                     float* d_weight, float* d_bias, void* workspace, size_t workspace_bytes,
                                     hexgnn_stream_t stream);
+
+/* ---- CachedGraphNorm (GN0/models.py:644-670; torch_geometric GraphNorm + a statistics cache) as CachifiedGNN.forward calls
+ *      it, WITHOUT a batch vector (GN0/models.py:282-283): per-CHANNEL statistics over all n nodes of the batch,
+ *          mean_c = mean_i x_ic;  o = x - mean * mean_scale;  var_c = mean_i o_ic^2;  y = weight * o / sqrt(var + eps) + bias,
+ *      then the activation CachifiedGNN applies after the norm (relu != 0).  stats [2][HP] = mean | var: WRITTEN when
+ *      use_cache == 0 (the caller keeps them as mean_cache / var_cache on set_cache), READ when use_cache != 0 (eval mode after
+ *      a set_cache forward: the statistics are constants, also in the backward).  Deterministic (fp64 column partials). ---- */
+size_t hexgnn_graph_colnorm_workspace_bytes(int hidden);
+int hexgnn_graph_colnorm_forward(int n, int hidden, const float* x, const float* weight /*[hidden]*/,
+                                 const float* bias /*[hidden]*/, const float* mean_scale /*[hidden]*/, float eps, int relu,
+                                 int use_cache, float* y, float* stats /*[2][HP]*/,
+                                 void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+int hexgnn_graph_colnorm_backward(int n, int hidden, const float* x, const float* y, const float* weight,
+                                  const float* mean_scale, const float* stats, const float* dy, float eps, int relu,
+                                  int use_cache, float* dx, float* d_weight, float* d_bias, float* d_mean_scale,
+                                  void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
 
 /* ---- SAGE stack with that LayerNorm between every layer's contraction and its ReLU (CachifiedGNN.forward with norms,
  *      GN0/models.py:261-294: x = relu(norm_l(conv_l(x)))): the per-layer sequence above in one call per direction -- weights

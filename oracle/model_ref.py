@@ -18,11 +18,14 @@ on the reference's own call sites:
                                GN0/models.py:8,935,945), mode "graph", called WITHOUT a batch
                                vector (GN0/models.py:286-287,550-551): statistics over all
                                nodes and channels of the batch, eps added to the std
+* ``CachedGraphNormRef``    <- GN0/models.py:644-670 over torch_geometric 2.2.0 ``GraphNorm`` (the ``two_headed``
+                               family, GN0/models.py:901-918; called without a batch vector,
+                               GN0/models.py:282-283: per-channel statistics over all nodes)
 * ``FactorizedNoisyLinearRef`` <- GN0/models.py:84-141 (--noisy_dqn=True: the heads'
                                advantage linear, GN0/models.py:331-334)
 * ``HeadNetworkRef``        <- GN0/models.py:318-384
 * ``DuellingTwoHeadedRef``  <- GN0/models.py:477-590
-* ``get_pre_defined_ref``   <- GN0/models.py:892-947 (``modern_two_headed`` only)
+* ``get_pre_defined_ref``   <- GN0/models.py:892-947 (``modern_two_headed`` and ``two_headed``)
 * ``scatter_ref``           <- torch_scatter 2.1.0 ``scatter`` (sum / mean / max /
                                min over dim 0; mean divides by max(count,1); max/min
                                send their gradient to the FIRST index that attains
@@ -139,6 +142,42 @@ class LayerNormRef(torch.nn.Module):
         return out * self.weight + self.bias
 
 
+class CachedGraphNormRef(torch.nn.Module):
+    """GN0/models.py:644-670 on top of pyg 2.2.0 GraphNorm (weight = 1, bias = 0, mean_scale = 1, eps = 1e-5 inside the
+    square root), statement for statement; scatter_mean restated through scatter_ref."""
+
+    supports_cache = True
+
+    def __init__(self, in_channels: int, eps: float = 1e-5):
+        super().__init__()
+        self.in_channels, self.eps = in_channels, eps
+        self.weight = torch.nn.Parameter(torch.ones(in_channels))
+        self.bias = torch.nn.Parameter(torch.zeros(in_channels))
+        self.mean_scale = torch.nn.Parameter(torch.ones(in_channels))
+        self.mean_cache = None
+        self.var_cache = None
+
+    def forward(self, x: Tensor, batch: Optional[Tensor] = None, set_cache=False, use_cache=False) -> Tensor:
+        if batch is None:
+            batch = x.new_zeros(x.size(0), dtype=torch.long)
+        batch_size = int(batch.max()) + 1
+        if use_cache and not set_cache:
+            mean = self.mean_cache
+        else:
+            mean = scatter_ref(x, batch, dim_size=batch_size, reduce="mean")
+            if set_cache:
+                self.mean_cache = mean
+        out = x - mean.index_select(0, batch) * self.mean_scale
+        if use_cache and not set_cache:
+            var = self.var_cache
+        else:
+            var = scatter_ref(out.pow(2), batch, dim_size=batch_size, reduce="mean")
+            if set_cache:
+                self.var_cache = var
+        std = (var + self.eps).sqrt().index_select(0, batch)
+        return self.weight * out / std + self.bias
+
+
 class GraphSAGERef(torch.nn.Module):
     """BasicGNN layout (torch_script_models.py:118-144) + CachifiedGNN loop (models.py:261-294)."""
 
@@ -162,18 +201,40 @@ class GraphSAGERef(torch.nn.Module):
             c = hidden_channels
         self.convs.append(SAGEConvRef(c, self.out_channels))
         self.norms = None
+        self.cached_norm = cached_norm
+        self.has_cache = False
         if norm is not None:     # BasicGNN: num_layers - 1 norms; CachifiedGNN appends the last one (GN0/models.py:158-162)
-            self.norms = torch.nn.ModuleList(LayerNormRef(hidden_channels) for _ in range(num_layers - 1))
+            make = CachedGraphNormRef if norm == "cached_graph_norm" else LayerNormRef
+            self.norms = torch.nn.ModuleList(make(hidden_channels) for _ in range(num_layers - 1))
             if not self.has_output:
-                self.norms.append(LayerNormRef(hidden_channels))
+                self.norms.append(make(hidden_channels))
+
+    def export_norm_cache(self):                          # GN0/models.py:165-174
+        if self.norms is None:
+            return
+        assert self.has_cache
+        return (torch.stack([n.mean_cache for n in self.norms]), torch.stack([n.var_cache for n in self.norms]))
+
+    def import_norm_cache(self, mean_cache, var_cache):   # GN0/models.py:176-182
+        if self.norms is None or not self.cached_norm:
+            return
+        self.has_cache = True
+        for i, norm in enumerate(self.norms):
+            norm.mean_cache = mean_cache[i]
+            norm.var_cache = var_cache[i]
 
     def forward(self, x: Tensor, edge_index: Tensor, set_cache: bool = False) -> Tensor:
+        if set_cache and self.cached_norm:
+            self.has_cache = True
         for i in range(self.num_layers):
             x = self.convs[i](x, edge_index)
             if i == self.num_layers - 1 and self.has_output:
                 break
-            if self.norms is not None:          # act_first is False: norm, then activation (GN0/models.py:284-291)
-                x = self.norms[i](x)
+            if self.norms is not None:          # act_first is False: norm, then activation (GN0/models.py:281-291)
+                if self.cached_norm:
+                    x = self.norms[i](x, set_cache=set_cache, use_cache=self.has_cache and not self.training)
+                else:
+                    x = self.norms[i](x)
             x = F.relu(x)
         return x
 
@@ -217,10 +278,11 @@ class HeadNetworkRef(torch.nn.Module):
     """GN0/models.py:318-384."""
 
     def __init__(self, in_channels, hidden_channels, out_channels, value_head_type="linear",
-                 value_aggr_types=("mean",), num_layers=2, noisy_dqn=False, noise_sigma=0, norm=None, **_):
+                 value_aggr_types=("mean",), num_layers=2, noisy_dqn=False, noise_sigma=0, norm=None,
+                 cached_norm=False, **_):
         super().__init__()
         self.gnn = GraphSAGERef(in_channels=in_channels, hidden_channels=hidden_channels, num_layers=num_layers,
-                                norm=norm)
+                                norm=norm, cached_norm=cached_norm)
         self.supports_cache = True
         self.value_head_type = value_head_type
         self.hidden_channels = hidden_channels
@@ -235,8 +297,14 @@ class HeadNetworkRef(torch.nn.Module):
         else:
             self.linear = torch.nn.Linear(hidden_channels, out_channels)
 
+    def export_norm_cache(self):
+        return self.gnn.export_norm_cache()
+
+    def import_norm_cache(self, *args):
+        return self.gnn.import_norm_cache(*args)
+
     def forward(self, x, edge_index, graph_indices, advantages_only=False, set_cache=False):
-        x = self.gnn(x, edge_index)
+        x = self.gnn(x, edge_index, set_cache=set_cache)
         advantages = self.linear(x)
         if advantages_only:
             return advantages
@@ -252,7 +320,10 @@ class DuellingTwoHeadedRef(torch.nn.Module):
     def __init__(self, gnn_kwargs, head_kwargs):
         super().__init__()
         self.gnn = GraphSAGERef(**gnn_kwargs)
-        self.after_embed_norm = LayerNormRef(gnn_kwargs["hidden_channels"]) if gnn_kwargs.get("norm") else None
+        self.after_embed_norm = None
+        if gnn_kwargs.get("norm"):
+            make = CachedGraphNormRef if gnn_kwargs["norm"] == "cached_graph_norm" else LayerNormRef
+            self.after_embed_norm = make(gnn_kwargs["hidden_channels"])
         self.supports_cache = True
         self.value_activation = torch.nn.Tanh()
         self.advantage_activation = torch.nn.Tanh()
@@ -273,14 +344,14 @@ class DuellingTwoHeadedRef(torch.nn.Module):
         x = x[:, :2]
         if graph_indices is None:
             graph_indices = x.new_zeros(x.size(0), dtype=torch.long)
-        embeds = self.gnn(x, edge_index)
+        embeds = self.gnn(x, edge_index, set_cache=set_cache)
         if self.after_embed_norm is not None:
             embeds = self.after_embed_norm(embeds)
         self.final_conv_acts = embeds
         if embeds.requires_grad:
             embeds.register_hook(self.activations_hook)
         head = self.maker_head if is_maker == 1 else self.breaker_head
-        head_res = head(embeds, edge_index, graph_indices, advantages_only=advantages_only)
+        head_res = head(embeds, edge_index, graph_indices, advantages_only=advantages_only, set_cache=set_cache)
         if advantages_only:
             return 2 * self.advantage_activation(head_res)
         advantages = 2 * self.advantage_activation(head_res[0])
@@ -292,6 +363,14 @@ class DuellingTwoHeadedRef(torch.nn.Module):
         return (value.index_select(0, graph_indices)
                 + (advantages - adv_means.index_select(0, graph_indices))).squeeze()
 
+    def export_norm_cache(self):                           # GN0/models.py:513-521
+        return [m.export_norm_cache() for m in (self.gnn, self.maker_head, self.breaker_head)]
+
+    def import_norm_cache(self, *args):                    # GN0/models.py:523-535
+        for m, a in zip((self.gnn, self.maker_head, self.breaker_head), args):
+            if a is not None:
+                m.import_norm_cache(*a)
+
     def simple_forward(self, data):
         if hasattr(data, "batch") and data.batch is not None:
             return self.forward(data.x, data.edge_index, data.batch, getattr(data, "ptr", None))
@@ -299,7 +378,15 @@ class DuellingTwoHeadedRef(torch.nn.Module):
 
 
 def get_pre_defined_ref(name: str, args: Optional[Namespace] = None) -> torch.nn.Module:
-    """GN0/models.py:892-947, ``modern_two_headed`` branch only."""
+    """GN0/models.py:892-947, the ``modern_two_headed`` and ``two_headed`` branches."""
+    if name == "two_headed":                               # GN0/models.py:901-918
+        norm = "cached_graph_norm" if getattr(args, "norm", False) else None
+        return DuellingTwoHeadedRef(
+            gnn_kwargs=dict(in_channels=2, num_layers=args.num_layers, hidden_channels=args.hidden_channels,
+                            cached_norm=True, norm=norm, act="relu"),
+            head_kwargs=dict(num_layers=args.num_head_layers if hasattr(args, "num_head_layers") else 2,
+                             noisy_dqn=getattr(args, "noisy_dqn", False), noise_sigma=getattr(args, "noisy_sigma0", 0.5),
+                             cached_norm=True, norm=norm))
     if name != "modern_two_headed":
         raise NotImplementedError(name)
     norm = True if getattr(args, "norm", False) else None

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), "libhexgnn.so does not export %s" % name
     assert set(declared) == set(_lib.exported_symbols()), "ctypes signature table out of sync with the header"
-    assert L.hexgnn_abi_version() == _lib.ABI_VERSION == 3
+    assert L.hexgnn_abi_version() == _lib.ABI_VERSION == 4
     assert L.hexgnn_padded_width(110) == 112 and L.hexgnn_padded_width(35) == 48 and L.hexgnn_padded_width(129) < 0
     assert L.hexgnn_strerror(-3).decode() == "workspace too small"
     assert L.hexgnn_qnet_supported(2, 110, 123) == 1 and L.hexgnn_qnet_supported(2, 110, 146) == 0
@@ -64,9 +64,28 @@ def test_model_tree_matches_reference_layout():
 def test_unsupported_configurations_fail_loudly():
     from gnn_hex_amd.models import get_pre_defined
     with pytest.raises(NotImplementedError):
-        get_pre_defined("two_headed", model_args(3, 8))
-    with pytest.raises(NotImplementedError):
         get_pre_defined("pna_two_headed", model_args(3, 8))
+    with pytest.raises(NotImplementedError):
+        get_pre_defined("sage+norm", model_args(3, 8))
+
+
+def test_two_headed_module_tree_and_state_dict_keys():
+    """get_pre_defined("two_headed") (GN0/models.py:901-918): CachedGraphNorm (weight, bias, mean_scale) per body / head
+    layer + after_embed_norm with cached_norm=True, Linear(H, 1) value head over mean pooling; keys as the oracle's."""
+    from gnn_hex_amd.models import CachedGraphNorm, get_pre_defined
+    from oracle.model_ref import get_pre_defined_ref
+    args = model_args(4, 16)
+    args.norm = True
+    m, r = get_pre_defined("two_headed", args), get_pre_defined_ref("two_headed", args)
+    assert list(m.state_dict().keys()) == list(r.state_dict().keys())
+    assert sum(p.numel() for p in m.parameters()) == sum(p.numel() for p in r.parameters())
+    assert len(m.gnn.norms) == 4 and isinstance(m.after_embed_norm, CachedGraphNorm) and m.gnn.cached_norm
+    assert m.maker_head.value_head.weight.shape == (1, 16) and m.maker_head.value_head_type == "linear"
+    assert torch.equal(m.gnn.norms[0].mean_scale, torch.ones(16)) and m.gnn.norms[0].mean_cache is None
+    with pytest.raises(AssertionError):
+        m.export_norm_cache()              # no cache set yet (GN0/models.py:168)
+    args.norm = False
+    assert get_pre_defined("two_headed", args).gnn.norms is None
 
 
 def test_norm_module_tree_and_state_dict_keys():

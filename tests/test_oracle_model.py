@@ -195,3 +195,122 @@ def test_oracle_agrees_with_an_independent_dense_restatement(norm, noisy, maker)
         q_ref = ref(x.double(), ei, batch).numpy()
     q_dense = _dense_numpy_forward(ref.state_dict(), 4, 12, x, ei, batch, norm=norm, noisy=noisy)
     assert np.abs(q_ref - q_dense).max() < 1e-10
+
+
+# ---- the two_headed family (GN0/models.py:901-918): CachedGraphNorm + linear value head over mean pooling ------------------
+
+def test_cached_graph_norm_known_answer_and_cache():
+    """CachedGraphNormRef (GN0/models.py:644-670) against the formula worked in numpy: per-channel statistics over all nodes,
+    mean_scale inside the centring, eps inside the square root; then the cache protocol of the reference."""
+    from oracle.model_ref import CachedGraphNormRef
+    rng = np.random.default_rng(3)
+    x = rng.normal(size=(9, 4)) * 2.0 + 0.7
+    norm = CachedGraphNormRef(4).double()
+    with torch.no_grad():
+        norm.weight.copy_(torch.tensor([1.5, 0.5, 2.0, 1.0]))
+        norm.bias.copy_(torch.tensor([0.1, -0.2, 0.0, 0.3]))
+        norm.mean_scale.copy_(torch.tensor([1.0, 0.5, 0.0, 1.2]))
+    w, b, ms = (p.detach().numpy() for p in (norm.weight, norm.bias, norm.mean_scale))
+    mean = x.mean(0)
+    out = x - mean * ms
+    var = (out ** 2).mean(0)
+    want = w * out / np.sqrt(var + 1e-5) + b
+    got = norm(torch.from_numpy(x)).detach().numpy()
+    assert np.abs(got - want).max() < 1e-12
+    # set_cache stores [1, C] statistics; use_cache on OTHER data normalises with them
+    norm(torch.from_numpy(x), set_cache=True)
+    assert norm.mean_cache.shape == (1, 4) and norm.var_cache.shape == (1, 4)
+    assert np.abs(norm.mean_cache.numpy()[0] - mean).max() < 1e-12 and np.abs(norm.var_cache.detach().numpy()[0] - var).max() < 1e-12
+    x2 = rng.normal(size=(5, 4))
+    got2 = norm(torch.from_numpy(x2), use_cache=True).detach().numpy()
+    want2 = w * (x2 - mean * ms) / np.sqrt(var + 1e-5) + b
+    assert np.abs(got2 - want2).max() < 1e-12
+    # set_cache wins over use_cache (GN0/models.py:656,663: `use_cache and not set_cache`)
+    got3 = norm(torch.from_numpy(x2), set_cache=True, use_cache=True).detach().numpy()
+    o3 = x2 - x2.mean(0) * ms
+    assert np.abs(got3 - (w * o3 / np.sqrt((o3 ** 2).mean(0) + 1e-5) + b)).max() < 1e-12
+
+
+def _dense_numpy_two_headed(sd, layers, x, ei, batch, norm, eps=1e-5):
+    """Independent dense float64 restatement of get_pre_defined("two_headed") (shares no code with oracle/model_ref.py)."""
+    g = lambda k: sd[k].double().numpy()                                          # noqa: E731
+    x = x.double().numpy()
+    n = x.shape[0]
+    A = np.zeros((n, n))
+    np.add.at(A, (ei[1].numpy(), ei[0].numpy()), 1.0)
+    M = A / np.maximum(A.sum(1, keepdims=True), 1.0)
+    maker = x[0, 2] == 1
+
+    def gn(h, prefix):
+        o = h - h.mean(0, keepdims=True) * g(prefix + ".mean_scale")
+        return g(prefix + ".weight") * o / np.sqrt((o * o).mean(0, keepdims=True) + eps) + g(prefix + ".bias")
+
+    def stack(h, prefix, count):
+        for i in range(count):
+            h = (M @ h) @ g("%s.convs.%d.lin_l.weight" % (prefix, i)).T + g("%s.convs.%d.lin_l.bias" % (prefix, i)) \
+                + h @ g("%s.convs.%d.lin_r.weight" % (prefix, i)).T
+            if norm:
+                h = gn(h, "%s.norms.%d" % (prefix, i))
+            h = np.maximum(h, 0.0)
+        return h
+
+    emb = stack(x[:, :2], "gnn", layers)
+    if norm:
+        emb = gn(emb, "after_embed_norm")
+    head = "maker_head" if maker else "breaker_head"
+    h = stack(emb, head + ".gnn", 2)
+    adv = 2.0 * np.tanh(h @ g(head + ".linear.weight").T + g(head + ".linear.bias"))[:, 0]
+    bt = batch.numpy()
+    q = np.zeros(n)
+    for gi in range(int(bt.max()) + 1):
+        rows = np.nonzero(bt == gi)[0]
+        v = np.tanh(g(head + ".value_head.weight") @ h[rows].mean(0) + g(head + ".value_head.bias"))[0]
+        q[rows] = v + adv[rows] - adv[rows].mean()
+    return q
+
+
+@pytest.mark.parametrize("norm", [False, True])
+@pytest.mark.parametrize("maker", [True, False])
+def test_two_headed_oracle_agrees_with_an_independent_dense_restatement(norm, maker):
+    from argparse import Namespace
+    torch.manual_seed(9)
+    args = Namespace(num_layers=3, hidden_channels=10, norm=norm, noisy_dqn=False, noisy_sigma0=0.5, num_head_layers=2)
+    ref = get_pre_defined_ref("two_headed", args).double()
+    with torch.no_grad():
+        for k, p in ref.named_parameters():
+            if "norm" in k:
+                p.add_(torch.randn(p.shape, dtype=torch.float64) * 0.3)
+    x, ei, batch, ptr = batch_tensors("D1", [5, 7, 6], maker=maker)
+    with torch.no_grad():
+        q_ref = ref(x.double(), ei, batch).numpy()
+    assert np.abs(q_ref - _dense_numpy_two_headed(ref.state_dict(), 3, x, ei, batch, norm)).max() < 1e-10
+    keys = list(ref.state_dict().keys())
+    assert "maker_head.value_head.weight" in keys and ref.state_dict()["maker_head.value_head.weight"].shape == (1, 10)
+    assert ("gnn.norms.0.mean_scale" in keys) == norm
+
+
+def test_two_headed_oracle_norm_cache_protocol():
+    """set_cache in eval mode stores the statistics of that batch in every norm of body and evaluated head; a later eval
+    forward of ANOTHER batch uses them (different from its fresh-statistics result), training mode ignores them, and
+    export_norm_cache / import_norm_cache move them to a second model (GN0/models.py:165-182, 513-535)."""
+    from argparse import Namespace
+    torch.manual_seed(11)
+    args = Namespace(num_layers=2, hidden_channels=8, norm=True, noisy_dqn=False, noisy_sigma0=0.5, num_head_layers=2)
+    ref = get_pre_defined_ref("two_headed", args).double().eval()
+    xa, eia, ba, _ = batch_tensors("D1", [5, 6], maker=True)
+    xb, eib, bb, _ = batch_tensors("D1", [7], maker=True)
+    with torch.no_grad():
+        fresh_b = ref(xb.double(), eib, bb)
+        ref(xa.double(), eia, ba, set_cache=True)
+        assert ref.gnn.has_cache and ref.maker_head.gnn.has_cache and not ref.breaker_head.gnn.has_cache
+        cached_b = ref(xb.double(), eib, bb)
+        assert (cached_b - fresh_b).abs().max() > 1e-6
+        ref.train()
+        assert torch.equal(ref(xb.double(), eib, bb), fresh_b)
+        ref.eval()
+        other = get_pre_defined_ref("two_headed", args).double().eval()
+        other.load_state_dict(ref.state_dict())
+        caches = [ref.gnn.export_norm_cache(), ref.maker_head.export_norm_cache(), None]
+        assert caches[0][0].shape == (2, 1, 8)
+        other.import_norm_cache(*caches)
+        assert torch.equal(other(xb.double(), eib, bb), cached_b)
