@@ -58,6 +58,11 @@ _SIGS = {
     "hexgnn_head_linear_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_head_linear_backward_workspace_bytes": (sz, [ci, ci, ci]),
     "hexgnn_head_linear_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "hexgnn_sage_scalar_forward": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_sage_scalar_backward_workspace_bytes": (sz, [ci, ci]),
+    "hexgnn_sage_scalar_backward": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
+    "hexgnn_policy_log_softmax_forward": (ci, [ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_policy_log_softmax_backward": (ci, [ci, ci, vp, vp, ci, ci, vp, vp, vp, vp, vp, vp]),
     "hexgnn_qnet_supported": (ci, [ci, ci, ci]),
     "hexgnn_qnet_saved_bytes": (sz, [ci, ci, ci, ci, ci]),
     "hexgnn_qnet_forward": (ci, [ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,

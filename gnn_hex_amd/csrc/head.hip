@@ -545,6 +545,194 @@ __global__ __launch_bounds__(256) void head_linear_bwd_kernel(
     }
 }
 
+// ---- HexAra policy head pieces (GN0/torch_script_models.py:286-379) ----------------------------------------------------------
+// (a) the policy head's LAST layer is a SAGEConv(H, 1) (ModifiedBaseNet with out_channels=1, lines 123-144, 296):
+//       out_i = b + w_r . h_i + mean_{j in N(i)} w_l . h_j
+//     two dot products per row, then the mean of a scalar over the CSR: HBM-bound, no MFMA.
+__global__ __launch_bounds__(256) void sage_scalar_dots_kernel(int n, int H, int hp, const float* __restrict__ h,
+                                                              const float* __restrict__ wl, const float* __restrict__ wr,
+                                                              float* __restrict__ s /*[n][2]*/) {
+    __shared__ __attribute__((aligned(16))) float s_l[128], s_r[128];
+    const int tid = threadIdx.x;
+    if (tid < 128) { s_l[tid] = tid < H ? wl[tid] : 0.f; s_r[tid] = tid < H ? wr[tid] : 0.f; }
+    __syncthreads();
+    const int sub = tid & 3, q4n = hp / 4;
+    const int row = blockIdx.x * 64 + (tid >> 2);
+    if (row >= n) return;                                   // (the four lanes of a row leave together)
+    const f32x4* hr = reinterpret_cast<const f32x4*>(h + (size_t)row * hp);
+    float a = 0.f, u = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int c = sub + 4 * k;
+        if (c < q4n) {
+            const f32x4 hv = hr[c], lw = reinterpret_cast<const f32x4*>(s_l)[c], rw = reinterpret_cast<const f32x4*>(s_r)[c];
+            a += hv[0] * lw[0] + hv[1] * lw[1] + hv[2] * lw[2] + hv[3] * lw[3];
+            u += hv[0] * rw[0] + hv[1] * rw[1] + hv[2] * rw[2] + hv[3] * rw[3];
+        }
+    }
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
+    u += __shfl_xor(u, 1); u += __shfl_xor(u, 2);
+    if (sub == 0) { s[2 * (size_t)row] = a; s[2 * (size_t)row + 1] = u; }
+}
+
+__global__ __launch_bounds__(256) void sage_scalar_gather_kernel(int n, const int* __restrict__ rowptr,
+                                                                const int* __restrict__ col, const float* __restrict__ invdeg,
+                                                                const float* __restrict__ s, const float* __restrict__ bias,
+                                                                float* __restrict__ out) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float acc = 0.f;
+    for (int e = rowptr[i]; e < rowptr[i + 1]; ++e) acc += s[2 * (size_t)col[e]];       // ascending neighbour order
+    out[i] = bias[0] + s[2 * (size_t)i + 1] + invdeg[i] * acc;
+}
+
+// backward: ds_r = dout,  ds_l[j] = sum_{i in T(j)} dout_i / deg_i,  dh_j = ds_l[j] w_l + ds_r[j] w_r;
+// block partials (64 rows): lpart[blk] = (sum ds_l h | sum dout), rpart[blk] = (sum ds_r h | 0)
+__global__ __launch_bounds__(256) void sage_scalar_bwd_kernel(int n, int H, int hp, const int* __restrict__ rowptr_t,
+                                                             const int* __restrict__ col_t, const float* __restrict__ invdeg,
+                                                             const float* __restrict__ h, const float* __restrict__ wl,
+                                                             const float* __restrict__ wr, const float* __restrict__ dout,
+                                                             float* __restrict__ dh, float* __restrict__ lpart,
+                                                             float* __restrict__ rpart) {
+    __shared__ float s_l[128], s_r[128];
+    __shared__ float s_dl[64], s_dr[64];
+    __shared__ float s_acc[2][129];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.x * 64, r1 = min(n, r0 + 64);
+    if (tid < 128) { s_l[tid] = tid < H ? wl[tid] : 0.f; s_r[tid] = tid < H ? wr[tid] : 0.f; }
+    if (tid < 64) {
+        const int j = r0 + tid;
+        float dl = 0.f, dr = 0.f;
+        if (j < n) {
+            dr = dout[j];
+            for (int e = rowptr_t[j]; e < rowptr_t[j + 1]; ++e) { const int i = col_t[e]; dl += dout[i] * invdeg[i]; }
+        }
+        s_dl[tid] = dl;
+        s_dr[tid] = dr;
+    }
+    __syncthreads();
+    {
+        const int sub = tid & 3, q4n = hp / 4, row = r0 + (tid >> 2);
+        if (row < n) {
+            const float dl = s_dl[tid >> 2], dr = s_dr[tid >> 2];
+            f32x4* d = reinterpret_cast<f32x4*>(dh + (size_t)row * hp);
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int q = sub + 4 * k;
+                if (q < q4n) {
+                    f32x4 v;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) { const int c = 4 * q + jj; v[jj] = c < H ? dl * s_l[c] + dr * s_r[c] : 0.f; }
+                    d[q] = v;
+                }
+            }
+        }
+    }
+    {
+        const int c = tid & 127, ph = tid >> 7;
+        float al = 0.f, ar = 0.f, ab = 0.f;
+        for (int row = r0 + ph; row < r1; row += 2) {
+            const float hv = c < hp ? h[(size_t)row * hp + c] : 0.f;
+            al += s_dl[row - r0] * hv;
+            ar += s_dr[row - r0] * hv;
+            ab += s_dr[row - r0];
+        }
+        if (ph == 1) { s_acc[0][c] = al; s_acc[1][c] = ar; if (c == 0) s_acc[0][128] = ab; }
+        __syncthreads();
+        if (ph == 0) {
+            if (c < hp) {
+                lpart[(size_t)blockIdx.x * (hp + 1) + c] = al + s_acc[0][c];
+                rpart[(size_t)blockIdx.x * (hp + 1) + c] = ar + s_acc[1][c];
+            }
+            if (c == 0) {
+                lpart[(size_t)blockIdx.x * (hp + 1) + hp] = ab + s_acc[0][128];
+                rpart[(size_t)blockIdx.x * (hp + 1) + hp] = 0.f;
+            }
+        }
+    }
+}
+
+// (b) output surgery + scatter_log_softmax (lines 326-378): per graph g the output segment holds the logits of its
+//     non-terminal nodes (rows gptr[g]+2 ..) and, when swapping is allowed in g, the graph's swap logit behind them;
+//     segment start = gptr[g] - 2g + (number of swap slots of graphs < g) = output_batch_ptr[g]; log-softmax per segment.
+//     swap flag of graph g (lines 337-347): feature 2 of the graph's LAST node for g < b-1, of its FIRST node for g = b-1.
+__device__ __forceinline__ int swap_flag(int g, int b, const int* gptr, const float* x, int xs, int swap_allowed) {
+    if (!swap_allowed) return 0;
+    const int row = g < b - 1 ? gptr[g + 1] - 1 : gptr[g];
+    return x[(size_t)row * xs + 2] != 0.f ? 1 : 0;
+}
+__device__ __forceinline__ float block_max_256(float v, float* s4) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(s4[0], s4[1]), fmaxf(s4[2], s4[3]));
+}
+__device__ __forceinline__ int block_isum_256(int v, int* s4) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+__global__ __launch_bounds__(256) void policy_lsm_fwd_kernel(int b, const int* __restrict__ gptr, const float* __restrict__ x,
+                                                            int xs, int swap_allowed, const float* __restrict__ pi_raw,
+                                                            const float* __restrict__ should_swap, float* __restrict__ out_pi,
+                                                            int64_t* __restrict__ out_gi, int64_t* __restrict__ out_ptr) {
+    __shared__ float s4[4];
+    __shared__ int i4[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    int before = 0;
+    for (int j = tid; j < g; j += 256) before += swap_flag(j, b, gptr, x, xs, swap_allowed);
+    before = block_isum_256(before, i4);
+    const int flag = swap_flag(g, b, gptr, x, xs, swap_allowed);
+    const int r0 = gptr[g] + 2, r1 = gptr[g + 1];
+    const int len = max(r1 - r0, 0) + flag;
+    const int64_t o0 = (int64_t)gptr[g] - 2 * (int64_t)g + before;
+    auto val = [&](int k) { return k < r1 - r0 ? pi_raw[r0 + k] : should_swap[g]; };
+    float mx = -INFINITY;
+    for (int k = tid; k < len; k += 256) mx = fmaxf(mx, val(k));
+    mx = block_max_256(mx, s4);
+    float se = 0.f;
+    for (int k = tid; k < len; k += 256) se += expf(val(k) - mx);
+    se = block_sum_256(se, s4);
+    const float lse = logf(se);
+    for (int k = tid; k < len; k += 256) {
+        out_pi[o0 + k] = val(k) - mx - lse;
+        out_gi[o0 + k] = g;
+    }
+    if (tid == 0) {
+        out_ptr[g] = o0;
+        if (g == b - 1) out_ptr[b] = o0 + len;
+    }
+}
+
+// d logit_k = d out_k - softmax_k * sum(d out);  terminal rows get 0
+__global__ __launch_bounds__(256) void policy_lsm_bwd_kernel(int b, const int* __restrict__ gptr, const float* __restrict__ x,
+                                                            int xs, int swap_allowed, const int64_t* __restrict__ out_ptr,
+                                                            const float* __restrict__ out_pi, const float* __restrict__ d_out,
+                                                            float* __restrict__ d_pi_raw, float* __restrict__ d_should_swap) {
+    __shared__ float s4[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int flag = swap_flag(g, b, gptr, x, xs, swap_allowed);
+    const int r0 = gptr[g] + 2, r1 = gptr[g + 1];
+    const int nn = max(r1 - r0, 0), len = nn + flag;
+    const int64_t o0 = out_ptr[g];
+    float sd = 0.f;
+    for (int k = tid; k < len; k += 256) sd += d_out[o0 + k];
+    sd = block_sum_256(sd, s4);
+    for (int k = tid; k < len; k += 256) {
+        const float d = d_out[o0 + k] - expf(out_pi[o0 + k]) * sd;
+        if (k < nn) d_pi_raw[r0 + k] = d;
+        else d_should_swap[g] = d;
+    }
+    if (tid < 2 && gptr[g] + tid < r1) d_pi_raw[gptr[g] + tid] = 0.f;
+    if (tid == 0 && !flag && d_should_swap) d_should_swap[g] = 0.f;
+}
+
 int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const float* dvr, const float* pooled,
                             const float* z, const float* lin_part, float* d_lin_w, float* d_lin_b, float* d_v0_w,
                             float* d_v0_b, float* d_v1_w, float* d_v1_b, hipStream_t st) {
@@ -913,6 +1101,70 @@ int hexgnn_head_linear_backward(int n, int b, int hidden, int mode, const int* g
                                                   lpart, vpart, mask_dh);
     head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, lpart, d_lin_w, d_lin_b);
     if (has_value) head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, vpart, d_val_w, d_val_b);
+    return check_launch();
+}
+
+int hexgnn_sage_scalar_forward(int n, int hidden, const int* rowptr, const int* col, const float* invdeg, const float* h,
+                               const float* wl, const float* wr, const float* bias, float* out, float* dots,
+                               hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    const int hp = padded_width(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    if (n < 0 || !wl || !wr || !bias || (n > 0 && (!rowptr || !col || !invdeg || !h || !out || !dots))) return HEXGNN_EINVAL;
+    if (n == 0) return HEXGNN_OK;
+    sage_scalar_dots_kernel<<<(n + 63) / 64, 256, 0, st>>>(n, hidden, hp, h, wl, wr, dots);
+    sage_scalar_gather_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, rowptr, col, invdeg, dots, bias, out);
+    return check_launch();
+}
+
+size_t hexgnn_sage_scalar_backward_workspace_bytes(int n, int hidden) {
+    const int hp = padded_width(hidden);
+    if (n < 0 || hp < 0) return 0;
+    return 2 * align_up(sizeof(float) * (size_t)((n + 63) / 64 + 1) * (hp + 1), 256);
+}
+
+int hexgnn_sage_scalar_backward(int n, int hidden, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                const float* h, const float* wl, const float* wr, const float* dout, float* dh,
+                                float* d_wl, float* d_wr, float* d_bias, void* workspace, size_t workspace_bytes,
+                                hexgnn_stream_t stream_) {
+    hipStream_t st = (hipStream_t)stream_;
+    const int hp = padded_width(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    if (n < 0 || !wl || !wr || !d_wl || !d_wr || !d_bias) return HEXGNN_EINVAL;
+    if (n > 0 && (!rowptr_t || !col_t || !invdeg || !h || !dout || !dh)) return HEXGNN_EINVAL;
+    if (!workspace || workspace_bytes < hexgnn_sage_scalar_backward_workspace_bytes(n, hidden)) return HEXGNN_EWORKSPACE;
+    const int nblk = (n + 63) / 64;
+    float* lpart = (float*)workspace;
+    float* rpart = (float*)((char*)workspace + align_up(sizeof(float) * (size_t)(nblk + 1) * (hp + 1), 256));
+    if (nblk > 0)
+        sage_scalar_bwd_kernel<<<nblk, 256, 0, st>>>(n, hidden, hp, rowptr_t, col_t, invdeg, h, wl, wr, dout, dh, lpart, rpart);
+    // (the right part's bias slot is zero: its sum lands in the scratch float behind the partials)
+    head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(nblk, hp, hidden, lpart, d_wl, d_bias);
+    head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(nblk, hp, hidden, rpart, d_wr, rpart + (size_t)nblk * (hp + 1));
+    return check_launch();
+}
+
+int hexgnn_policy_log_softmax_forward(int n, int b, const int* gptr, const float* x, int x_stride, int swap_allowed,
+                                      const float* pi_raw, const float* should_swap, float* out_pi, int64_t* out_gi,
+                                      int64_t* out_ptr, hexgnn_stream_t stream_) {
+    if (n < 0 || b < 0 || !out_ptr) return HEXGNN_EINVAL;
+    if (b > 0 && (!gptr || !pi_raw || !out_pi || !out_gi)) return HEXGNN_EINVAL;
+    if (swap_allowed && b > 0 && (!x || x_stride < 3 || !should_swap)) return HEXGNN_EINVAL;
+    if (b == 0) { (void)hipMemsetAsync(out_ptr, 0, sizeof(int64_t), (hipStream_t)stream_); return check_launch(); }
+    policy_lsm_fwd_kernel<<<b, 256, 0, (hipStream_t)stream_>>>(b, gptr, x, x_stride, swap_allowed, pi_raw, should_swap, out_pi,
+                                                              out_gi, out_ptr);
+    return check_launch();
+}
+
+int hexgnn_policy_log_softmax_backward(int n, int b, const int* gptr, const float* x, int x_stride, int swap_allowed,
+                                       const int64_t* out_ptr, const float* out_pi, const float* d_out, float* d_pi_raw,
+                                       float* d_should_swap, hexgnn_stream_t stream_) {
+    if (n < 0 || b < 0) return HEXGNN_EINVAL;
+    if (b > 0 && (!gptr || !out_ptr || !out_pi || !d_out || !d_pi_raw)) return HEXGNN_EINVAL;
+    if (swap_allowed && b > 0 && (!x || x_stride < 3 || !d_should_swap)) return HEXGNN_EINVAL;
+    if (b == 0) return HEXGNN_OK;
+    policy_lsm_bwd_kernel<<<b, 256, 0, (hipStream_t)stream_>>>(b, gptr, x, x_stride, swap_allowed, out_ptr, out_pi, d_out,
+                                                              d_pi_raw, d_should_swap);
     return check_launch();
 }
 

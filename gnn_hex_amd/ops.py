@@ -657,6 +657,96 @@ class HeadLinearTailFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
+# HexAra policy head pieces (GN0/torch_script_models.py:286-379)
+# ------------------------------------------------------------------------------------------------
+
+class SageScalarFn(torch.autograd.Function):
+    """SAGEConv(H, 1), the last layer of the HexAra policy head: ``b + wr . h_i + mean_{j in N(i)} wl . h_j`` -> [n]."""
+
+    @staticmethod
+    def forward(ctx, h, gs: GraphStructure, hidden: int, wl, bl, wr):
+        L = _lib.lib()
+        dev = h.device
+        n = int(h.shape[0])
+        hpad = as_padded(h, hidden, trust_pads=False)
+        ps = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous() for p in (wl, bl, wr)]
+        out = torch.empty(n, dtype=torch.float32, device=dev)
+        dots = torch.empty((n, 2), dtype=torch.float32, device=dev)
+        _lib.check(L.hexgnn_sage_scalar_forward(n, hidden, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
+                                                hpad.data_ptr(), ps[0].data_ptr(), ps[2].data_ptr(), ps[1].data_ptr(),
+                                                out.data_ptr(), dots.data_ptr(), _stream()), "hexgnn_sage_scalar_forward")
+        ctx.gs = gs
+        ctx.dims = (n, hidden)
+        ctx.bufs = (hpad, ps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        L = _lib.lib()
+        n, hidden = ctx.dims
+        hpad, ps = ctx.bufs
+        gs = ctx.gs
+        dev = hpad.device
+        hp = padded_width(hidden)
+        dout = dout.float().contiguous()
+        dh = torch.empty((n, hp), dtype=torch.float32, device=dev)
+        g = [torch.empty_like(p) for p in ps]
+        ws_bytes = L.hexgnn_sage_scalar_backward_workspace_bytes(n, hidden)
+        ws = _bytes(ws_bytes, dev)
+        _lib.check(L.hexgnn_sage_scalar_backward(n, hidden, gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.invdeg.data_ptr(),
+                                                 hpad.data_ptr(), ps[0].data_ptr(), ps[2].data_ptr(), dout.data_ptr(),
+                                                 dh.data_ptr(), g[0].data_ptr(), g[2].data_ptr(), g[1].data_ptr(),
+                                                 ws.data_ptr(), ws_bytes, _stream()), "hexgnn_sage_scalar_backward")
+        return _logical(dh, hidden), None, None, g[0], g[1], g[2]
+
+
+def sage_scalar(h: torch.Tensor, gs: GraphStructure, hidden: int, conv) -> torch.Tensor:
+    _require_cuda(h, "h")
+    return SageScalarFn.apply(h, gs, hidden, conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight)
+
+
+class PolicyLogSoftmaxFn(torch.autograd.Function):
+    """Terminal rows dropped, swap logits inserted, scatter_log_softmax per graph (torch_script_models.py:326-378).
+    -> (pi [capacity], output_graph_indices [capacity], output_batch_ptr [b+1]); the caller trims to output_batch_ptr[-1]."""
+
+    @staticmethod
+    def forward(ctx, pi_raw, should_swap, x, gptr, b: int, swap_allowed: bool):
+        L = _lib.lib()
+        dev = pi_raw.device
+        n = int(pi_raw.shape[0])
+        pi_raw = pi_raw.float().contiguous()
+        ss = should_swap.float().contiguous() if should_swap is not None else None
+        cap = max(n - 2 * b + (b if swap_allowed else 0), 0)
+        out_pi = torch.empty(cap, dtype=torch.float32, device=dev)
+        out_gi = torch.empty(cap, dtype=torch.int64, device=dev)
+        out_ptr = torch.empty(b + 1, dtype=torch.int64, device=dev)
+        xs = x if (x.dtype == torch.float32 and x.stride(1) == 1) else x.float().contiguous()
+        _lib.check(L.hexgnn_policy_log_softmax_forward(
+            n, b, gptr.data_ptr(), xs.data_ptr(), xs.stride(0) if n > 0 else 3, int(swap_allowed), pi_raw.data_ptr(),
+            ss.data_ptr() if ss is not None else None, out_pi.data_ptr(), out_gi.data_ptr(), out_ptr.data_ptr(), _stream()),
+            "hexgnn_policy_log_softmax_forward")
+        ctx.dims = (n, b, bool(swap_allowed), cap)
+        ctx.bufs = (gptr, xs, out_ptr, out_pi)
+        ctx.mark_non_differentiable(out_gi, out_ptr)
+        return out_pi, out_gi, out_ptr
+
+    @staticmethod
+    def backward(ctx, d_pi, _dgi, _dptr):
+        L = _lib.lib()
+        n, b, swap_allowed, cap = ctx.dims
+        gptr, xs, out_ptr, out_pi = ctx.bufs
+        dev = out_pi.device
+        d_pi = d_pi.float().contiguous()
+        d_raw = torch.empty(n, dtype=torch.float32, device=dev)
+        d_ss = torch.empty(b, dtype=torch.float32, device=dev) if swap_allowed else None
+        _lib.check(L.hexgnn_policy_log_softmax_backward(
+            n, b, gptr.data_ptr(), xs.data_ptr(), xs.stride(0) if n > 0 else 3, int(swap_allowed), out_ptr.data_ptr(),
+            out_pi.data_ptr(), d_pi.data_ptr(), d_raw.data_ptr(), d_ss.data_ptr() if d_ss is not None else None, _stream()),
+            "hexgnn_policy_log_softmax_backward")
+        return d_raw, d_ss, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------
 # fused per-graph path: whole network in one launch per direction (graphs <= 128 nodes, hidden <= 112)
 # ------------------------------------------------------------------------------------------------
 

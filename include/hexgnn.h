@@ -172,6 +172,32 @@ int hexgnn_head_linear_backward(int n, int b, int hidden, int mode /* | HEXGNN_H
                                 float* d_lin_w, float* d_lin_b, float* d_val_w, float* d_val_b,
                                 void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
 
+/* ---- HexAra policy/value network SAGE_torch_script (GN0/torch_script_models.py:286-379), the pieces the SAGE stack and
+ *      the head tail above do not cover:
+ *      (a) the policy head's last layer SAGEConv(H, 1) (ModifiedBaseNet with out_channels=1, lines 123-144,296):
+ *          out[i] = bias + wr . h_i + mean_{j in N(i)} wl . h_j.   dots: [n][2] scratch (kept for nothing: recomputed backward).
+ *      (b) lines 326-378: terminal nodes (the first two rows of every graph) dropped, the graph's swap logit appended to its
+ *          segment when swapping is allowed there (feature 2 of the graph's last row; of its FIRST row for the last graph),
+ *          scatter_log_softmax per segment.  out_pi / out_gi: capacity n - 2b + b entries; out_ptr [b+1] =
+ *          output_batch_ptr (out_ptr[b] = number of entries written).  Pinned by rl_loop/unittest_model.py:16-92. ---- */
+int hexgnn_sage_scalar_forward(int n, int hidden, const int* rowptr, const int* col, const float* invdeg,
+                               const float* h /*[n][HP]*/, const float* wl /*[hidden]*/, const float* wr /*[hidden]*/,
+                               const float* bias /*[1]*/, float* out /*[n]*/, float* dots /*[n][2]*/,
+                               hexgnn_stream_t stream);
+size_t hexgnn_sage_scalar_backward_workspace_bytes(int n, int hidden);
+int hexgnn_sage_scalar_backward(int n, int hidden, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                const float* h, const float* wl, const float* wr, const float* dout /*[n]*/,
+                                float* dh /*[n][HP]*/, float* d_wl, float* d_wr, float* d_bias,
+                                void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+int hexgnn_policy_log_softmax_forward(int n, int b, const int* gptr, const float* x /*[n][x_stride], feature 2 read*/,
+                                      int x_stride, int swap_allowed, const float* pi_raw /*[n]*/,
+                                      const float* should_swap /*[b] or NULL*/, float* out_pi, int64_t* out_gi,
+                                      int64_t* out_ptr /*[b+1]*/, hexgnn_stream_t stream);
+int hexgnn_policy_log_softmax_backward(int n, int b, const int* gptr, const float* x, int x_stride, int swap_allowed,
+                                       const int64_t* out_ptr, const float* out_pi, const float* d_out,
+                                       float* d_pi_raw /*[n]*/, float* d_should_swap /*[b] or NULL*/,
+                                       hexgnn_stream_t stream);
+
 /* ---- whole-batch LayerNorm (--norm=True): torch_geometric 2.2.0 LayerNorm(hidden, mode="graph") as
  *      CachifiedGNN.forward / DuellingTwoHeaded.forward call it, WITHOUT a batch vector (GN0/models.py:8,286-287,550-551,
  *      935,945): mean and biased std over ALL n x hidden elements, y = (x - mean) / (std + eps) * weight + bias, then the

@@ -1,0 +1,132 @@
+"""CPU restatement of the HexAra policy/value network ``SAGE_torch_script`` (GN0/torch_script_models.py:286-379).
+
+TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  The arithmetic (SAGEConv, scatter, scatter_log_softmax) is
+torch_geometric / torch_scatter code that is absent here: PARITY UNPINNED for the floating-point values.  The INDEX
+surgery of the output (terminal nodes removed, swap logit inserted, output batch pointer / graph indices) IS pinned: the
+reference's own ``rl_loop/unittest_model.py:16-92`` holds exact expected sizes, graph indices and batch pointers for three
+hand-made batches and a randomized property test; ``tests/test_oracle_hexara.py`` replays them against this file.
+
+* ``ModifiedBaseNetRef``   <- GN0/torch_script_models.py:75-189 (layer layout 123-144; forward 167-189: activation after
+                              every layer but the last, norms unsupported here = ``norm=None``, the default of
+                              ``get_current_model``, line 495)
+* ``SageTorchScriptRef``   <- GN0/torch_script_models.py:286-379, statement for statement
+* ``scatter_log_softmax_ref`` <- torch_scatter 2.1.0 ``composite.scatter_log_softmax``: per group, x - max, then
+                              minus log(sum(exp(.)))
+* ``get_current_model_ref`` <- GN0/torch_script_models.py:495-507, ``net_type="SAGE"``
+"""
+from __future__ import annotations
+
+import torch
+from torch import Tensor
+
+from .model_ref import MLPRef, SAGEConvRef, scatter_ref
+
+
+def scatter_log_softmax_ref(src: Tensor, index: Tensor) -> Tensor:
+    n_groups = int(index.max()) + 1 if index.numel() > 0 else 0
+    mx = scatter_ref(src.detach().view(-1, 1), index, dim_size=n_groups, reduce="max").view(-1)
+    rec = src - mx.index_select(0, index)
+    se = src.new_zeros(n_groups).index_add(0, index, rec.exp())
+    return rec - se.log().index_select(0, index)
+
+
+class ModifiedBaseNetRef(torch.nn.Module):
+    def __init__(self, in_channels: int, hidden_channels: int, num_layers: int, out_channels=None, norm=None, **_):
+        super().__init__()
+        if norm is not None:
+            raise NotImplementedError("oracle: norm=None only (get_current_model's default)")
+        self.in_channels, self.hidden_channels, self.num_layers = in_channels, hidden_channels, num_layers
+        self.out_channels = out_channels if out_channels is not None else hidden_channels
+        self.convs = torch.nn.ModuleList()
+        c = in_channels
+        if num_layers > 1:
+            self.convs.append(SAGEConvRef(c, hidden_channels))
+            c = hidden_channels
+        for _ in range(num_layers - 2):
+            self.convs.append(SAGEConvRef(c, hidden_channels))
+            c = hidden_channels
+        self.convs.append(SAGEConvRef(c, self.out_channels))
+        self.norms = None
+
+    def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
+        for i, conv in enumerate(self.convs):
+            x = conv(x, edge_index)
+            if i != self.num_layers - 1:
+                x = torch.relu(x)
+        return x
+
+
+class SageTorchScriptRef(torch.nn.Module):
+    def __init__(self, hidden_channels, hidden_layers, policy_layers, value_layers, in_channels=3, swap_allowed=False,
+                 norm=None):
+        super().__init__()
+        self.final_conv_acts = None
+        self.final_conv_grads = None
+        self.swap_allowed = swap_allowed
+        self.gnn = ModifiedBaseNetRef(in_channels, hidden_channels, hidden_layers, norm=norm)
+        self.my_modules = torch.nn.ModuleDict()
+        self.my_modules["value_head"] = ModifiedBaseNetRef(hidden_channels, hidden_channels, value_layers, norm=norm)
+        self.my_modules["policy_head"] = ModifiedBaseNetRef(hidden_channels, hidden_channels, policy_layers, out_channels=1,
+                                                            norm=norm)
+        self.my_modules["value_linear"] = MLPRef(hidden_channels // 2, 1, hidden_channels * 4, 1)
+        self.my_modules["swap_linear"] = MLPRef(hidden_channels // 2, 1, hidden_channels * 4, 1)
+        self.before_head_norm = None
+        self.value_activation = torch.nn.Tanh()
+
+    def activations_hook(self, grad):
+        self.final_conv_grads = grad
+
+    def forward(self, x: Tensor, edge_index: Tensor, graph_indices: Tensor, batch_ptr: Tensor):
+        assert ((batch_ptr[1:] - batch_ptr[:-1]) > 2).all()
+        embeds = self.gnn(x, edge_index)
+        self.final_conv_acts = embeds
+        if embeds.requires_grad:
+            embeds.register_hook(self.activations_hook)
+        pi = self.my_modules["policy_head"](embeds, edge_index)
+        value_embeds = self.my_modules["value_head"](embeds, edge_index)
+        nb = batch_ptr.numel() - 1
+        parts = [scatter_ref(value_embeds, graph_indices, dim_size=nb, reduce=r) for r in ("sum", "max", "min", "mean")]
+        graph_parts = torch.cat(parts, dim=1)
+        value = self.value_activation(self.my_modules["value_linear"](graph_parts))
+        pi = pi.reshape(pi.size(0))
+        if self.swap_allowed:
+            should_swap = self.my_modules["swap_linear"](graph_parts)
+            should_swap = should_swap.reshape(should_swap.size(0))
+            swap_parts = x[batch_ptr[1:-1] - 1, 2].type(torch.bool)
+            swap_indices = batch_ptr[1:-1][swap_parts]
+            to_select = torch.ones(pi.size(), dtype=torch.bool)
+            to_select[batch_ptr[0]] = False
+            to_select[batch_ptr[1:-1]] = swap_parts
+            to_select[batch_ptr[:-1] + 1] = False
+            all_swap_parts = torch.empty(len(batch_ptr), dtype=torch.bool)
+            all_swap_parts[0] = 0
+            all_swap_parts[1:-1] = swap_parts
+            all_swap_parts[-1] = x[batch_ptr[-2], 2]
+            output_batch_ptr = batch_ptr - torch.arange(0, len(batch_ptr) * 2, 2) + torch.cumsum(all_swap_parts, dim=0)
+            pi = pi.clone()
+            pi[swap_indices] = should_swap[:-1][swap_parts]
+            output_graph_indices = graph_indices.clone()
+            output_graph_indices[swap_indices] = output_graph_indices[swap_indices - 1]
+            pi = pi[to_select]
+            output_graph_indices = output_graph_indices[to_select]
+            if x[batch_ptr[-2], 2]:
+                pi = torch.cat((pi, should_swap[-1:]))
+                output_graph_indices = torch.cat((output_graph_indices, output_graph_indices[-1:]))
+        else:
+            to_select = torch.ones(pi.size(), dtype=torch.bool)
+            to_select[batch_ptr[:-1]] = False
+            to_select[batch_ptr[:-1] + 1] = False
+            output_batch_ptr = batch_ptr - torch.arange(0, len(batch_ptr) * 2, 2)
+            output_graph_indices = graph_indices.clone()
+            pi = pi[to_select]
+            output_graph_indices = output_graph_indices[to_select]
+        pi = scatter_log_softmax_ref(pi, output_graph_indices)
+        return pi, value.reshape(value.size(0)), output_graph_indices, output_batch_ptr
+
+
+def get_current_model_ref(net_type="SAGE", hidden_channels=60, hidden_layers=15, policy_layers=2, value_layers=2,
+                          in_channels=3, swap_allowed=False, norm=None):
+    if net_type != "SAGE":
+        raise NotImplementedError(net_type)
+    return SageTorchScriptRef(hidden_channels=hidden_channels, hidden_layers=hidden_layers, policy_layers=policy_layers,
+                              value_layers=value_layers, in_channels=in_channels, swap_allowed=swap_allowed, norm=norm)
