@@ -317,6 +317,7 @@ const char* hexgnn_strerror(int code) {
         case HEXGNN_EUNSUPPORTED: return "shape not supported by the compiled kernels";
         case HEXGNN_EWORKSPACE: return "workspace too small";
         case HEXGNN_EHIP: return "HIP runtime error at launch";
+        case HEXGNN_ETIMEOUT: return "grid barrier of a one-launch stack kernel timed out (results of that call are invalid)";
         default: return "unknown hexgnn error";
     }
 }

@@ -6,6 +6,7 @@
 namespace hexgnn {
 
 constexpr int kMaxLayers = 64;
+constexpr int kStackFlagWords = 512;   // row blocks a one-launch stack kernel can track (>= CUs of the device)
 constexpr int kDwMaxSlices = 64;   // row slices per layer of the weight-gradient GEMM (workspace is sized for this many)
 // slabs a plan with `layers` layers must hold: kDwMaxSlices per layer, and one- / two-layer launches use up to twice that
 inline size_t dw_slab_count(int layers) {
@@ -19,7 +20,8 @@ struct StackPlan {
     size_t fwd_off[kMaxLayers];   // byte offsets into wpack
     size_t bwd_off[kMaxLayers];
     size_t bias_off[kMaxLayers];
-    size_t pack_bytes;
+    size_t flag_off;              // 2 x kStackFlagWords unsigned (forward, backward): per-block progress counters of the
+    size_t pack_bytes;            // one-launch stack kernels
     size_t agg_off[kMaxLayers];   // byte offsets into saved
     size_t saved_bytes;
 };

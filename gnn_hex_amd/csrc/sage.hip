@@ -47,6 +47,7 @@ int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
         }
         p->bias_off[l] = off; off += align_up(sizeof(float) * (hp + 2), 256);   // bias[hp], then {w scale, 1/scale} (math 1)
     }
+    p->flag_off = off; off += sizeof(unsigned) * 2 * kStackFlagWords;
     p->pack_bytes = off;
     p->saved_bytes = soff;
     return HEXGNN_OK;
@@ -56,6 +57,7 @@ int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
 struct PackArgs {
     LayerPtrs p;
     size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers], bias_off[kMaxLayers];
+    size_t flag_off;
     int hp, nt, L, c_in, hidden, small_first;
 };
 
@@ -68,6 +70,11 @@ __global__ void sage_pack_kernel(PackArgs a, char* __restrict__ wpack) {
     float* bias = (float*)(wpack + a.bias_off[l]);
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid < hp) bias[tid] = tid < H ? bl[tid] : 0.f;
+    // progress counters of the one-launch stack kernels (forward + backward) start every forward call at zero
+    if (l == 0) {
+        unsigned* flags = reinterpret_cast<unsigned*>(wpack + a.flag_off);
+        for (int i = tid; i < 2 * kStackFlagWords; i += gridDim.x * blockDim.x) flags[i] = 0u;
+    }
     if (l == 0 && a.small_first) {
         float* w0 = (float*)(wpack + a.fwd_off[l]);
         const int tot = hp * kSmallCin;
@@ -703,6 +710,384 @@ __global__ __launch_bounds__(512) void sage_hidden_bwd_kernel(
     sage_layer_body<NT, true>(n, rowptr_t, col_t, invdeg, g_in, wpackb, nullptr, ymask, out, tap, 1, wlds);
 }
 
+// ---- ALL hidden layers of a stack in ONE launch (round 3) ---------------------------------------------------------------
+// The per-layer launches above pay, for every layer, the launch itself plus a prologue in which nothing computes: weights,
+// the block's own rows and the CSR row bounds arrive (one round trip), then the column ids (a second, dependent one) --
+// 9 k of a layer's 45 k ticks on MIX (profiles/r03/layer_stamps_MIX_r03.txt).  When the whole batch fits ONE resident
+// workgroup per CU (n <= 128 x CUs) the layers run as a loop inside one kernel instead:
+//   * the CSR state of a row (neighbour offsets into LDS / global memory, 1/deg, the wave's slot count) is layer-invariant:
+//     fetched ONCE;
+//   * a wave's output rows are the next layer's self rows IN THE SAME LANE LAYOUT: they stay in registers, and go to the LDS
+//     row copy (the neighbours inside the block) without touching memory;
+//   * the next layer's weights are requested by LDS-DMA BEFORE the grid-wide barrier and land while the workgroup waits in it;
+//   * only neighbour rows owned by OTHER workgroups come from global memory (the saved activations every layer writes
+//     anyway), which is what the barrier between two layers is for.
+// No grid-wide barrier: every 128-row block has a progress counter (its waves add 1 each per finished layer, after their
+// stores are acknowledged); a wave that needs rows of OTHER blocks -- known from the row's neighbour list, layer-invariant --
+// waits at the start of a layer until the blocks it reads from have finished the previous one.  Blocks made of whole graphs
+// never wait; a graph cut by a block boundary couples just the blocks it touches, so the skew between workgroups does not
+// add up over the layers the way it does with a kernel boundary (or a grid barrier: 1.10 ms per MIX step, against 1.02 ms
+// with per-layer launches) after every layer.  Rows that cross workgroups go through AGENT-scope accesses (sc1: stores write
+// through the XCD's L2, loads do not hit stale lines in it -- the eight L2s are not coherent with each other); fencing instead
+// (buffer_wbl2 / buffer_inv per workgroup and layer) cost 1.37 ms per step.  Every workgroup is resident (host-side guard), so
+// every wait ends; a poll budget (seconds) turns a would-be hang into HEXGNN_ETIMEOUT in the library's status word.
+struct StackKArgs {
+    int n, l_first, n_layers;          // forward: layers l_first, l_first + 1, ...; backward: l_first, l_first - 1, ...
+    int relu_last, last_of_stack;      // forward: the stack's last layer index and whether it has a ReLU
+    int tap_layer;                     // backward: layer whose output gradient (unmasked) also goes to tap_out (-1: none)
+    const int* rowptr;                 // backward: the transposed CSR
+    const int* col;
+    const float* invdeg;
+    const float* in0;                  // rows entering the first processed layer
+    float* slabs;                      // forward: acts (layer l's output = slabs + slab * l); backward: G (output of layer l's
+    size_t slab;                       //          launch = slabs + slab * (l - 1))
+    const float* masks;                // backward: acts (mask of layer l's output gradient = masks + slab * (l - 1))
+    float* dx;                         // backward: output of layer 0 (a hidden-width stack input)
+    const char* w0;                    // packed weights of the first processed layer, wstride bytes per layer
+    size_t wstride;
+    const char* b0;                    // forward: bias of the first processed layer (same stride)
+    char* agg0;                        // forward: saved aggregate of the first processed layer (null: not saved), astride per layer
+    size_t astride;
+    float* tap_out;
+    unsigned* flags;                   // [blocks] progress counters, zero at launch
+    int* status;
+};
+constexpr unsigned kBarMaxPolls = 1u << 21;
+
+constexpr int kAuxSc1 = 16;
+__device__ __forceinline__ f32x4 buf_load_coh(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, kAuxSc1));
+}
+__device__ __forceinline__ void buf_store_coh(const f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, v), r, off, 0, kAuxSc1);
+}
+// wave-wide wait: blocks lo..hi except `self` have all finished `target / 8` layers (lane t polls block lo + t, + 64, ...)
+__device__ __forceinline__ void wait_blocks(const unsigned* flags, int lo, int hi, int self, unsigned target, int* status) {
+    const int lane = threadIdx.x & 63;
+    for (int b0 = lo; b0 <= hi; b0 += 64) {
+        const int j = b0 + lane;
+        const bool mine = j <= hi && j != self;
+        unsigned polls = 0;
+        while (true) {
+            const unsigned v = mine ? __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
+            if (__ballot(v < target) == 0ull) break;
+            __builtin_amdgcn_s_sleep(4);
+            if (++polls > kBarMaxPolls) {          // never expected: every workgroup is resident
+                if (status && lane == 0) *status = HEXGNN_ETIMEOUT;
+                break;
+            }
+        }
+    }
+}
+
+template <int NT, bool BWD>
+__device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds) {
+    static_assert(NT >= 3, "the round-robin MFMA order needs three tiles");
+    constexpr int HP = 16 * NT;
+    const int n = a.n;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)wlds;
+    auto stage_weights = [&](const char* wp) {
+        const f32x4* w4 = reinterpret_cast<const f32x4*>(wp);
+        for (int p = wave; p < 2 * NT * NT; p += 8) dma_piece(w4 + p * 64, 16 * lane, lds_w + p * 1024);
+    };
+    stage_weights(a.w0);
+    const int row0 = (blockIdx.x * 8 + wave) * 16;
+    const int r = lane & 15, g = lane >> 4;
+    const int row = row0 + r;
+    const bool valid = row < n;
+    f32x4 xs[NT], ag[NT];
+#pragma unroll
+    for (int c = 0; c < NT; ++c) xs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int e0 = 0, e1 = 0;
+    float sc = 0.f;                    // 1 / deg of the row: forward the scale of its aggregate, backward of its row as a SOURCE
+    if (valid) {
+        const f32x4* xr = reinterpret_cast<const f32x4*>(a.in0 + (size_t)row * HP) + g;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) xs[c] = xr[4 * c];
+        e0 = a.rowptr[row];
+        e1 = a.rowptr[row + 1];
+        sc = a.invdeg[row];
+    }
+    using RL = RowsLds<NT>;
+    float* rowsl = reinterpret_cast<float*>(wlds + 2 * NT * NT * 64);
+    // backward: a gathered row G_j enters the sum as G_j / deg_j -- a property of the SOURCE row, so the LDS copy holds the
+    // rows already scaled and the in-block slots need no per-slot factor (sixteen registers less than the per-layer kernel)
+    auto rows_to_lds = [&]() {
+        if constexpr (RL::on) {
+            f32x4* mine = reinterpret_cast<f32x4*>(rowsl + (wave * 16 + r) * RL::XS) + g;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) {
+                if constexpr (BWD) mine[4 * c] = xs[c] * sc;
+                else mine[4 * c] = xs[c];
+            }
+        }
+    };
+    rows_to_lds();
+    if constexpr (RL::on) {
+        if (tid < RL::XS / 4) reinterpret_cast<f32x4*>(rowsl + 128 * RL::XS)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    wait_vmem();
+    __syncthreads();
+
+    // ---- layer-invariant CSR state of the row ----
+    const int deg = e1 - e0;
+    using GS = GatherSched<NT>;
+    using GL = GatherLds<NT>;
+    constexpr int kFillGaps = RL::on ? GL::kGaps : GS::kGaps;
+    unsigned noff[kEll];
+    unsigned loff[RL::on ? kEll / 2 : 1];
+    unsigned gneed = 0;
+    constexpr bool kNs = BWD && !RL::on;          // per-slot factors only where every neighbour comes from global memory
+    float ns[kNs ? kEll : 1];
+    const __amdgpu_buffer_rsrc_t ir_ = slab_rsrc(a.invdeg);
+    const int blk = blockIdx.x;
+    int dlo = blk, dhi = blk;                     // blocks this wave reads rows from
+    {
+        int nid[kEll];
+        const __amdgpu_buffer_rsrc_t colr = slab_rsrc(a.col);
+#pragma unroll
+        for (int k = 0; k < kEll; ++k)
+            nid[k] = __builtin_amdgcn_raw_buffer_load_b32(colr, k < deg ? (unsigned)(e0 + k) * 4u : kOob, 0, 0);
+        if constexpr (kNs) {
+#pragma unroll
+            for (int k = 0; k < kEll; ++k)
+                ns[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir_, k < deg ? (unsigned)nid[k] * 4u : kOob, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < kEll; ++k) {
+            if (k < deg) { dlo = min(dlo, nid[k] >> 7); dhi = max(dhi, nid[k] >> 7); }
+        }
+        if (valid) {
+            for (int e = e0 + kEll; e < e1; ++e) { const int j = a.col[e] >> 7; dlo = min(dlo, j); dhi = max(dhi, j); }
+        }
+        if constexpr (RL::on) {
+            const unsigned blk0 = blockIdx.x * 128u;
+#pragma unroll
+            for (int k = 0; k < kEll / 2; ++k) loff[k] = 0u;
+#pragma unroll
+            for (int k = 0; k < kEll; ++k) {
+                const unsigned loc = (unsigned)nid[k] - blk0;
+                const bool have = k < deg, inb = have && loc < 128u;
+                loff[k >> 1] |= ((inb ? loc : 128u) * (unsigned)(RL::XS * 4) + 16u * g) << (16 * (k & 1));
+                noff[k] = (have && !inb) ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
+                gneed |= (__ballot(have && !inb) != 0ull ? 1u : 0u) << k;
+            }
+            gneed = __builtin_amdgcn_readfirstlane(gneed);
+        } else {
+#pragma unroll
+            for (int k = 0; k < kEll; ++k) noff[k] = k < deg ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
+        }
+    }
+    int wmax = deg < kEll ? deg : kEll;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        wmax = max(wmax, __shfl_xor(wmax, o));
+        dlo = min(dlo, __shfl_xor(dlo, o));
+        dhi = max(dhi, __shfl_xor(dhi, o));
+    }
+    wmax = __builtin_amdgcn_readfirstlane(wmax);
+    dlo = __builtin_amdgcn_readfirstlane(dlo);
+    dhi = __builtin_amdgcn_readfirstlane(dhi);
+    const bool remote = dlo != blk || dhi != blk;        // wave-uniform
+
+    const float* xin = a.in0;
+    for (int it = 0; it < a.n_layers; ++it) {
+        const int l = BWD ? a.l_first - it : a.l_first + it;
+        float* out = BWD ? (l >= 1 ? a.slabs + a.slab * (size_t)(l - 1) : a.dx) : a.slabs + a.slab * (size_t)l;
+        const float* ymask = BWD ? (l >= 1 ? a.masks + a.slab * (size_t)(l - 1) : nullptr) : nullptr;
+        float* side = BWD ? ((a.tap_out && l - 1 == a.tap_layer) ? a.tap_out : nullptr)
+                          : (a.agg0 ? reinterpret_cast<float*>(a.agg0 + a.astride * (size_t)it) : nullptr);
+        const float* bias = BWD ? nullptr : reinterpret_cast<const float*>(a.b0 + a.wstride * (size_t)it);
+        const int relu = BWD ? 1 : ((l != a.last_of_stack) || a.relu_last);
+        const __amdgpu_buffer_rsrc_t xr_ = slab_rsrc(xin);
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 tb[RL::on ? 3 : GS::kWin][NT];
+        float rs[2] = {0.f, 0.f};                 // backward, LDS path: 1 / deg of the rows in the global landing ring
+        (void)rs;
+        if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, blk, 8u * (unsigned)it, a.status);
+        auto filler_lds = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            const char* lbase = reinterpret_cast<const char*>(rowsl);
+            static_for_<0, kEll>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                if constexpr (GL::add_gap(k) == Q) {
+                    if (k < wmax) {
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) ag[c] += tb[2][c];       // (backward: the LDS rows are pre-scaled)
+                    }
+                }
+                if constexpr (GL::gadd_gap(k) == Q) {
+                    if (gneed & (1u << k)) {
+                        if constexpr (BWD) {
+#pragma unroll
+                            for (int c = 0; c < NT; ++c) ag[c] += tb[k % 2][c] * rs[k % 2];
+                        } else {
+#pragma unroll
+                            for (int c = 0; c < NT; ++c) ag[c] += tb[k % 2][c];
+                        }
+                    }
+                }
+            });
+            static_for_<0, kEll>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                if constexpr (GL::rd_gap(k) == Q) {
+                    if (k < wmax) {
+                        const unsigned lo = (k & 1) ? (loff[k >> 1] >> 16) : (loff[k >> 1] & 0xffffu);
+                        const f32x4* lr = reinterpret_cast<const f32x4*>(lbase + lo);
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) tb[2][c] = lr[4 * c];
+                    }
+                    if (gneed & (1u << k)) {
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) tb[k % 2][c] = buf_load_coh(xr_, noff[k] + 64 * c);
+                        if constexpr (BWD) {      // 1 / deg of the remote source row: its id back from the byte offset
+                            const unsigned j = (noff[k] - 16u * g) / (unsigned)(HP * 4);
+                            rs[k % 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                ir_, noff[k] == kOob ? kOob : j * 4u, 0, 0));
+                        }
+                    }
+                }
+            });
+        };
+        auto filler_glb = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            static_for_<0, kEll>([&](auto kk) {
+                constexpr int k = decltype(kk)::value;
+                if constexpr (GS::add_gap(k) == Q) {
+                    if (k < wmax) {
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) {
+                            if constexpr (BWD) ag[c] += tb[k % GS::kWin][c] * ns[k];
+                            else ag[c] += tb[k % GS::kWin][c];
+                        }
+                    }
+                }
+            });
+            static_for_<Q * GS::kP, (Q + 1) * GS::kP < kEll * NT ? (Q + 1) * GS::kP : kEll * NT>([&](auto ii) {
+                constexpr int i = decltype(ii)::value, k = i / NT, c = i % NT;
+                if (k < wmax) tb[k % GS::kWin][c] = buf_load_coh(xr_, noff[k] + 64 * c);
+            });
+        };
+        auto filler = [&](auto qq) {
+            if constexpr (RL::on) filler_lds(qq);
+            else filler_glb(qq);
+        };
+        f32x4 acc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        auto contract_rr = [&](const f32x4* __restrict__ base, const f32x4 (&rows)[NT], auto&& fill) {
+            using MS = MfmaSeq<NT>;
+            f32x4 fr[4];
+#pragma unroll
+            for (int i = 0; i < 3; ++i) fr[i] = base[i * 64 + lane];
+            static_for_<0, MS::kGroups>([&](auto gg) {
+                constexpr int gi = decltype(gg)::value, nn = MS::group_size(gi), u0 = 3 * gi;
+                if constexpr (gi + 2 == MS::kGroups && MS::group_size(gi + 1) == 4) fr[3] = base[(u0 + 6) * 64 + lane];
+                if constexpr (MS::kGroups == 1 && nn == 4) fr[3] = base[3 * 64 + lane];
+                static_for_<0, 4 * nn>([&](auto pp) {
+                    constexpr int pos = decltype(pp)::value, j = pos / nn, i = pos % nn, u = u0 + i, c = u / NT, t = u % NT;
+                    constexpr int sl = 4 * u0 + pos;
+                    acc[t] = mfma16x16x4(fr[i][j], rows[c][j], acc[t]);
+                    if constexpr (j == 3 && gi + 1 < MS::kGroups && i < 3) fr[i] = base[(u0 + 3 + i) * 64 + lane];
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (sl % 4 == 3) {
+                        fill(std::integral_constant<int, sl / 4>{});
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                });
+            });
+        };
+        contract_rr(wlds + NT * NT * 64, xs, filler);
+        static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
+        f32x4 ym[BWD ? NT : 1];
+        if constexpr (BWD) {
+            const __amdgpu_buffer_rsrc_t yr_ = slab_rsrc(ymask);
+            const unsigned off = (valid && ymask) ? (unsigned)row * (unsigned)(HP * 4) + 16u * g : kOob;
+#pragma unroll
+            for (int c = 0; c < NT; ++c) ym[c] = buf_load(yr_, off + 64 * c);
+        }
+        if (valid) {
+            if (deg > kEll) {
+                for (int e = e0 + kEll; e < e1; ++e) {
+                    const int j = a.col[e];
+                    const unsigned oj = (unsigned)j * (unsigned)(HP * 4) + 16u * g;
+                    float sj = 1.f;
+                    if constexpr (BWD) sj = a.invdeg[j];
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        if constexpr (BWD) ag[c] += buf_load_coh(xr_, oj + 64 * c) * sj;
+                        else ag[c] += buf_load_coh(xr_, oj + 64 * c);
+                    }
+                }
+            }
+            if constexpr (!BWD) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ag[c] *= sc;
+                if (side) {
+                    f32x4* ar = reinterpret_cast<f32x4*>(side + (size_t)row * HP) + g;
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) ar[4 * c] = ag[c];
+                }
+            }
+        }
+        contract_rr(wlds, ag, [](auto) {});
+        // epilogue: the stored rows ARE the next layer's self rows, in the same lane layout -> they stay in xs
+        if (valid) {
+            const __amdgpu_buffer_rsrc_t or_ = slab_rsrc(out);
+            const unsigned oo = (unsigned)row * (unsigned)(HP * 4) + 16u * g;
+            if constexpr (!BWD) {
+                const f32x4* br = reinterpret_cast<const f32x4*>(bias) + g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 v = acc[t] + br[4 * t];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = (v[q] > 0.f || !relu) ? v[q] : 0.f;
+                    buf_store_coh(v, or_, oo + 64 * t);
+                    xs[t] = v;
+                }
+            } else {
+                if (side) {
+                    f32x4* tr = reinterpret_cast<f32x4*>(side + (size_t)row * HP) + g;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t) tr[4 * t] = acc[t];
+                }
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    f32x4 v = acc[t];
+                    if (ymask) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = ym[t][q] > 0.f ? v[q] : 0.f;
+                    }
+                    buf_store_coh(v, or_, oo + 64 * t);
+                    xs[t] = v;
+                }
+            }
+        }
+        if (it + 1 == a.n_layers) break;
+        // ---- between two layers ----
+        lds_barrier();        // every wave is past its MFMAs and its reads of the LDS rows (no wait for the stores here)
+        rows_to_lds();
+        stage_weights(a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)(it + 1)) : (ptrdiff_t)(a.wstride * (size_t)(it + 1))));
+        wait_vmem();          // this wave's rows are written through, its weight pieces have landed
+        if (lane == 0) __hip_atomic_fetch_add(a.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        xin = out;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(512) void sage_stack_fwd_kernel(StackKArgs a) {
+    extern __shared__ f32x4 wlds[];
+    if constexpr (NT >= 3) sage_stack_body<NT, false>(a, wlds);
+}
+template <int NT>
+__global__ __launch_bounds__(512) void sage_stack_bwd_kernel(StackKArgs a) {
+    extern __shared__ f32x4 wlds[];
+    if constexpr (NT >= 3) sage_stack_body<NT, true>(a, wlds);
+}
+
 // ---- out = dxs + sum_{j in T(i)} dagg_j, optionally masked by y>0 (stack-input gradient / G of a raw first layer) ----
 __global__ void sage_combine_kernel(int n, int hp, const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
                                     const float* __restrict__ dxs, const float* __restrict__ dagg,
@@ -1154,6 +1539,72 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
         n, rowptr_t, col_t, invdeg, g_in, (const f32x4*)wpb, ymask, out, tap);
 }
 
+// One-launch stack kernels: usable when every workgroup can be resident at once (one per CU: 128 rows x CUs) and the status
+// word (pinned host memory the kernels can write: a poll budget exceeded) exists.  HEXGNN_NO_PERSIST=1 keeps the per-layer
+// launches (A/B measurements, debugging).
+static int g_cu_count = 0;
+static int* g_stack_status = nullptr;
+static bool persist_ready(hipStream_t st) {
+    static int state = 0;                      // 0 = not tried yet, 1 = ready, -1 = unavailable
+    if (state != 0) return state > 0;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
+        (void)hipGetLastError();
+        return false;                          // (no allocation while a graph is being captured: try again at the next call)
+    }
+    state = -1;
+    const char* off = getenv("HEXGNN_NO_PERSIST");
+    if (off && off[0] && off[0] != '0') return false;
+    int dev = 0, cus = 0;
+    void* p = nullptr;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        cus <= 0 || hipHostMalloc(&p, 64, hipHostMallocMapped) != hipSuccess || !p) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_stack_status = static_cast<int*>(p);
+    *g_stack_status = 0;
+    g_cu_count = cus;
+    state = 1;
+    return true;
+}
+// a poll budget exceeded in an EARLIER launch is reported by the next stack call (like hipGetLastError)
+static int take_stack_status() {
+    if (!g_stack_status) return HEXGNN_OK;
+    const int c = *reinterpret_cast<volatile int*>(g_stack_status);
+    if (c != 0) *g_stack_status = 0;
+    return c;
+}
+static bool persist_fits(int n, int nt, int layers, hipStream_t st) {
+    return nt >= 3 && layers >= 2 && n > 0 && persist_ready(st) && (n + 127) / 128 <= g_cu_count &&
+           (n + 127) / 128 <= kStackFlagWords;
+}
+
+template <int NT>
+static void launch_stack_fwd(const StackKArgs& a, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_stack_fwd_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
+        return true;
+    }();
+    (void)once;
+    KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
+    if constexpr (NT >= 3)
+        sage_stack_fwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(a);
+}
+template <int NT>
+static void launch_stack_bwd(const StackKArgs& a, hipStream_t st) {
+    static bool once = [] {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_stack_bwd_kernel<NT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
+        return true;
+    }();
+    (void)once;
+    KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
+    if constexpr (NT >= 3)
+        sage_stack_bwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(a);
+}
+
 template <int NT>
 static void launch_dw(const DwArgs& a, int layers, float* part, hipStream_t st) {
     KernelTimer kt(HEXGNN_K_SAGE_DW, st);
@@ -1236,6 +1687,7 @@ int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl
         pa.fwd_off[l] = p.fwd_off[l]; pa.bwd_off[l] = p.bwd_off[l]; pa.bias_off[l] = p.bias_off[l];
     }
     pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
+    pa.flag_off = p.flag_off;
     const int pack_elems = 2 * p.nt * p.nt * 256;
     sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
     if (math == 1) {   // overwrite the hidden layers' weight packs with the split-f16 layout (biases / raw layer stay fp32)
@@ -1337,6 +1789,10 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     const size_t slab = (size_t)n * p.hp;
     char* wp = (char*)wpack;
     char* sv = (char*)saved;
+    rc = take_stack_status();
+    if (rc != HEXGNN_OK) return rc;
+    const int fh = p.small_first ? 1 : 0;
+    const bool one_launch = persist_fits(n, p.nt, p.L - fh, st);
     for (int l = 0; l < p.L; ++l) {
         float* y = acts + slab * l;
         const float* bias = (const float*)(wp + p.bias_off[l]);
@@ -1346,6 +1802,21 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
             KernelTimer kt(HEXGNN_K_SAGE_FIRST, st);
             sage_first_fwd_kernel<<<(n + 31) / 32, 256, 0, st>>>(n, c_in, p.hp, rowptr, col, invdeg, x, x_stride,
                                                               (const float*)(wp + p.fwd_off[0]), bias, y, agg, relu);
+        } else if (one_launch) {
+            StackKArgs a{};
+            a.n = n; a.l_first = l; a.n_layers = p.L - l;
+            a.relu_last = !(flags & HEXGNN_SAGE_LINEAR_LAST); a.last_of_stack = p.L - 1; a.tap_layer = -1;
+            a.rowptr = rowptr; a.col = col; a.invdeg = invdeg;
+            a.in0 = l == 0 ? x : acts + slab * (l - 1);
+            a.slabs = acts; a.slab = slab;
+            a.w0 = wp + p.fwd_off[l]; a.wstride = p.L - l > 1 ? p.fwd_off[l + 1] - p.fwd_off[l] : 0;
+            a.b0 = wp + p.bias_off[l];
+            a.agg0 = need_backward ? sv + p.agg_off[l] : nullptr;
+            a.astride = p.L - l > 1 ? p.agg_off[l + 1] - p.agg_off[l] : 0;
+            a.flags = reinterpret_cast<unsigned*>(wp + p.flag_off);
+            a.status = g_stack_status;
+            HEXGNN_NT_SWITCH(p.nt, (launch_stack_fwd<NT_>(a, st)));
+            break;
         } else {
             const float* xin = l == 0 ? x : acts + slab * (l - 1);
             HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, relu, st)));
@@ -1427,7 +1898,24 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
                                                    G + slab * (p.L - 1));
     }
     if (tap_out && (tap_layer < 0 || tap_layer >= p.L - 1)) return HEXGNN_EINVAL;
-    for (int l = p.L - 1; l >= first_hidden; --l) {
+    rc = take_stack_status();
+    if (rc != HEXGNN_OK) return rc;
+    const int lo = (first_hidden == 0 && !dx) ? 1 : first_hidden;        // last layer whose data gradient is wanted
+    const bool one_launch = persist_fits(n, p.nt, p.L - lo, st);
+    if (one_launch) {
+        StackKArgs a{};
+        a.n = n; a.l_first = p.L - 1; a.n_layers = p.L - lo;
+        a.tap_layer = tap_out ? tap_layer : -1; a.tap_out = tap_out;
+        a.rowptr = rowptr_t; a.col = col_t; a.invdeg = invdeg;
+        a.in0 = G + slab * (p.L - 1);
+        a.slabs = G; a.slab = slab; a.masks = acts; a.dx = dx;
+        a.w0 = wp + p.bwd_off[p.L - 1]; a.wstride = p.bwd_off[p.L - 1] - p.bwd_off[p.L - 2];
+        a.flags = reinterpret_cast<unsigned*>(const_cast<char*>(wp) + p.flag_off) + kStackFlagWords;
+        (void)hipMemsetAsync(a.flags, 0, sizeof(unsigned) * kStackFlagWords, st);     // (a second backward over one forward)
+        a.status = g_stack_status;
+        HEXGNN_NT_SWITCH(p.nt, (launch_stack_bwd<NT_>(a, st)));
+    }
+    for (int l = p.L - 1; l >= first_hidden && !one_launch; --l) {
         float* out = l >= 1 ? G + slab * (l - 1) : dx;
         if (!out) break;                                   // l == 0 and nobody asked for the input gradient
         const float* ymask = l >= 1 ? acts + slab * (l - 1) : nullptr;

@@ -32,6 +32,7 @@ extern "C" {
 #define HEXGNN_EUNSUPPORTED (-2) /* shape outside the compiled kernels (hidden > 128, c_in > 8, ...) */
 #define HEXGNN_EWORKSPACE (-3)   /* workspace smaller than the matching *_bytes() query */
 #define HEXGNN_EHIP (-4)         /* HIP runtime reported an error at launch (see hexgnn_last_hip_error) */
+#define HEXGNN_ETIMEOUT (-5)     /* a one-launch stack kernel gave up waiting in its grid barrier (an EARLIER call; sticky once) */
 
 typedef void* hexgnn_stream_t; /* hipStream_t */
 
