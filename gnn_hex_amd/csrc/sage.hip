@@ -306,8 +306,11 @@ __device__ __forceinline__ void static_for_(F&& f) {
 // s_memtime at fixed points of the layer-major kernels (the last launch of each kind wins)
 __device__ unsigned long long g_lstamps[2][8][8];
 #define LSTAMP(k, p) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) g_lstamps[k][p][threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_pstamps[2][16][8];      // one-launch stack kernels: layer 8 of the mid-grid workgroup
+#define PSTAMP(k, p) do { if (it == 8 && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) g_pstamps[k][p][threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define LSTAMP(k, p) do {} while (0)
+#define PSTAMP(k, p) do {} while (0)
 #endif
 
 // ---- hidden layer, forward and backward (data) -------------------------------------------------------------------
@@ -827,6 +830,37 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     if constexpr (RL::on) {
         if (tid < RL::XS / 4) reinterpret_cast<f32x4*>(rowsl + 128 * RL::XS)[tid] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
+    // With the LDS row copy (hidden 49..112) the hand-over between two layers keeps nothing on the critical path but two LDS
+    // barriers (kV3).  Three workgroup counters behind the row copy:
+    //   ctl[0]  waves that finished the self half (the W_r region is free once all eight have, while the slower waves are
+    //           still in their aggregate half): the waves that are DONE with the layer -- they would only wait -- claim the
+    //           next layer's W_r pieces one by one (ctl[1]) and stage them, so W_r is in place when the last wave arrives;
+    //   ctl[2]  waves 0-3 stage the next layer's W_l part behind the barrier and report (a few MFMA groups into the next
+    //           self half, where they wait for their pieces -- the other four waves keep the matrix pipe busy meanwhile);
+    //           nobody enters an aggregate half before all four have.
+    // The progress counter of the block (global) is raised at the same point, after the wave's stores are acknowledged,
+    // and only then does a wave that reads other blocks' rows wait for those blocks (publishing first: two neighbouring
+    // blocks wait for each other); the global half of the gather starts kGo gaps into the self half for that reason.
+    // Rows of OTHER blocks are fetched in the TAIL of the self half (behind its last MFMA group, a ring of three landing
+    // buffers -- the LDS landing buffer is free by then): a neighbour block's counter needs a write-through acknowledge, an
+    // atomic and a poll round trip (8-10 k ticks after the layer started, profiles/r03/pstamps_*.txt); waiting for it a few
+    // groups into the self half made the edge waves of every block the slow ones of every layer.
+    constexpr bool kV3 = RL::on;
+    constexpr int kGo = kV3 ? 4 : 0;              // gap of the publish hook + 1
+    constexpr int kGt = kV3 ? (GatherLds<NT>::G > GatherLds<NT>::add_gap(kEll - 1) + 1 ? GatherLds<NT>::G
+                                                                                     : GatherLds<NT>::add_gap(kEll - 1) + 1) : 0;   // first tail gap
+    constexpr unsigned kCtlWaves = BWD ? 4u : 5u; // waves that stage something behind barrier 1 (W_l; forward: + the bias)
+    unsigned* ctl = reinterpret_cast<unsigned*>(rowsl + 129 * RL::XS);
+    float* bias_lds = reinterpret_cast<float*>(ctl + 16);         // forward: the layer's bias, 1 KiB (one LDS-DMA piece)
+    const unsigned lds_b = lds_w + (unsigned)(2 * NT * NT * 1024 + 129 * RL::XS * 4 + 64);
+    if constexpr (kV3) {
+        if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; ctl[2] = kCtlWaves; }
+        if constexpr (!BWD) {
+            if (wave == 4) dma_piece(a.b0, 16 * lane, lds_b);     // (reads past the 4 * HP bias bytes, inside the pack buffer)
+        }
+    }
+    auto lds_count = [&](int i) { return __hip_atomic_load(ctl + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+    auto lds_bump = [&](int i) { if (lane == 0) __hip_atomic_fetch_add(ctl + i, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
     wait_vmem();
     __syncthreads();
 
@@ -834,7 +868,8 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     const int deg = e1 - e0;
     using GS = GatherSched<NT>;
     using GL = GatherLds<NT>;
-    constexpr int kFillGaps = RL::on ? GL::kGaps : GS::kGaps;
+    constexpr int kRing = 4;                      // landing buffers of the tail: tb[0..2] and the registers of the self rows (dead there)
+    constexpr int kFillGaps = RL::on ? (kV3 ? kGt + kEll + kRing - 1 : GL::kGaps) : GS::kGaps;
     unsigned noff[kEll];
     unsigned loff[RL::on ? kEll / 2 : 1];
     unsigned gneed = 0;
@@ -889,7 +924,11 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     wmax = __builtin_amdgcn_readfirstlane(wmax);
     dlo = __builtin_amdgcn_readfirstlane(dlo);
     dhi = __builtin_amdgcn_readfirstlane(dhi);
-    const bool remote = dlo != blk || dhi != blk;        // wave-uniform
+    // a row with more than kEll neighbours finishes its sum from GLOBAL memory, rows of its own block included: such a wave
+    // also waits for its own block's counter (the other waves' stores acknowledged)
+    const bool longrow = __ballot(deg > kEll) != 0ull;
+    const int self_excl = longrow ? -1 : blk;
+    const bool remote = dlo != blk || dhi != blk || longrow;        // wave-uniform
 
     const float* xin = a.in0;
     for (int it = 0; it < a.n_layers; ++it) {
@@ -901,15 +940,46 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         const float* bias = BWD ? nullptr : reinterpret_cast<const float*>(a.b0 + a.wstride * (size_t)it);
         const int relu = BWD ? 1 : ((l != a.last_of_stack) || a.relu_last);
         const __amdgpu_buffer_rsrc_t xr_ = slab_rsrc(xin);
+        constexpr int KS = BWD ? 1 : 0;
+        (void)KS;
+        PSTAMP(KS, 0);
+        if constexpr (kV3) {
+            // W_l (and the bias) of THIS layer: requested by waves 0-3 (4) behind the second barrier, so that the other waves
+            // are already in their self halves; needed from the aggregate half on (ctl[2])
+            if (it > 0) {
+                const f32x4* wc = reinterpret_cast<const f32x4*>(
+                    a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)it) : (ptrdiff_t)(a.wstride * (size_t)it)));
+                if (wave < 4) {
+                    for (int pw = wave; pw < NT * NT; pw += 4) dma_piece(wc + pw * 64, 16 * lane, lds_w + pw * 1024);
+                }
+                if constexpr (!BWD) {
+                    if (wave == 4) dma_piece(a.b0 + a.wstride * (size_t)it, 16 * lane, lds_b);
+                }
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         f32x4 tb[RL::on ? 3 : GS::kWin][NT];
-        float rs[2] = {0.f, 0.f};                 // backward, LDS path: 1 / deg of the rows in the global landing ring
+        float rs[kRing] = {0.f, 0.f, 0.f, 0.f};   // backward, LDS path: 1 / deg of the rows in the global landing ring
         (void)rs;
-        if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, blk, 8u * (unsigned)it, a.status);
+        if constexpr (!kV3) {
+            if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, blk, 8u * (unsigned)it, a.status);
+        }
         auto filler_lds = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             const char* lbase = reinterpret_cast<const char*>(rowsl);
+            if constexpr (kV3 && Q == kGo - 1) {
+                if (it > 0) {
+                    wait_vmem();                  // previous layer's rows written through; waves 0-3: their W_l pieces landed
+                    if (wave < (int)kCtlWaves) lds_bump(2);
+                    if (lane == 0) __hip_atomic_fetch_add(a.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                PSTAMP(KS, 1);
+            }
+            if constexpr (kV3 && Q == kGt) {
+                if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, self_excl, 8u * (unsigned)it, a.status);
+                PSTAMP(KS, 12);
+            }
             static_for_<0, kEll>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
                 if constexpr (GL::add_gap(k) == Q) {
@@ -918,14 +988,16 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                         for (int c = 0; c < NT; ++c) ag[c] += tb[2][c];       // (backward: the LDS rows are pre-scaled)
                     }
                 }
-                if constexpr (GL::gadd_gap(k) == Q) {
+                if constexpr ((kV3 ? kGt + k + kRing - 1 : GL::gadd_gap(k)) == Q) {
+                    constexpr int rb = kV3 ? k % kRing : k % 2;
                     if (gneed & (1u << k)) {
-                        if constexpr (BWD) {
 #pragma unroll
-                            for (int c = 0; c < NT; ++c) ag[c] += tb[k % 2][c] * rs[k % 2];
-                        } else {
-#pragma unroll
-                            for (int c = 0; c < NT; ++c) ag[c] += tb[k % 2][c];
+                        for (int c = 0; c < NT; ++c) {
+                            f32x4 v;
+                            if constexpr (rb < 3) v = tb[rb][c];
+                            else v = xs[c];
+                            if constexpr (BWD) ag[c] += v * rs[rb];
+                            else ag[c] += v;
                         }
                     }
                 }
@@ -939,12 +1011,18 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
 #pragma unroll
                         for (int c = 0; c < NT; ++c) tb[2][c] = lr[4 * c];
                     }
+                }
+                if constexpr ((kV3 ? kGt + k : GL::rd_gap(k)) == Q) {
+                    constexpr int rb = kV3 ? k % kRing : k % 2;
                     if (gneed & (1u << k)) {
 #pragma unroll
-                        for (int c = 0; c < NT; ++c) tb[k % 2][c] = buf_load_coh(xr_, noff[k] + 64 * c);
+                        for (int c = 0; c < NT; ++c) {
+                            if constexpr (rb < 3) tb[rb][c] = buf_load_coh(xr_, noff[k] + 64 * c);
+                            else xs[c] = buf_load_coh(xr_, noff[k] + 64 * c);
+                        }
                         if constexpr (BWD) {      // 1 / deg of the remote source row: its id back from the byte offset
                             const unsigned j = (noff[k] - 16u * g) / (unsigned)(HP * 4);
-                            rs[k % 2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                            rs[rb] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                                 ir_, noff[k] == kOob ? kOob : j * 4u, 0, 0));
                         }
                     }
@@ -1001,6 +1079,8 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         };
         contract_rr(wlds + NT * NT * 64, xs, filler);
         static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
+        if constexpr (kV3) lds_bump(0);           // this wave's last W_r fragment has been read
+        PSTAMP(KS, 2);
         f32x4 ym[BWD ? NT : 1];
         if constexpr (BWD) {
             const __amdgpu_buffer_rsrc_t yr_ = slab_rsrc(ymask);
@@ -1032,13 +1112,19 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 }
             }
         }
+        PSTAMP(KS, 3);
+        if constexpr (kV3) {
+            while (lds_count(2) < kCtlWaves * (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);   // (W_l / bias of this layer in place)
+        }
+        PSTAMP(KS, 4);
         contract_rr(wlds, ag, [](auto) {});
+        PSTAMP(KS, 5);
         // epilogue: the stored rows ARE the next layer's self rows, in the same lane layout -> they stay in xs
         if (valid) {
             const __amdgpu_buffer_rsrc_t or_ = slab_rsrc(out);
             const unsigned oo = (unsigned)row * (unsigned)(HP * 4) + 16u * g;
             if constexpr (!BWD) {
-                const f32x4* br = reinterpret_cast<const f32x4*>(bias) + g;
+                const f32x4* br = reinterpret_cast<const f32x4*>(kV3 ? bias_lds : bias) + g;
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
                     f32x4 v = acc[t] + br[4 * t];
@@ -1065,8 +1151,36 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 }
             }
         }
+        PSTAMP(KS, 6);
         if (it + 1 == a.n_layers) break;
         // ---- between two layers ----
+        if constexpr (kV3) {
+            const f32x4* wn = reinterpret_cast<const f32x4*>(
+                a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)(it + 1)) : (ptrdiff_t)(a.wstride * (size_t)(it + 1))));
+            while (lds_count(0) < 8u * (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(2);      // every self half is over
+            PSTAMP(KS, 7);
+            bool issued = false;
+            while (true) {
+                unsigned pc = 0;
+                if (lane == 0) pc = __hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pc = __builtin_amdgcn_readfirstlane(pc);
+                if (pc >= (unsigned)(NT * NT)) break;
+                const unsigned pw = (unsigned)(NT * NT) + pc;
+                dma_piece(wn + pw * 64, 16 * lane, lds_w + pw * 1024);
+                issued = true;
+            }
+            if (issued) wait_vmem();
+            PSTAMP(KS, 8);
+            lds_barrier();            // every wave is past its MFMAs and its reads of the LDS rows; W_r of the next layer complete
+            PSTAMP(KS, 9);
+            rows_to_lds();
+            if (tid == 0) ctl[1] = 0u;
+            PSTAMP(KS, 10);
+            lds_barrier();
+            PSTAMP(KS, 11);
+            xin = out;
+            continue;
+        }
         lds_barrier();        // every wave is past its MFMAs and its reads of the LDS rows (no wait for the stores here)
         rows_to_lds();
         stage_weights(a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)(it + 1)) : (ptrdiff_t)(a.wstride * (size_t)(it + 1))));
@@ -1584,25 +1698,25 @@ template <int NT>
 static void launch_stack_fwd(const StackKArgs& a, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_stack_fwd_kernel<NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024);
         return true;
     }();
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
     if constexpr (NT >= 3)
-        sage_stack_fwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(a);
+        sage_stack_fwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
 }
 template <int NT>
 static void launch_stack_bwd(const StackKArgs& a, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_stack_bwd_kernel<NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes);
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024);
         return true;
     }();
     (void)once;
     KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
     if constexpr (NT >= 3)
-        sage_stack_bwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes, st>>>(a);
+        sage_stack_bwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
 }
 
 template <int NT>
@@ -2047,6 +2161,10 @@ int hexgnn_debug_layer_stamps(unsigned long long* out, int capacity) {
     if (capacity < 128) return HEXGNN_EINVAL;
     if (hipDeviceSynchronize() != hipSuccess) return HEXGNN_EHIP;
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(hexgnn::g_lstamps), sizeof(unsigned long long) * 128) != hipSuccess) return HEXGNN_EHIP;
+    if (capacity >= 384) {       // + the one-launch stack kernels' stamps, [2][16][8]
+        if (hipMemcpyFromSymbol(out + 128, HIP_SYMBOL(hexgnn::g_pstamps), sizeof(unsigned long long) * 256) != hipSuccess) return HEXGNN_EHIP;
+        return 384;
+    }
     return 128;
 }
 #endif

@@ -36,9 +36,20 @@ def main():
     fn = _lib.lib().hexgnn_debug_layer_stamps
     fn.restype = C.c_int
     fn.argtypes = [C.c_void_p, C.c_int]
-    buf = np.zeros(128, dtype=np.uint64)
-    assert fn(buf.ctypes.data, 128) == 128
-    st = buf.reshape(2, 8, 8).astype(np.float64)
+    buf = np.zeros(384, dtype=np.uint64)
+    assert fn(buf.ctypes.data, 384) == 384
+    st = buf[:128].reshape(2, 8, 8).astype(np.float64)
+    ps = buf[128:].reshape(2, 16, 8).astype(np.float64)
+    PN = ["layer start", "stores acked / W_l landed / flag / remote wait (gap 3)", "self half + gather done", "long rows, aggregate stored",
+          "W_l of the layer in place", "aggregate half done", "epilogue stores issued", "every self half over", "W_r pieces claimed + landed",
+          "barrier 1", "rows -> LDS, W_l pieces issued", "barrier 2", "tail: other blocks' counters seen"]
+    for k, name in enumerate(["sage_stack_fwd_kernel", "sage_stack_bwd_kernel"]):
+        if ps[k].max() == 0:
+            continue
+        t0 = ps[k, 0][ps[k, 0] > 0].min()
+        print("%s, layer 8: ticks from the workgroup's first stamp, per wave 0..7" % name)
+        for p in range(13):
+            print("  %-62s %s" % (PN[p], " ".join("%6d" % v for v in (ps[k, p] - t0))))
     for k, name in enumerate(["sage_hidden_fwd_kernel", "sage_hidden_bwd_kernel"]):
         t0 = st[k, 0].min()
         print("%s: ticks from the workgroup's first stamp, per wave 0..7" % name)
