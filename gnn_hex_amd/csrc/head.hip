@@ -345,11 +345,24 @@ __global__ __launch_bounds__(256) void head_value_wgrad_kernel(int b, int H, con
                                                              const float* __restrict__ pooled,
                                                              const float* __restrict__ z, float* __restrict__ d_v0_w,
                                                              float* __restrict__ d_v0_b, float* __restrict__ d_v1_w,
-                                                             float* __restrict__ d_v1_b) {
+                                                             float* __restrict__ d_v1_b, int hp,
+                                                             const float* __restrict__ lin_part,
+                                                             float* __restrict__ d_lin_w, float* __restrict__ d_lin_b) {
     __shared__ float red[3][64];
     const int H2 = H / 2, H4 = 4 * H;
     const int k = blockIdx.y;
     const int tid = threadIdx.x, cl = tid & 63, ph = tid >> 6;
+    if (k == H2) {      // the extra row of workgroups: the advantage linear's gradient from the per-graph partials (one wave
+                        // per column, same order as head_lin_grad_reduce_kernel)
+        for (int c = blockIdx.x * 4 + ph; c <= H; c += 4 * gridDim.x) {
+            const int src = c < H ? c : hp;
+            float s = 0.f;
+            for (int g = cl; g < b; g += 64) s += lin_part[(size_t)g * (hp + 1) + src];
+            s = wave_sum(s);
+            if (cl == 0) { if (c < H) d_lin_w[c] = s; else d_lin_b[0] = s; }
+        }
+        return;
+    }
     const int c = blockIdx.x * 64 + cl;
     float s = 0.f;
     if (c < H4) {
@@ -737,10 +750,11 @@ int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const 
                             const float* z, const float* lin_part, float* d_lin_w, float* d_lin_b, float* d_v0_w,
                             float* d_v0_b, float* d_v1_w, float* d_v1_b, hipStream_t st) {
     const int hp = padded_width(hidden), H2 = hidden / 2, H4 = 4 * hidden;
-    if (mode != 2 && mode != 4 && H2 > 0)
-        head_value_wgrad_kernel<<<dim3((H4 + 63) / 64, H2), 256, 0, st>>>(b, hidden, dz, dvr, pooled, z, d_v0_w, d_v0_b,
-                                                                          d_v1_w, d_v1_b);
-    head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, lin_part, d_lin_w, d_lin_b);
+    if (mode != 2 && mode != 4 && H2 > 0)       // one launch: the value MLP's gradients + (last row of workgroups) the linear's
+        head_value_wgrad_kernel<<<dim3((H4 + 63) / 64, H2 + 1), 256, 0, st>>>(b, hidden, dz, dvr, pooled, z, d_v0_w, d_v0_b,
+                                                                              d_v1_w, d_v1_b, hp, lin_part, d_lin_w, d_lin_b);
+    else
+        head_lin_grad_reduce_kernel<<<hidden + 1, 64, 0, st>>>(b, hp, hidden, lin_part, d_lin_w, d_lin_b);
     return HEXGNN_OK;
 }
 

@@ -845,7 +845,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     // buffers -- the LDS landing buffer is free by then): a neighbour block's counter needs a write-through acknowledge, an
     // atomic and a poll round trip (8-10 k ticks after the layer started, profiles/r03/pstamps_*.txt); waiting for it a few
     // groups into the self half made the edge waves of every block the slow ones of every layer.
-    constexpr bool kV3 = RL::on;
+    constexpr bool kV3 = RL::on && !BWD;      // (backward: the plain hand-over measured faster, 349 vs 357 us per MIX launch)
     constexpr int kGo = kV3 ? 4 : 0;              // gap of the publish hook + 1
     constexpr int kGt = kV3 ? (GatherLds<NT>::G > GatherLds<NT>::add_gap(kEll - 1) + 1 ? GatherLds<NT>::G
                                                                                      : GatherLds<NT>::add_gap(kEll - 1) + 1) : 0;   // first tail gap
@@ -929,6 +929,11 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     const bool longrow = __ballot(deg > kEll) != 0ull;
     const int self_excl = longrow ? -1 : blk;
     const bool remote = dlo != blk || dhi != blk || longrow;        // wave-uniform
+    // the counters are never reset between launches over the same pack buffer (a second backward over one forward): every
+    // block ends a launch at the same value, 8 x (layers - 1) above where it started, so a block's own counter at kernel
+    // start is everybody's starting value
+    const unsigned fbase = __builtin_amdgcn_readfirstlane(
+        __hip_atomic_load(a.flags + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
 
     const float* xin = a.in0;
     for (int it = 0; it < a.n_layers; ++it) {
@@ -963,7 +968,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         float rs[kRing] = {0.f, 0.f, 0.f, 0.f};   // backward, LDS path: 1 / deg of the rows in the global landing ring
         (void)rs;
         if constexpr (!kV3) {
-            if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, blk, 8u * (unsigned)it, a.status);
+            if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, blk, fbase + 8u * (unsigned)it, a.status);
         }
         auto filler_lds = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
@@ -977,7 +982,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 PSTAMP(KS, 1);
             }
             if constexpr (kV3 && Q == kGt) {
-                if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, self_excl, 8u * (unsigned)it, a.status);
+                if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, self_excl, fbase + 8u * (unsigned)it, a.status);
                 PSTAMP(KS, 12);
             }
             static_for_<0, kEll>([&](auto kk) {
@@ -2025,7 +2030,6 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
         a.slabs = G; a.slab = slab; a.masks = acts; a.dx = dx;
         a.w0 = wp + p.bwd_off[p.L - 1]; a.wstride = p.bwd_off[p.L - 1] - p.bwd_off[p.L - 2];
         a.flags = reinterpret_cast<unsigned*>(const_cast<char*>(wp) + p.flag_off) + kStackFlagWords;
-        (void)hipMemsetAsync(a.flags, 0, sizeof(unsigned) * kStackFlagWords, st);     // (a second backward over one forward)
         a.status = g_stack_status;
         HEXGNN_NT_SWITCH(p.nt, (launch_stack_bwd<NT_>(a, st)));
     }
