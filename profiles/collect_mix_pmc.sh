@@ -23,6 +23,6 @@ for sub in ("fetch","write","l2","mfma","sq"):
         k = (r["Kernel_Name"].split("(")[0][-40:], r["Counter_Name"])
         tot[k] += float(r["Counter_Value"]); cnt[k] += 1
     for k in sorted(tot):
-        if any(s in k[0] for s in ("sage_hidden", "head_fwd", "head_bwd", "sage_dw_kernel")):
+        if any(s in k[0] for s in ("sage_hidden", "sage_stack", "head_fwd", "head_bwd", "sage_dw_kernel")):
             print(sub, k[0], k[1], round(tot[k] / cnt[k], 1), cnt[k])
 PY

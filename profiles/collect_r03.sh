@@ -13,6 +13,7 @@ B="$R/bench.py --no-cpu-baseline --no-split --no-other-configs --no-collective-p
 for m in ${PROFILE_MODES:-fp32}; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$m -o s -- python3 $B --math $m --steps 20 --warmup 5 > $O/stats_$m.log 2>&1
   echo "stats $m done"
+  [ -n "$PROFILE_SKIP_PMC" ] && continue        # (re-collection of the kernel times only: the PMC figures stay valid)
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/fetch_$m -o p -- python3 $B --math $m --steps 8 --warmup 2 > $O/fetch_$m.log 2>&1
   echo "fetch $m done"
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $O/write_$m -o p -- python3 $B --math $m --steps 8 --warmup 2 > $O/write_$m.log 2>&1
@@ -43,7 +44,7 @@ mkdir -p $S
 cp $O/stats_fp32/s_kernel_stats.csv $S/kernel_stats_fp32.csv
 cp $O/stats_S256/s_kernel_stats.csv $S/kernel_stats_S256.csv
 cp $O/stats_MIX/s_kernel_stats.csv $S/kernel_stats_MIX.csv
-python3 profiles/pmc_to_json.py $O fp32 > $S/traffic_pmc.json
+[ -z "$PROFILE_SKIP_PMC" ] && python3 profiles/pmc_to_json.py $O fp32 > $S/traffic_pmc.json
 cp $O/bench_*.json $S/
 rm -rf $O
 ls -la $S

@@ -49,6 +49,8 @@ def main():
         t0 = ps[k, 0][ps[k, 0] > 0].min()
         print("%s, layer 8: ticks from the workgroup's first stamp, per wave 0..7" % name)
         for p in range(13):
+            if ps[k, p].max() == 0:
+                continue                     # (a point this kernel's hand-over does not pass)
             print("  %-62s %s" % (PN[p], " ".join("%6d" % v for v in (ps[k, p] - t0))))
     for k, name in enumerate(["sage_hidden_fwd_kernel", "sage_hidden_bwd_kernel"]):
         t0 = st[k, 0].min()
