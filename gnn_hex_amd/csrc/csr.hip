@@ -3,7 +3,7 @@
 //
 // Replaces the per-layer edge_index indexing of torch_geometric's propagate (GN0/models.py:276)
 // and torch_geometric Batch.ptr / torch_scatter's segment lookup (GN0/models.py:381,578).
-#include "hexgnn_common.h"
+#include "hexgnn_internal.h"
 
 namespace hexgnn {
 
@@ -324,7 +324,7 @@ const char* hexgnn_strerror(int code) {
 
 int hexgnn_last_hip_error(void) { return g_last_hip_error; }
 
-int hexgnn_padded_width(int hidden) { return padded_width(hidden); }
+int hexgnn_padded_width(int hidden) { return padded_width_wide(hidden); }      // (129..256: the plain kernels of wide.hip)
 
 size_t hexgnn_csr_workspace_bytes(int n, int e) {
     (void)e;
@@ -399,7 +399,7 @@ int hexgnn_graph_ptr(int n, int b, const int64_t* batch, int* gptr, hexgnn_strea
 }
 
 int hexgnn_pad_rows(int n, int hidden, const float* src, int src_stride, float* dst, hexgnn_stream_t stream_) {
-    const int hp = padded_width(hidden);
+    const int hp = padded_width_wide(hidden);
     if (hp < 0) return HEXGNN_EUNSUPPORTED;
     if (n < 0 || (n > 0 && (!src || !dst)) || src_stride < hidden) return HEXGNN_EINVAL;
     if (n == 0) return HEXGNN_OK;
@@ -409,7 +409,7 @@ int hexgnn_pad_rows(int n, int hidden, const float* src, int src_stride, float* 
 }
 
 int hexgnn_unpad_rows(int n, int hidden, const float* src, float* dst, int dst_stride, hexgnn_stream_t stream_) {
-    const int hp = padded_width(hidden);
+    const int hp = padded_width_wide(hidden);
     if (hp < 0) return HEXGNN_EUNSUPPORTED;
     if (n < 0 || (n > 0 && (!src || !dst)) || dst_stride < hidden) return HEXGNN_EINVAL;
     if (n == 0) return HEXGNN_OK;

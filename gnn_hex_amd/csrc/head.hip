@@ -25,7 +25,7 @@ HeadSaved head_saved_plan(int n, int b, int hidden) {
 
 HeadWs head_ws_plan(int n, int b, int hidden) {
     HeadWs w;
-    const int hp = padded_width(hidden), h2 = hidden / 2;
+    const int hp = padded_width_wide(hidden), h2 = hidden / 2;
     size_t off = 0;
     w.dadv_off = off; off += align_up(sizeof(float) * (size_t)n, 256);
     w.dz_off = off; off += align_up(sizeof(float) * (size_t)b * (h2 > 0 ? h2 : 1), 256);
@@ -118,6 +118,17 @@ __global__ __launch_bounds__(256) void head_fwd_kernel(
             // eight rows' loads in flight per step (the loop-carried sum / extremum chain is cheap; one load per iteration
             // made the loop cost a memory round trip per row: 47 us for a 171-row graph)
             int row = r0 + ph;
+            for (; row + 30 < r1; row += 32) {      // sixteen rows' loads in flight (same order of the sums and comparisons)
+                float v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = h[(size_t)(row + 2 * u) * hp + c];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) {
+                    sum += v[u];
+                    if (v[u] > mx) { mx = v[u]; ax = row + 2 * u; }
+                    if (v[u] < mn) { mn = v[u]; an = row + 2 * u; }
+                }
+            }
             for (; row + 14 < r1; row += 16) {
                 float v[8];
 #pragma unroll
@@ -313,6 +324,17 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         const int c = tid & 127, ph = tid >> 7;
         float acc = 0.f, accb = 0.f;
         int row = r0 + ph;
+        for (; row + 30 < r1 && c < hp; row += 32) {        // sixteen rows' loads in flight per step, same summation order
+            float v[16], d[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int rr = row + 2 * u;
+                v[u] = h[(size_t)rr * hp + c];
+                d[u] = (rr - r0 < 1024) ? s_dar[rr - r0] : dadv[rr];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { acc += d[u] * v[u]; accb += d[u]; }
+        }
         for (; row + 14 < r1 && c < hp; row += 16) {        // eight rows' loads in flight per step, same summation order
             float v[8], d[8];
 #pragma unroll
@@ -749,7 +771,7 @@ __global__ __launch_bounds__(256) void policy_lsm_bwd_kernel(int b, const int* _
 int launch_head_param_grads(int b, int hidden, int mode, const float* dz, const float* dvr, const float* pooled,
                             const float* z, const float* lin_part, float* d_lin_w, float* d_lin_b, float* d_v0_w,
                             float* d_v0_b, float* d_v1_w, float* d_v1_b, hipStream_t st) {
-    const int hp = padded_width(hidden), H2 = hidden / 2, H4 = 4 * hidden;
+    const int hp = padded_width_wide(hidden), H2 = hidden / 2, H4 = 4 * hidden;
     if (mode != 2 && mode != 4 && H2 > 0)       // one launch: the value MLP's gradients + (last row of workgroups) the linear's
         head_value_wgrad_kernel<<<dim3((H4 + 63) / 64, H2 + 1), 256, 0, st>>>(b, hidden, dz, dvr, pooled, z, d_v0_w, d_v0_b,
                                                                               d_v1_w, d_v1_b, hp, lin_part, d_lin_w, d_lin_b);
@@ -994,14 +1016,14 @@ int hexgnn_td_loss_forward_backward(int n, int k, const float* q, const int64_t*
 }
 
 size_t hexgnn_head_saved_bytes(int n, int b, int hidden) {
-    if (n < 0 || b < 0 || padded_width(hidden) < 0) return 0;
+    if (n < 0 || b < 0 || padded_width_wide(hidden) < 0) return 0;
     return head_saved_plan(n, b, hidden).total;
 }
 
 int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
                         const float* lin_b, const float* v0_w, const float* v0_b, const float* v1_w,
                         const float* v1_b, float* q, float* out_v, void* saved, hexgnn_stream_t stream_) {
-    const int hp = padded_width(hidden);
+    const int hp = padded_width_wide(hidden);
     if (hp < 0 || hidden < 2) return HEXGNN_EUNSUPPORTED;
     if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
     if (!gptr || !lin_w || !lin_b || !saved) return HEXGNN_EINVAL;
@@ -1009,6 +1031,9 @@ int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, con
     if ((mode == 1 || mode == 3) && !out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!h || !q)) return HEXGNN_EINVAL;
     if (b == 0) return HEXGNN_OK;
+    if (hidden > 16 * kMaxNT)
+        return wide_head_forward(n, b, hidden, mode, gptr, h, lin_w, lin_b, v0_w, v0_b, v1_w, v1_b, q, out_v, saved,
+                                 (hipStream_t)stream_);
     const HeadSaved s = head_saved_plan(n, b, hidden);
     char* sv = (char*)saved;
     KernelTimer kt(HEXGNN_K_HEAD_FWD, (hipStream_t)stream_);
@@ -1020,7 +1045,7 @@ int hexgnn_head_forward(int n, int b, int hidden, int mode, const int* gptr, con
 }
 
 size_t hexgnn_head_backward_workspace_bytes(int n, int b, int hidden) {
-    if (n < 0 || b < 0 || padded_width(hidden) < 0) return 0;
+    if (n < 0 || b < 0 || padded_width_wide(hidden) < 0) return 0;
     return head_ws_plan(n, b, hidden).total;
 }
 
@@ -1030,8 +1055,9 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
                          float* d_v0_b, float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes,
                          hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
-    const int hp = padded_width(hidden);
+    const int hp = padded_width_wide(hidden);
     if (hp < 0 || hidden < 2) return HEXGNN_EUNSUPPORTED;
+    const int mode_in = mode;
     const int mask_dh = (mode & HEXGNN_HEAD_MASK_DH) ? 1 : 0;
     mode &= ~HEXGNN_HEAD_MASK_DH;
     if (n < 0 || b < 0 || mode < 0 || mode > 4) return HEXGNN_EINVAL;
@@ -1039,6 +1065,9 @@ int hexgnn_head_backward(int n, int b, int hidden, int mode, const int* gptr, co
     if (mode != 2 && mode != 4 && (!v0_w || !v1_w || !d_v0_w || !d_v0_b || !d_v1_w || !d_v1_b)) return HEXGNN_EINVAL;
     if ((mode == 1 || mode == 3) && !d_out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!h || !dq || !dh)) return HEXGNN_EINVAL;
+    if (hidden > 16 * kMaxNT)
+        return wide_head_backward(n, b, hidden, mode_in, gptr, h, lin_w, v0_w, v1_w, saved, dq, d_out_v, dh, d_lin_w, d_lin_b,
+                                  d_v0_w, d_v0_b, d_v1_w, d_v1_b, workspace, workspace_bytes, st);
     const HeadWs w = head_ws_plan(n, b, hidden);
     if (!workspace || workspace_bytes < w.total) return HEXGNN_EWORKSPACE;
     const HeadSaved s = head_saved_plan(n, b, hidden);

@@ -52,6 +52,32 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
 // one launch and gets the first layer's per-graph partials from its backward kernel).
 // math 1: f16x3 split with per-layer power-of-two scales from xmax[l] = max |[agg_l | x_l]|, gmax[l] = max |G_l| (bit patterns)
 
+// ---- hidden 129..256 (wide.hip): plain kernels behind the same entry points ------------------------------------------------
+constexpr int kWideMaxHidden = 256;
+int padded_width_wide(int hidden);           // 16-multiple up to 256, -1 beyond
+struct WidePlan {
+    int hp, L;
+    bool small_first;
+    size_t w_off[kMaxLayers], bias_off[kMaxLayers], pack_bytes;
+    size_t agg_off[kMaxLayers], saved_bytes;
+    size_t g_off, tmp_off, bwd_bytes;
+};
+int wide_make_plan(int n, int c_in, int hidden, int L, WidePlan* p);
+int wide_stack_forward(int n, int c_in, int hidden, int L, const int* rowptr, const int* col, const float* invdeg,
+                       const float* x, int x_stride, const float* const* wl, const float* const* bl,
+                       const float* const* wr, void* wpack, float* acts, void* saved, int flags, hipStream_t st);
+int wide_stack_backward(int n, int c_in, int hidden, int L, const int* rowptr_t, const int* col_t, const float* invdeg,
+                        const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                        const float* dy, float* dx, float* const* d_wl, float* const* d_bl, float* const* d_wr,
+                        void* workspace, size_t workspace_bytes, int flags, int tap_layer, float* tap_out, hipStream_t st);
+int wide_head_forward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
+                      const float* lin_b, const float* v0_w, const float* v0_b, const float* v1_w, const float* v1_b,
+                      float* q, float* out_v, void* saved, hipStream_t st);
+int wide_head_backward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
+                       const float* v0_w, const float* v1_w, const void* saved, const float* dq, const float* d_out_v,
+                       float* dh, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b, float* d_v1_w,
+                       float* d_v1_b, void* workspace, size_t workspace_bytes, hipStream_t st);
+
 struct HeadSaved { size_t adv_off, pooled_off, amax_off, amin_off, z_off, v_off, total; };
 HeadSaved head_saved_plan(int n, int b, int hidden);
 struct HeadWs { size_t dadv_off, dz_off, dvr_off, part_off, total; };

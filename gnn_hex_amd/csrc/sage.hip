@@ -1876,12 +1876,14 @@ using namespace hexgnn;
 extern "C" {
 
 size_t hexgnn_sage_stack_pack_bytes(int c_in, int hidden, int num_layers) {
+    if (hidden > 16 * kMaxNT) { WidePlan w; return wide_make_plan(0, c_in, hidden, num_layers, &w) == HEXGNN_OK ? w.pack_bytes : 0; }
     StackPlan p;
     if (make_plan(0, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
     return p.pack_bytes;
 }
 
 size_t hexgnn_sage_stack_saved_bytes(int n, int c_in, int hidden, int num_layers) {
+    if (hidden > 16 * kMaxNT) { WidePlan w; return (n >= 0 && wide_make_plan(n, c_in, hidden, num_layers, &w) == HEXGNN_OK) ? w.saved_bytes : 0; }
     StackPlan p;
     if (n < 0 || make_plan(n, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
     return p.saved_bytes;
@@ -1894,6 +1896,12 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
+    if (hidden > 16 * kMaxNT) {        // 129..256: the plain kernels of wide.hip (always materialise the aggregates in `saved`)
+        if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
+        if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts)) return HEXGNN_EINVAL;
+        return wide_stack_forward(n, c_in, hidden, num_layers, rowptr, col, invdeg, x, x_stride, wl, bl, wr, wpack, acts, saved,
+                                  flags, st);
+    }
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
@@ -1945,6 +1953,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
 }
 
 size_t hexgnn_sage_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers) {
+    if (hidden > 16 * kMaxNT) { WidePlan w; return (n >= 0 && wide_make_plan(n, c_in, hidden, num_layers, &w) == HEXGNN_OK) ? w.bwd_bytes : 0; }
     StackPlan p;
     if (n < 0 || make_plan(n, c_in, hidden, num_layers, &p) != HEXGNN_OK) return 0;
     BwdPlan b;
@@ -1974,6 +1983,12 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
     StackPlan p;
     if (n < 0 || (flags & ~(HEXGNN_SAGE_LINEAR_LAST | HEXGNN_SAGE_DY_IN_PLACE))) return HEXGNN_EINVAL;
     if ((flags & HEXGNN_SAGE_DY_IN_PLACE) && (flags & HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
+    if (hidden > 16 * kMaxNT) {
+        if (!d_wl || !d_bl || !d_wr || !wpack || !saved) return HEXGNN_EINVAL;
+        if (n > 0 && (!rowptr_t || !col_t || !invdeg || !x || !acts || !dy)) return HEXGNN_EINVAL;
+        return wide_stack_backward(n, c_in, hidden, num_layers, rowptr_t, col_t, invdeg, x, x_stride, acts, saved, wpack, dy, dx,
+                                   d_wl, d_bl, d_wr, workspace, workspace_bytes, flags, tap_layer, tap_out, st);
+    }
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     BwdPlan b;

@@ -1,0 +1,581 @@
+// hidden_channels 129..256: the SAGE stack and the head tail beyond the widths the LDS-resident kernels are compiled for.
+//
+// Reference: CachifiedGNN.grow_width / DuellingTwoHeaded.grow_width widen a model to ANY width (GN0/models.py:187-238,
+// 497-508); no configuration of the reference goes past 110, so this path is built for coverage, not for speed: plain,
+// deterministic kernels -- a mean gather (HBM-bound), one exact-fp32 MFMA GEMM streaming its operands from L2 (no LDS
+// staging, no fusion with the gather), transposed weight copies for the backward, one wave per 16 x 16 weight-gradient tile
+// running over all rows in a fixed order, simple per-graph head-tail kernels.  Same arithmetic as the narrow kernels
+// (v_mfma_f32_16x16x4_f32, fmaf chains in k order), same saved-tensor layout (acts [L][n][HP], agg per layer), same C entry
+// points (sage.hip / head.hip dispatch here when hidden > 128).  Not covered at these widths: the fused per-graph kernels, the
+// norms, the two_headed tail and the HexAra pieces (their entry points refuse loudly).
+#include "hexgnn_internal.h"
+
+namespace hexgnn {
+
+int padded_width_wide(int hidden) {
+    if (hidden <= 0 || hidden > kWideMaxHidden) return -1;
+    return 16 * ((hidden + 15) / 16);
+}
+
+// ---- plans -------------------------------------------------------------------------------------------------------------
+// wpack (per layer): raw first layer [HP][8] Wl, [HP][8] Wr, bias[HP]; hidden layer: WlP, WrP (forward operands, [HP][HP],
+// row = output channel, zero padded), WlT, WrT (their transposes: backward operands), bias[HP].
+int wide_make_plan(int n, int c_in, int hidden, int L, WidePlan* p) {
+    const int hp = padded_width_wide(hidden);
+    if (hp < 0 || L < 1 || L > kMaxLayers) return HEXGNN_EUNSUPPORTED;
+    if (c_in != hidden && (c_in < 1 || c_in > kSmallCin)) return HEXGNN_EUNSUPPORTED;
+    if (n > 0 && (size_t)n * hp * sizeof(float) > 0x7fffffffull) return HEXGNN_EUNSUPPORTED;
+    p->hp = hp; p->L = L; p->small_first = c_in != hidden;
+    size_t off = 0, soff = 0;
+    const size_t sq = sizeof(float) * (size_t)hp * hp;
+    for (int l = 0; l < L; ++l) {
+        if (l == 0 && p->small_first) {
+            p->w_off[l] = off; off += sizeof(float) * (size_t)hp * kSmallCin * 2;
+            p->agg_off[l] = soff; soff += align_up(sizeof(float) * (size_t)n * kSmallCin, 256);
+        } else {
+            p->w_off[l] = off; off += 4 * sq;
+            p->agg_off[l] = soff; soff += align_up(sizeof(float) * (size_t)n * hp, 256);
+        }
+        p->bias_off[l] = off; off += align_up(sizeof(float) * hp, 256);
+    }
+    p->pack_bytes = off;
+    p->saved_bytes = soff;
+    // backward workspace: G [L][n][HP], two scratch slabs (dAgg, dXs)
+    const size_t slab = align_up(sizeof(float) * (size_t)n * hp, 256);
+    p->g_off = 0;
+    p->tmp_off = slab * L;
+    p->bwd_bytes = slab * (L + 2);
+    return HEXGNN_OK;
+}
+
+struct WidePackArgs {
+    const float* wl[kMaxLayers];
+    const float* bl[kMaxLayers];
+    const float* wr[kMaxLayers];
+    size_t w_off[kMaxLayers], bias_off[kMaxLayers];
+    int hp, hidden, c_in, small_first;
+};
+
+__global__ void wide_pack_kernel(WidePackArgs a, char* __restrict__ wpack) {
+    const int l = blockIdx.y, hp = a.hp, H = a.hidden;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    float* bias = (float*)(wpack + a.bias_off[l]);
+    if (tid < hp) bias[tid] = tid < H ? a.bl[l][tid] : 0.f;
+    if (l == 0 && a.small_first) {
+        float* w0 = (float*)(wpack + a.w_off[l]);
+        const int tot = hp * kSmallCin;
+        if (tid < tot) {
+            const int o = tid / kSmallCin, q = tid % kSmallCin;
+            const bool ok = o < H && q < a.c_in;
+            w0[tid] = ok ? a.wl[l][o * a.c_in + q] : 0.f;
+            w0[tot + tid] = ok ? a.wr[l][o * a.c_in + q] : 0.f;
+        }
+        return;
+    }
+    if (tid >= hp * hp) return;
+    const int r = tid / hp, c = tid % hp;
+    float* w = (float*)(wpack + a.w_off[l]);
+    const size_t sq = (size_t)hp * hp;
+    const bool ok = r < H && c < H;
+    w[tid] = ok ? a.wl[l][r * H + c] : 0.f;                 // WlP[o = r][k = c]
+    w[sq + tid] = ok ? a.wr[l][r * H + c] : 0.f;            // WrP
+    w[2 * sq + tid] = ok ? a.wl[l][c * H + r] : 0.f;        // WlT[i = r][o = c]
+    w[3 * sq + tid] = ok ? a.wr[l][c * H + r] : 0.f;        // WrT
+}
+
+// ---- raw first layer (c_in <= 8) ------------------------------------------------------------------------------------------
+__global__ void wide_first_agg_kernel(int n, int c_in, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                      const float* __restrict__ invdeg, const float* __restrict__ x, int xs,
+                                      float* __restrict__ agg0 /*[n][8]*/) {
+    const int row = blockIdx.x * blockDim.x + threadIdx.x;
+    if (row >= n) return;
+    float a[kSmallCin];
+#pragma unroll
+    for (int q = 0; q < kSmallCin; ++q) a[q] = 0.f;
+    for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) {
+        const float* xr = x + (size_t)col[e] * xs;
+#pragma unroll
+        for (int q = 0; q < kSmallCin; ++q) if (q < c_in) a[q] += xr[q];
+    }
+    const float sc = invdeg[row];
+#pragma unroll
+    for (int q = 0; q < kSmallCin; ++q) agg0[(size_t)row * kSmallCin + q] = a[q] * sc;
+}
+
+__global__ void wide_first_out_kernel(int n, int c_in, int hp, const float* __restrict__ agg0, const float* __restrict__ x,
+                                      int xs, const float* __restrict__ w0, const float* __restrict__ bias,
+                                      float* __restrict__ y, int relu) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * hp) return;
+    const int row = (int)(i / hp), c = (int)(i % hp);
+    const float* wl = w0 + (size_t)c * kSmallCin;
+    const float* wr = w0 + (size_t)hp * kSmallCin + (size_t)c * kSmallCin;
+    float v = bias[c];
+#pragma unroll
+    for (int q = 0; q < kSmallCin; ++q) {
+        const float xq = q < c_in ? x[(size_t)row * xs + q] : 0.f;
+        v += wl[q] * agg0[(size_t)row * kSmallCin + q] + wr[q] * xq;
+    }
+    y[i] = (v > 0.f || !relu) ? v : 0.f;
+}
+
+// d w0: thread (o, q, which) walks all rows in order (deterministic); one block = 16 outputs x (8 + 8) inputs
+__global__ __launch_bounds__(256) void wide_first_dw_kernel(int n, int c_in, int H, int hp, const float* __restrict__ G,
+                                                           const float* __restrict__ agg0, const float* __restrict__ x,
+                                                           int xs, float* __restrict__ d_wl, float* __restrict__ d_wr) {
+    const int o = blockIdx.x * 16 + (threadIdx.x >> 4), qq = threadIdx.x & 15;
+    const int which = qq >> 3, q = qq & 7;
+    if (o >= H || q >= c_in) return;
+    float acc = 0.f;
+    for (int m = 0; m < n; ++m) {
+        const float g = G[(size_t)m * hp + o];
+        const float v = which == 0 ? agg0[(size_t)m * kSmallCin + q] : x[(size_t)m * xs + q];
+        acc += g * v;
+    }
+    (which == 0 ? d_wl : d_wr)[o * c_in + q] = acc;
+}
+
+// ---- mean gather: out[i] = s_i * sum_{j in N(i)} x[j]  (16-byte column groups) ----------------------------------------------
+__global__ void wide_gather_kernel(int n, int hp, const int* __restrict__ rowptr, const int* __restrict__ col,
+                                   const float* __restrict__ scale, const float* __restrict__ x, float* __restrict__ out) {
+    const int q4 = hp / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * q4) return;
+    const int row = (int)(i / q4), p = (int)(i % q4);
+    f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int e = rowptr[row]; e < rowptr[row + 1]; ++e) v += reinterpret_cast<const f32x4*>(x + (size_t)col[e] * hp)[p];
+    reinterpret_cast<f32x4*>(out + (size_t)row * hp)[p] = v * scale[row];
+}
+
+// ---- C[m][n] = epi( sum_k A1[m][k] W1[n][k] (+ sum_k A2[m][k] W2[n][k]) + bias[n] ) * rowscale[m] --------------------------
+// All operands in the padded layout (row stride HP, pad columns / rows zero).  Block = 4 waves = 64 rows x 64 columns; a
+// wave = 16 rows x four 16-column tiles; k in chunks of 16 (one 16-byte load per lane and operand, four MFMAs per tile).
+// Operands swapped (a = weight fragment, b = row fragment): lane (i, kk) ends with C[m0 + i][n0 + 4 kk .. + 3].
+__global__ __launch_bounds__(256) void wide_gemm_kernel(int M, int hp, const float* __restrict__ A1, const float* __restrict__ W1,
+                                                       const float* __restrict__ A2, const float* __restrict__ W2,
+                                                       const float* __restrict__ bias, const float* __restrict__ rowscale,
+                                                       int relu, float* __restrict__ C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int m0 = blockIdx.x * 64 + wave * 16, nb = blockIdx.y * 64;
+    const int row = m0 + i;
+    const bool rv = row < M;
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pass = 0; pass < 2; ++pass) {
+        const float* A = pass == 0 ? A1 : A2;
+        const float* W = pass == 0 ? W1 : W2;
+        if (!A) continue;
+        for (int k0 = 0; k0 < hp; k0 += 16) {
+            const f32x4 a4 = rv ? *reinterpret_cast<const f32x4*>(A + (size_t)row * hp + k0 + 4 * kk) : z4;
+            f32x4 w4[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int nn = nb + 16 * t + i;
+                w4[t] = nn < hp ? *reinterpret_cast<const f32x4*>(W + (size_t)nn * hp + k0 + 4 * kk) : z4;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[t] = mfma16x16x4(w4[t][j], a4[j], acc[t]);
+            }
+        }
+    }
+    if (!rv) return;
+    const float rs = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const int nn = nb + 16 * t + 4 * kk;
+        if (nn >= hp) continue;
+        f32x4 v = acc[t];
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + nn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((v[q] > 0.f || !relu) ? v[q] : 0.f) * rs;
+        *reinterpret_cast<f32x4*>(C + (size_t)row * hp + nn) = v;
+    }
+}
+
+// ---- weight gradient: one wave per 16 x 16 tile of dW[o][i] = sum_m G[m][o] X[m][i], all rows in order -----------------------
+// lane (i, kk): a = G[m + 4 kk + j][o0 + i], b = X[m + 4 kk + j][i0 + i]; acc[r] = dW[o0 + 4 kk + r][i0 + i].
+__global__ __launch_bounds__(64) void wide_dw_kernel(int n, int H, int hp, const float* __restrict__ G,
+                                                    const float* __restrict__ X, float* __restrict__ dW /*[H][H]*/) {
+    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
+    const int o0 = blockIdx.x * 16, i0 = blockIdx.y * 16;
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < n; m += 16) {
+        float a[4], b[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = m + 4 * kk + j;
+            a[j] = r < n ? G[(size_t)r * hp + o0 + i] : 0.f;
+            b[j] = r < n ? X[(size_t)r * hp + i0 + i] : 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc = mfma16x16x4(a[j], b[j], acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = o0 + 4 * kk + r, c = i0 + i;
+        if (o < H && c < H) dW[(size_t)o * H + c] = acc[r];
+    }
+}
+
+// column sums of G (the bias gradient): block = 16 columns x 16 row phases, fixed-order combine
+__global__ __launch_bounds__(256) void wide_colsum_kernel(int n, int H, int hp, const float* __restrict__ G,
+                                                         float* __restrict__ d_b) {
+    __shared__ float s[16][17];
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4;
+    float acc = 0.f;
+    if (c < hp) {
+        for (int m = ph; m < n; m += 16) acc += G[(size_t)m * hp + c];
+    }
+    s[ph][threadIdx.x & 15] = acc;
+    __syncthreads();
+    if (ph == 0 && c < H) {
+        float t = 0.f;
+        for (int p = 0; p < 16; ++p) t += s[p][threadIdx.x & 15];
+        d_b[c] = t;
+    }
+}
+
+// out = a * [y > 0] (or a)
+__global__ void wide_mask_kernel(int64_t tot4, const float* __restrict__ a, const float* __restrict__ ymask,
+                                 float* __restrict__ out) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= tot4) return;
+    f32x4 v = reinterpret_cast<const f32x4*>(a)[i];
+    if (ymask) {
+        const f32x4 y = reinterpret_cast<const f32x4*>(ymask)[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = y[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(out)[i] = v;
+}
+
+// out[i] = (dxs[i] + sum_{j in T(i)} dagg[j]) * [y_i > 0]   (dagg rows already carry their 1 / deg_j)
+__global__ void wide_combine_kernel(int n, int hp, const int* __restrict__ rowptr_t, const int* __restrict__ col_t,
+                                    const float* __restrict__ dxs, const float* __restrict__ dagg,
+                                    const float* __restrict__ ymask, float* __restrict__ out) {
+    const int q4 = hp / 4;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)n * q4) return;
+    const int row = (int)(i / q4), p = (int)(i % q4);
+    f32x4 v = reinterpret_cast<const f32x4*>(dxs + (size_t)row * hp)[p];
+    for (int e = rowptr_t[row]; e < rowptr_t[row + 1]; ++e)
+        v += reinterpret_cast<const f32x4*>(dagg + (size_t)col_t[e] * hp)[p];
+    if (ymask) {
+        const f32x4 yv = reinterpret_cast<const f32x4*>(ymask + (size_t)row * hp)[p];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = yv[j] > 0.f ? v[j] : 0.f;
+    }
+    reinterpret_cast<f32x4*>(out + (size_t)row * hp)[p] = v;
+}
+
+static void gemm(int n, int hp, const float* A1, const float* W1, const float* A2, const float* W2, const float* bias,
+                 const float* rowscale, int relu, float* C, hipStream_t st) {
+    wide_gemm_kernel<<<dim3((n + 63) / 64, (hp + 63) / 64), 256, 0, st>>>(n, hp, A1, W1, A2, W2, bias, rowscale, relu, C);
+}
+
+// ---- SAGE stack, forward ------------------------------------------------------------------------------------------------
+int wide_stack_forward(int n, int c_in, int hidden, int L, const int* rowptr, const int* col, const float* invdeg,
+                       const float* x, int x_stride, const float* const* wl, const float* const* bl,
+                       const float* const* wr, void* wpack, float* acts, void* saved, int flags, hipStream_t st) {
+    WidePlan p;
+    int rc = wide_make_plan(n, c_in, hidden, L, &p);
+    if (rc != HEXGNN_OK) return rc;
+    if (!saved && n > 0) return HEXGNN_EINVAL;           // (the aggregate of a layer is materialised: always needs `saved`)
+    if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
+    WidePackArgs pa;
+    for (int l = 0; l < L; ++l) {
+        if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
+        pa.wl[l] = wl[l]; pa.bl[l] = bl[l]; pa.wr[l] = wr[l];
+        pa.w_off[l] = p.w_off[l]; pa.bias_off[l] = p.bias_off[l];
+    }
+    pa.hp = p.hp; pa.hidden = hidden; pa.c_in = c_in; pa.small_first = p.small_first;
+    wide_pack_kernel<<<dim3((p.hp * p.hp + 255) / 256, L), 256, 0, st>>>(pa, (char*)wpack);
+    if (n == 0) return check_launch();
+    const int hp = p.hp;
+    const size_t slab = (size_t)n * hp, sq = (size_t)hp * hp;
+    char* wp = (char*)wpack;
+    char* sv = (char*)saved;
+    const unsigned g4 = (unsigned)(((int64_t)n * (hp / 4) + 255) / 256);
+    for (int l = 0; l < L; ++l) {
+        float* y = acts + slab * l;
+        const float* bias = (const float*)(wp + p.bias_off[l]);
+        const int relu = !(l == L - 1 && (flags & HEXGNN_SAGE_LINEAR_LAST));
+        if (l == 0 && p.small_first) {
+            float* agg0 = (float*)(sv + p.agg_off[0]);
+            wide_first_agg_kernel<<<(n + 255) / 256, 256, 0, st>>>(n, c_in, rowptr, col, invdeg, x, x_stride, agg0);
+            wide_first_out_kernel<<<(unsigned)(((int64_t)n * hp + 255) / 256), 256, 0, st>>>(
+                n, c_in, hp, agg0, x, x_stride, (const float*)(wp + p.w_off[0]), bias, y, relu);
+        } else {
+            const float* xin = l == 0 ? x : acts + slab * (l - 1);
+            float* agg = (float*)(sv + p.agg_off[l]);
+            const float* w = (const float*)(wp + p.w_off[l]);
+            wide_gather_kernel<<<g4, 256, 0, st>>>(n, hp, rowptr, col, invdeg, xin, agg);
+            gemm(n, hp, agg, w, xin, w + sq, bias, nullptr, relu, y, st);
+        }
+    }
+    return check_launch();
+}
+
+// ---- SAGE stack, backward -------------------------------------------------------------------------------------------------
+int wide_stack_backward(int n, int c_in, int hidden, int L, const int* rowptr_t, const int* col_t, const float* invdeg,
+                        const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                        const float* dy, float* dx, float* const* d_wl, float* const* d_bl, float* const* d_wr,
+                        void* workspace, size_t workspace_bytes, int flags, int tap_layer, float* tap_out, hipStream_t st) {
+    WidePlan p;
+    int rc = wide_make_plan(n, c_in, hidden, L, &p);
+    if (rc != HEXGNN_OK) return rc;
+    if (!workspace || workspace_bytes < p.bwd_bytes) return HEXGNN_EWORKSPACE;
+    for (int l = 0; l < L; ++l) if (!d_wl[l] || !d_bl[l] || !d_wr[l]) return HEXGNN_EINVAL;
+    if (n == 0) {
+        for (int l = 0; l < L; ++l) {
+            const int in = l == 0 ? c_in : hidden;
+            (void)hipMemsetAsync(d_wl[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_wr[l], 0, sizeof(float) * (size_t)hidden * in, st);
+            (void)hipMemsetAsync(d_bl[l], 0, sizeof(float) * (size_t)hidden, st);
+        }
+        return check_launch();
+    }
+    const int hp = p.hp;
+    const size_t slab = (size_t)n * hp, sq = (size_t)hp * hp;
+    const size_t slab_b = align_up(sizeof(float) * slab, 256);
+    char* ws = (char*)workspace;
+    const char* wp = (const char*)wpack;
+    const char* sv = (const char*)saved;
+    auto Gl = [&](int l) { return (float*)(ws + p.g_off) + slab * l; };     // (contiguous [L][n][HP], as the narrow plan)
+    float* dagg = (float*)(ws + p.tmp_off);
+    float* dxs = (float*)(ws + p.tmp_off + slab_b);
+    const int64_t tot4 = (int64_t)n * (hp / 4);
+    const unsigned g4 = (unsigned)((tot4 + 255) / 256);
+    if (flags & HEXGNN_SAGE_DY_IN_PLACE) {
+        if (dy != Gl(L - 1)) return HEXGNN_EINVAL;
+    } else {
+        const bool relu_top = !(flags & HEXGNN_SAGE_LINEAR_LAST);
+        wide_mask_kernel<<<g4, 256, 0, st>>>(tot4, dy, relu_top ? acts + slab * (L - 1) : nullptr, Gl(L - 1));
+    }
+    if (tap_out && (tap_layer < 0 || tap_layer >= L - 1)) return HEXGNN_EINVAL;
+    const int first_hidden = p.small_first ? 1 : 0;
+    for (int l = L - 1; l >= first_hidden; --l) {
+        float* out = l >= 1 ? Gl(l - 1) : dx;
+        if (!out) break;
+        const float* w = (const float*)(wp + p.w_off[l]);
+        // d agg_j = (G_j Wl) / deg_j,  d xs = G Wr   (operands: the transposed copies, rows = input features)
+        gemm(n, hp, Gl(l), w + 2 * sq, nullptr, nullptr, nullptr, invdeg, 0, dagg, st);
+        gemm(n, hp, Gl(l), w + 3 * sq, nullptr, nullptr, nullptr, nullptr, 0, dxs, st);
+        if (tap_out && l - 1 == tap_layer) wide_combine_kernel<<<g4, 256, 0, st>>>(n, hp, rowptr_t, col_t, dxs, dagg, nullptr, tap_out);
+        wide_combine_kernel<<<g4, 256, 0, st>>>(n, hp, rowptr_t, col_t, dxs, dagg, l >= 1 ? acts + slab * (l - 1) : nullptr, out);
+    }
+    // parameter gradients
+    const dim3 tiles((hidden + 15) / 16, (hidden + 15) / 16);
+    for (int l = first_hidden; l < L; ++l) {
+        const float* xin = l == 0 ? x : acts + slab * (l - 1);
+        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hidden, hp, Gl(l), (const float*)(sv + p.agg_off[l]), d_wl[l]);
+        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hidden, hp, Gl(l), xin, d_wr[l]);
+        wide_colsum_kernel<<<(hp + 15) / 16, 256, 0, st>>>(n, hidden, hp, Gl(l), d_bl[l]);
+    }
+    if (p.small_first) {
+        wide_first_dw_kernel<<<(hidden + 15) / 16, 256, 0, st>>>(n, c_in, hidden, hp, Gl(0), (const float*)(sv + p.agg_off[0]),
+                                                                x, x_stride, d_wl[0], d_wr[0]);
+        wide_colsum_kernel<<<(hp + 15) / 16, 256, 0, st>>>(n, hidden, hp, Gl(0), d_bl[0]);
+    }
+    return check_launch();
+}
+
+// ---- head tail (advantage linear, [sum|max|min|mean] pooling, value MLP, dueling combine), one workgroup per graph -----------
+// Same modes, saved layout (HeadSaved) and tie rules as head_fwd_kernel / head_bwd_kernel; generic in the width.
+__device__ __forceinline__ float wsum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ float bsum256(float v, float* s4) {
+    v = wsum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) s4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return s4[0] + s4[1] + s4[2] + s4[3];
+}
+
+__global__ __launch_bounds__(256) void wide_head_fwd_kernel(
+    int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ h, const float* __restrict__ lin_w,
+    const float* __restrict__ lin_b, const float* __restrict__ v0_w, const float* __restrict__ v0_b,
+    const float* __restrict__ v1_w, const float* __restrict__ v1_b, float* __restrict__ q, float* __restrict__ out_v,
+    float* __restrict__ adv_raw, float* __restrict__ pooled, int* __restrict__ amax, int* __restrict__ amin,
+    float* __restrict__ z, float* __restrict__ vraw) {
+    __shared__ float s_w[kWideMaxHidden];
+    __shared__ float s_pool[4 * kWideMaxHidden];
+    __shared__ float s_z[kWideMaxHidden / 2];
+    __shared__ float s_red[4];
+    const int g = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
+    const int H2 = H / 2, H4 = 4 * H;
+    for (int c = tid; c < H; c += 256) s_w[c] = lin_w[c];
+    __syncthreads();
+    const float lb = lin_b[0];
+    float tsum = 0.f;
+    for (int row = r0 + wave; row < r1; row += 4) {           // one wave per row
+        float a = 0.f;
+        for (int c = lane; c < H; c += 64) a += h[(size_t)row * hp + c] * s_w[c];
+        a = wsum(a);
+        if (lane == 0) {
+            a += lb;
+            adv_raw[row] = a;
+            const float t = 2.f * tanhf(a);
+            tsum += t;
+            if (mode == 2) q[row] = t;
+            if (mode >= 3) q[row] = a;
+        }
+    }
+    if (mode == 2 || mode == 4) return;
+    const float adv_total = bsum256(tsum, s_red);
+    for (int c = tid; c < H; c += 256) {                      // pooling: a thread per column, rows in ascending order
+        float sum = 0.f, mx = -INFINITY, mn = INFINITY;
+        int ax = -1, an = -1;
+        for (int row = r0; row < r1; ++row) {
+            const float v = h[(size_t)row * hp + c];
+            sum += v;
+            if (v > mx) { mx = v; ax = row; }
+            if (v < mn) { mn = v; an = row; }
+        }
+        if (cnt == 0) { mx = 0.f; mn = 0.f; }
+        const float mean = sum / (float)max(cnt, 1);
+        s_pool[c] = sum; s_pool[H + c] = mx; s_pool[2 * H + c] = mn; s_pool[3 * H + c] = mean;
+        float* pg = pooled + (size_t)g * H4;
+        pg[c] = sum; pg[H + c] = mx; pg[2 * H + c] = mn; pg[3 * H + c] = mean;
+        amax[(size_t)g * H + c] = ax;
+        amin[(size_t)g * H + c] = an;
+    }
+    __syncthreads();
+    for (int k = wave; k < H2; k += 4) {                      // value MLP: one wave per hidden unit
+        float p = 0.f;
+        for (int c = lane; c < H4; c += 64) p += v0_w[(size_t)k * H4 + c] * s_pool[c];
+        p = wsum(p);
+        if (lane == 0) {
+            const float zz = fmaxf(p + v0_b[k], 0.f);
+            s_z[k] = zz;
+            z[(size_t)g * H2 + k] = zz;
+        }
+    }
+    __syncthreads();
+    float p = 0.f;
+    for (int k = tid; k < H2; k += 256) p += v1_w[k] * s_z[k];
+    const float v = bsum256(p, s_red) + v1_b[0];
+    if (tid == 0) vraw[g] = v;
+    const float V = mode == 3 ? v : tanhf(v);
+    if ((mode == 1 || mode == 3) && tid == 0) out_v[g] = V;
+    if (mode == 3) return;
+    const float mean_adv = adv_total / (float)max(cnt, 1);
+    for (int row = r0 + tid; row < r1; row += 256) q[row] = (mode == 0 ? V : 0.f) + 2.f * tanhf(adv_raw[row]) - mean_adv;
+}
+
+__global__ __launch_bounds__(256) void wide_head_bwd_kernel(
+    int H, int hp, int mode, const int* __restrict__ gptr, const float* __restrict__ h, const float* __restrict__ lin_w,
+    const float* __restrict__ v0_w, const float* __restrict__ v1_w, const float* __restrict__ adv_raw,
+    const int* __restrict__ amax, const int* __restrict__ amin, const float* __restrict__ z, const float* __restrict__ vraw,
+    const float* __restrict__ dq, const float* __restrict__ d_out_v, float* __restrict__ dh, float* __restrict__ dadv,
+    float* __restrict__ dz, float* __restrict__ dvr, float* __restrict__ lin_part, int mask_dh) {
+    __shared__ float s_dp[4 * kWideMaxHidden];
+    __shared__ float s_dz[kWideMaxHidden / 2];
+    __shared__ float s_lw[kWideMaxHidden];
+    __shared__ int s_ax[kWideMaxHidden], s_an[kWideMaxHidden];
+    __shared__ float s_red[4];
+    const int g = blockIdx.x, tid = threadIdx.x;
+    const int r0 = gptr[g], r1 = gptr[g + 1], cnt = r1 - r0;
+    const int H2 = H / 2, H4 = 4 * H;
+    const bool has_value = mode != 2 && mode != 4, raw = mode >= 3;
+    for (int c = tid; c < H; c += 256) s_lw[c] = lin_w[c];
+    float mean_dq = 0.f;
+    const float inv_cnt = 1.f / (float)max(cnt, 1);
+    if (has_value) {
+        float ps = 0.f;
+        for (int row = r0 + tid; row < r1; row += 256) ps += dq[row];
+        const float sdq = bsum256(ps, s_red);
+        mean_dq = raw ? 0.f : sdq * inv_cnt;
+        for (int c = tid; c < H; c += 256) { s_ax[c] = amax[(size_t)g * H + c]; s_an[c] = amin[(size_t)g * H + c]; }
+        const float dV = mode == 0 ? sdq : d_out_v[g];
+        const float dv = raw ? dV : dV * sech2f(vraw[g]);
+        if (tid == 0) dvr[g] = dv;
+        for (int k = tid; k < H2; k += 256) {
+            const float d = z[(size_t)g * H2 + k] > 0.f ? v1_w[k] * dv : 0.f;
+            s_dz[k] = d;
+            dz[(size_t)g * H2 + k] = d;
+        }
+        __syncthreads();
+        for (int c = tid; c < H4; c += 256) {                 // d pooled = v0_w^T dz, k ascending
+            float p = 0.f;
+            for (int k = 0; k < H2; ++k) p += v0_w[(size_t)k * H4 + c] * s_dz[k];
+            s_dp[c] = p;
+        }
+    }
+    __syncthreads();
+    for (int row = r0 + tid; row < r1; row += 256)
+        dadv[row] = raw ? dq[row] : (dq[row] - mean_dq) * 2.f * sech2f(adv_raw[row]);
+    __syncthreads();
+    for (int64_t i = tid; i < (int64_t)cnt * hp; i += 256) {  // dh
+        const int row = r0 + (int)(i / hp), c = (int)(i % hp);
+        float t = 0.f;
+        if (c < H) {
+            t = dadv[row] * s_lw[c];
+            if (has_value) {
+                t += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
+                if (s_ax[c] == row) t += s_dp[H + c];
+                if (s_an[c] == row) t += s_dp[2 * H + c];
+            }
+            if (mask_dh && !(h[(size_t)row * hp + c] > 0.f)) t = 0.f;
+        }
+        dh[(size_t)row * hp + c] = t;
+    }
+    for (int c = tid; c <= hp; c += 256) {                    // per-graph partial of the advantage linear's gradient
+        float acc = 0.f;
+        if (c < hp) { for (int row = r0; row < r1; ++row) acc += dadv[row] * h[(size_t)row * hp + c]; }
+        else { for (int row = r0; row < r1; ++row) acc += dadv[row]; }
+        lin_part[(size_t)g * (hp + 1) + c] = acc;
+    }
+}
+
+int wide_head_forward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
+                      const float* lin_b, const float* v0_w, const float* v0_b, const float* v1_w, const float* v1_b,
+                      float* q, float* out_v, void* saved, hipStream_t st) {
+    const int hp = padded_width_wide(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    if (b == 0) return HEXGNN_OK;
+    const HeadSaved s = head_saved_plan(n, b, hidden);
+    char* sv = (char*)saved;
+    wide_head_fwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, h, lin_w, lin_b, v0_w, v0_b, v1_w, v1_b, q, out_v,
+                                            (float*)(sv + s.adv_off), (float*)(sv + s.pooled_off), (int*)(sv + s.amax_off),
+                                            (int*)(sv + s.amin_off), (float*)(sv + s.z_off), (float*)(sv + s.v_off));
+    return check_launch();
+}
+
+int wide_head_backward(int n, int b, int hidden, int mode, const int* gptr, const float* h, const float* lin_w,
+                       const float* v0_w, const float* v1_w, const void* saved, const float* dq, const float* d_out_v,
+                       float* dh, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b, float* d_v1_w,
+                       float* d_v1_b, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int hp = padded_width_wide(hidden);
+    if (hp < 0) return HEXGNN_EUNSUPPORTED;
+    const int mask_dh = (mode & HEXGNN_HEAD_MASK_DH) ? 1 : 0;
+    mode &= ~HEXGNN_HEAD_MASK_DH;
+    const HeadWs w = head_ws_plan(n, b, hidden);
+    if (!workspace || workspace_bytes < w.total) return HEXGNN_EWORKSPACE;
+    const HeadSaved s = head_saved_plan(n, b, hidden);
+    const char* sv = (const char*)saved;
+    char* ws = (char*)workspace;
+    float* dadv = (float*)(ws + w.dadv_off);
+    float* dz = (float*)(ws + w.dz_off);
+    float* dvr = (float*)(ws + w.dvr_off);
+    float* part = (float*)(ws + w.part_off);
+    if (b > 0)
+        wide_head_bwd_kernel<<<b, 256, 0, st>>>(hidden, hp, mode, gptr, h, lin_w, v0_w, v1_w, (const float*)(sv + s.adv_off),
+                                                (const int*)(sv + s.amax_off), (const int*)(sv + s.amin_off),
+                                                (const float*)(sv + s.z_off), (const float*)(sv + s.v_off), dq, d_out_v, dh,
+                                                dadv, dz, dvr, part, mask_dh);
+    launch_head_param_grads(b, hidden, mode, dz, dvr, (const float*)(sv + s.pooled_off), (const float*)(sv + s.z_off), part,
+                            d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b, st);
+    return check_launch();
+}
+
+}  // namespace hexgnn

@@ -660,7 +660,7 @@ class DuellingTwoHeaded(torch.nn.Module):
 
         if gptr is None:
             gptr = gs.gptr
-        # general layer-major path (any graph size, hidden <= 128)
+        # general layer-major path (any graph size; hidden 129..256: the plain kernels of csrc/wide.hip behind the same calls)
         embeds = self.gnn(x2, edge_index, set_cache=set_cache, _graph=gs)
         if self.after_embed_norm is not None:
             embeds = self.after_embed_norm(embeds)

@@ -54,7 +54,7 @@ def hints_of(x: torch.Tensor):
 def padded_width(hidden: int) -> int:
     hp = _lib.lib().hexgnn_padded_width(int(hidden))
     if hp < 0:
-        raise _lib.HexGnnError("hidden_channels=%d not supported by the compiled kernels (1..128)" % hidden)
+        raise _lib.HexGnnError("hidden_channels=%d not supported by the compiled kernels (1..256)" % hidden)
     return hp
 
 
@@ -297,7 +297,8 @@ class SageStackFn(torch.autograd.Function):
         need_bwd = any(ctx.needs_input_grad)
         acts = torch.empty((num_layers, n, hp), dtype=torch.float32, device=dev)
         wpack = _bytes(L.hexgnn_sage_stack_pack_bytes(c_in, hidden, num_layers), dev)
-        saved = _bytes(L.hexgnn_sage_stack_saved_bytes(n, c_in, hidden, num_layers), dev) if need_bwd else None
+        # (hidden > 128: the plain kernels materialise every layer's aggregate, with or without a backward)
+        saved = _bytes(L.hexgnn_sage_stack_saved_bytes(n, c_in, hidden, num_layers), dev) if (need_bwd or hidden > 128) else None
         _lib.check(L.hexgnn_sage_stack_forward(
             n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
             xin.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), wpack.data_ptr(),

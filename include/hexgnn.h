@@ -29,7 +29,8 @@ extern "C" {
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
-#define HEXGNN_EUNSUPPORTED (-2) /* shape outside the compiled kernels (hidden > 128, c_in > 8, ...) */
+#define HEXGNN_EUNSUPPORTED (-2) /* shape outside the compiled kernels (hidden > 256 -- > 128 for the norm / two_headed / HexAra
+                                    entry points --, c_in > 8, ...) */
 #define HEXGNN_EWORKSPACE (-3)   /* workspace smaller than the matching *_bytes() query */
 #define HEXGNN_EHIP (-4)         /* HIP runtime reported an error at launch (see hexgnn_last_hip_error) */
 #define HEXGNN_ETIMEOUT (-5)     /* a one-launch stack kernel gave up waiting in its grid barrier (an EARLIER call; sticky once) */
@@ -76,6 +77,9 @@ int hexgnn_graph_ptr(int n, int b, const int64_t* batch, int* gptr /*[b+1]*/, he
  *      GN0/torch_script_models.py:52-73): y_i = W_l * mean_{j in N(i)} x_j + b_l + W_r * x_i, ReLU
  *      after every layer.  Layer 0 maps c_in -> hidden, the rest hidden -> hidden.
  *      c_in <= 8 (raw features, row stride x_stride floats) or c_in == hidden (padded layout).
+ *      hidden <= 128: LDS-resident kernels; hidden 129..256 (grow_width, GN0/models.py:187-238): plain kernels behind the
+ *      same calls -- `saved` is then REQUIRED by the forward call whatever need_backward says (every layer's aggregate is
+ *      materialised there).
  *      wl/bl/wr: HOST arrays (num_layers entries) of device pointers to the torch parameters
  *      lin_l.weight [out,in], lin_l.bias [out], lin_r.weight [out,in].
  *      flags: HEXGNN_SAGE_LINEAR_LAST = no ReLU after the LAST layer of the stack; a 1-layer stack with it is a bare

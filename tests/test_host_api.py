@@ -23,13 +23,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(raw, name), "libhexgnn.so does not export %s" % name
     assert set(declared) == set(_lib.exported_symbols()), "ctypes signature table out of sync with the header"
     assert L.hexgnn_abi_version() == _lib.ABI_VERSION == 4
-    assert L.hexgnn_padded_width(110) == 112 and L.hexgnn_padded_width(35) == 48 and L.hexgnn_padded_width(129) < 0
+    assert L.hexgnn_padded_width(110) == 112 and L.hexgnn_padded_width(35) == 48 and L.hexgnn_padded_width(129) == 144
+    assert L.hexgnn_padded_width(256) == 256 and L.hexgnn_padded_width(257) < 0
     assert L.hexgnn_strerror(-3).decode() == "workspace too small"
     assert L.hexgnn_qnet_supported(2, 110, 123) == 1 and L.hexgnn_qnet_supported(2, 110, 146) == 0
     assert L.hexgnn_qnet_supported(2, 128, 51) == 0
     # workspace queries are pure host arithmetic
     assert L.hexgnn_sage_stack_pack_bytes(2, 110, 15) > 14 * 2 * 100352
-    assert L.hexgnn_sage_stack_pack_bytes(2, 129, 3) == 0
+    assert L.hexgnn_sage_stack_pack_bytes(2, 129, 3) > 2 * 4 * 4 * 144 * 144 and L.hexgnn_sage_stack_pack_bytes(2, 257, 3) == 0
 
 
 def test_argument_validation_without_gpu():
@@ -38,7 +39,7 @@ def test_argument_validation_without_gpu():
     L = _lib.lib()
     assert L.hexgnn_csr_build(-1, 0, None, None, None, None, None, None, None, None, None, 0, None) == -1
     assert L.hexgnn_graph_ptr(4, 2, None, None, None) == -1
-    assert L.hexgnn_pad_rows(4, 200, None, 200, None, None) == -2
+    assert L.hexgnn_pad_rows(4, 300, None, 300, None, None) == -2
     assert L.hexgnn_profile_enable(99) == -1 and L.hexgnn_profile_enable(-1) == 0
 
 
