@@ -54,13 +54,14 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
 
 // ---- hidden 129..256 (wide.hip): plain kernels behind the same entry points ------------------------------------------------
 constexpr int kWideMaxHidden = 256;
+constexpr int kWideSlicesMax = 32;           // row slices of a wide weight-gradient launch (workspace sized for this many)
 int padded_width_wide(int hidden);           // 16-multiple up to 256, -1 beyond
 struct WidePlan {
     int hp, L;
     bool small_first;
     size_t w_off[kMaxLayers], bias_off[kMaxLayers], pack_bytes;
     size_t agg_off[kMaxLayers], saved_bytes;
-    size_t g_off, tmp_off, bwd_bytes;
+    size_t g_off, tmp_off, part_off, bwd_bytes;
 };
 int wide_make_plan(int n, int c_in, int hidden, int L, WidePlan* p);
 int wide_stack_forward(int n, int c_in, int hidden, int L, const int* rowptr, const int* col, const float* invdeg,

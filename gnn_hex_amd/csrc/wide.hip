@@ -44,7 +44,8 @@ int wide_make_plan(int n, int c_in, int hidden, int L, WidePlan* p) {
     const size_t slab = align_up(sizeof(float) * (size_t)n * hp, 256);
     p->g_off = 0;
     p->tmp_off = slab * L;
-    p->bwd_bytes = slab * (L + 2);
+    p->part_off = slab * (L + 2);               // row-slice partials of ONE weight-gradient launch (reused launch after launch)
+    p->bwd_bytes = p->part_off + align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256);
     return HEXGNN_OK;
 }
 
@@ -119,20 +120,33 @@ __global__ void wide_first_out_kernel(int n, int c_in, int hp, const float* __re
     y[i] = (v > 0.f || !relu) ? v : 0.f;
 }
 
-// d w0: thread (o, q, which) walks all rows in order (deterministic); one block = 16 outputs x (8 + 8) inputs
-__global__ __launch_bounds__(256) void wide_first_dw_kernel(int n, int c_in, int H, int hp, const float* __restrict__ G,
-                                                           const float* __restrict__ agg0, const float* __restrict__ x,
-                                                           int xs, float* __restrict__ d_wl, float* __restrict__ d_wr) {
-    const int o = blockIdx.x * 16 + (threadIdx.x >> 4), qq = threadIdx.x & 15;
+// d w0: thread (o, q, which) walks the rows of one slice in order; the slices are added in order afterwards (deterministic)
+__global__ __launch_bounds__(256) void wide_first_dw_kernel(int n, int c_in, int H, int hp, int rows_per_slice,
+                                                           const float* __restrict__ G, const float* __restrict__ agg0,
+                                                           const float* __restrict__ x, int xs,
+                                                           float* __restrict__ part /*[S][HP][16]*/) {
+    const int o = blockIdx.x * 16 + (threadIdx.x >> 4), qq = threadIdx.x & 15, sl = blockIdx.y;
     const int which = qq >> 3, q = qq & 7;
-    if (o >= H || q >= c_in) return;
+    const int m_lo = sl * rows_per_slice, m_hi = min(n, m_lo + rows_per_slice);
     float acc = 0.f;
-    for (int m = 0; m < n; ++m) {
-        const float g = G[(size_t)m * hp + o];
-        const float v = which == 0 ? agg0[(size_t)m * kSmallCin + q] : x[(size_t)m * xs + q];
-        acc += g * v;
+    if (o < H && q < c_in) {
+        for (int m = m_lo; m < m_hi; ++m) {
+            const float g = G[(size_t)m * hp + o];
+            const float v = which == 0 ? agg0[(size_t)m * kSmallCin + q] : x[(size_t)m * xs + q];
+            acc += g * v;
+        }
     }
-    (which == 0 ? d_wl : d_wr)[o * c_in + q] = acc;
+    if (o < hp) part[((size_t)sl * hp + o) * 16 + qq] = acc;
+}
+__global__ void wide_first_dw_reduce_kernel(int S, int c_in, int H, int hp, const float* __restrict__ part,
+                                            float* __restrict__ d_wl, float* __restrict__ d_wr) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * 16) return;
+    const int o = idx / 16, qq = idx % 16, which = qq >> 3, q = qq & 7;
+    if (q >= c_in) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[((size_t)k * hp + o) * 16 + qq];
+    (which == 0 ? d_wl : d_wr)[o * c_in + q] = s;
 }
 
 // ---- mean gather: out[i] = s_i * sum_{j in N(i)} x[j]  (16-byte column groups) ----------------------------------------------
@@ -197,47 +211,66 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(int M, int hp, const flo
     }
 }
 
-// ---- weight gradient: one wave per 16 x 16 tile of dW[o][i] = sum_m G[m][o] X[m][i], all rows in order -----------------------
-// lane (i, kk): a = G[m + 4 kk + j][o0 + i], b = X[m + 4 kk + j][i0 + i]; acc[r] = dW[o0 + 4 kk + r][i0 + i].
-__global__ __launch_bounds__(64) void wide_dw_kernel(int n, int H, int hp, const float* __restrict__ G,
-                                                    const float* __restrict__ X, float* __restrict__ dW /*[H][H]*/) {
+// ---- weight gradient: one wave per (16 x 16 tile of dW, row slice): part[s][o][i] = sum_{m in slice s} G[m][o] X[m][i] -------
+// lane (i, kk): a = G[m + 4 kk + j][o0 + i], b = X[m + 4 kk + j][i0 + i]; acc[r] = tile[4 kk + r][i].  The slices are added in
+// slice order by wide_slices_reduce_kernel: deterministic.  (The first version walked all rows in ONE wave per tile: 65 ms per
+// GNN-L step at hidden 160.)
+constexpr int kWideSlices = 32;
+__global__ __launch_bounds__(64) void wide_dw_kernel(int n, int hp, int rows_per_slice, const float* __restrict__ G,
+                                                    const float* __restrict__ X, float* __restrict__ part /*[S][HP][HP]*/) {
     const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int o0 = blockIdx.x * 16, i0 = blockIdx.y * 16;
+    const int o0 = blockIdx.x * 16, i0 = blockIdx.y * 16, sl = blockIdx.z;
+    const int m_lo = sl * rows_per_slice, m_hi = min(n, m_lo + rows_per_slice);
     f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int m = 0; m < n; m += 16) {
+
+    for (int m = m_lo; m < m_hi; m += 16) {
         float a[4], b[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = m + 4 * kk + j;
-            a[j] = r < n ? G[(size_t)r * hp + o0 + i] : 0.f;
-            b[j] = r < n ? X[(size_t)r * hp + i0 + i] : 0.f;
+            a[j] = r < m_hi ? G[(size_t)r * hp + o0 + i] : 0.f;
+            b[j] = r < m_hi ? X[(size_t)r * hp + i0 + i] : 0.f;
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc = mfma16x16x4(a[j], b[j], acc);
     }
+    float* t = part + ((size_t)sl * hp + o0 + 4 * kk) * hp + i0 + i;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int o = o0 + 4 * kk + r, c = i0 + i;
-        if (o < H && c < H) dW[(size_t)o * H + c] = acc[r];
-    }
+    for (int r = 0; r < 4; ++r) t[(size_t)r * hp] = acc[r];
+}
+__global__ void wide_slices_reduce_kernel(int S, int H, int hp, const float* __restrict__ part, float* __restrict__ dW /*[H][H]*/) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= H * H) return;
+    const int o = idx / H, c = idx % H;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[((size_t)k * hp + o) * hp + c];
+    dW[idx] = s;
 }
 
-// column sums of G (the bias gradient): block = 16 columns x 16 row phases, fixed-order combine
-__global__ __launch_bounds__(256) void wide_colsum_kernel(int n, int H, int hp, const float* __restrict__ G,
-                                                         float* __restrict__ d_b) {
+// column sums of G (the bias gradient): block = 16 columns x 16 row phases over one row slice, fixed-order combine
+__global__ __launch_bounds__(256) void wide_colsum_kernel(int n, int hp, int rows_per_slice, const float* __restrict__ G,
+                                                         float* __restrict__ part /*[S][HP]*/) {
     __shared__ float s[16][17];
-    const int c = blockIdx.x * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + (threadIdx.x & 15), ph = threadIdx.x >> 4, sl = blockIdx.y;
+    const int m_lo = sl * rows_per_slice, m_hi = min(n, m_lo + rows_per_slice);
     float acc = 0.f;
     if (c < hp) {
-        for (int m = ph; m < n; m += 16) acc += G[(size_t)m * hp + c];
+        for (int m = m_lo + ph; m < m_hi; m += 16) acc += G[(size_t)m * hp + c];
     }
     s[ph][threadIdx.x & 15] = acc;
     __syncthreads();
-    if (ph == 0 && c < H) {
+    if (ph == 0 && c < hp) {
         float t = 0.f;
         for (int p = 0; p < 16; ++p) t += s[p][threadIdx.x & 15];
-        d_b[c] = t;
+        part[(size_t)sl * hp + c] = t;
     }
+}
+__global__ void wide_colsum_reduce_kernel(int S, int H, int hp, const float* __restrict__ part, float* __restrict__ d_b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= H) return;
+    float s = 0.f;
+    for (int k = 0; k < S; ++k) s += part[(size_t)k * hp + c];
+    d_b[c] = s;
 }
 
 // out = a * [y > 0] (or a)
@@ -369,18 +402,26 @@ int wide_stack_backward(int n, int c_in, int hidden, int L, const int* rowptr_t,
         if (tap_out && l - 1 == tap_layer) wide_combine_kernel<<<g4, 256, 0, st>>>(n, hp, rowptr_t, col_t, dxs, dagg, nullptr, tap_out);
         wide_combine_kernel<<<g4, 256, 0, st>>>(n, hp, rowptr_t, col_t, dxs, dagg, l >= 1 ? acts + slab * (l - 1) : nullptr, out);
     }
-    // parameter gradients
-    const dim3 tiles((hidden + 15) / 16, (hidden + 15) / 16);
+    // parameter gradients: row-slice partials (one scratch region, launches are stream-ordered), added in slice order
+    const int S = kWideSlices, rps = ((n + S - 1) / S + 15) / 16 * 16;
+    float* part = (float*)(ws + p.part_off);
+    const dim3 tiles(hp / 16, hp / 16, S);
+    const unsigned rg = (unsigned)((hidden * hidden + 255) / 256);
     for (int l = first_hidden; l < L; ++l) {
         const float* xin = l == 0 ? x : acts + slab * (l - 1);
-        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hidden, hp, Gl(l), (const float*)(sv + p.agg_off[l]), d_wl[l]);
-        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hidden, hp, Gl(l), xin, d_wr[l]);
-        wide_colsum_kernel<<<(hp + 15) / 16, 256, 0, st>>>(n, hidden, hp, Gl(l), d_bl[l]);
+        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hp, rps, Gl(l), (const float*)(sv + p.agg_off[l]), part);
+        wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part, d_wl[l]);
+        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hp, rps, Gl(l), xin, part);
+        wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part, d_wr[l]);
+        wide_colsum_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, hp, rps, Gl(l), part);
+        wide_colsum_reduce_kernel<<<(hidden + 255) / 256, 256, 0, st>>>(S, hidden, hp, part, d_bl[l]);
     }
     if (p.small_first) {
-        wide_first_dw_kernel<<<(hidden + 15) / 16, 256, 0, st>>>(n, c_in, hidden, hp, Gl(0), (const float*)(sv + p.agg_off[0]),
-                                                                x, x_stride, d_wl[0], d_wr[0]);
-        wide_colsum_kernel<<<(hp + 15) / 16, 256, 0, st>>>(n, hidden, hp, Gl(0), d_bl[0]);
+        wide_first_dw_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, c_in, hidden, hp, rps, Gl(0),
+                                                                     (const float*)(sv + p.agg_off[0]), x, x_stride, part);
+        wide_first_dw_reduce_kernel<<<(hidden * 16 + 255) / 256, 256, 0, st>>>(S, c_in, hidden, hp, part, d_wl[0], d_wr[0]);
+        wide_colsum_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, hp, rps, Gl(0), part);
+        wide_colsum_reduce_kernel<<<(hidden + 255) / 256, 256, 0, st>>>(S, hidden, hp, part, d_bl[0]);
     }
     return check_launch();
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Eager forward + backward step time of model variants the bench has no configuration for (--norm=True, --noisy_dqn=True,
-Hex-13): python tools/time_variants.py [plain norm noisy norm+noisy S-norm hex13]"""
+Hex-13, hidden 128 / 160 / 256): python tools/time_variants.py [plain norm noisy norm+noisy S-norm hex13 wide]"""
 import sys, time, torch
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
 from argparse import Namespace
@@ -28,10 +28,14 @@ def run(name, norm, noisy, sizes, layers=15, hidden=110):
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
     print("%-28s %.3f ms/step  %.0f graphs/s" % (name, dt * 1e3, len(sizes) / dt))
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["plain", "norm", "noisy", "norm+noisy", "S-norm", "hex13"]
+    which = sys.argv[1:] or ["plain", "norm", "noisy", "norm+noisy", "S-norm", "hex13", "wide"]
     if "plain" in which: run("L256 plain", False, False, [11] * 256)
     if "norm" in which: run("L256 norm", True, False, [11] * 256)
     if "noisy" in which: run("L256 noisy", False, True, [11] * 256)
     if "norm+noisy" in which: run("L256 norm+noisy", True, True, [11] * 256)
     if "S-norm" in which: run("S256 norm", True, False, [7] * 256, 10, 35)
     if "hex13" in which: run("Hex-13 x256 plain", False, False, [13] * 256)
+    if "wide" in which:
+        run("L256 hidden 128 (layer-major)", False, False, [11] * 256, 15, 128)
+        run("L256 hidden 160 (wide.hip)", False, False, [11] * 256, 15, 160)
+        run("L256 hidden 256 (wide.hip)", False, False, [11] * 256, 15, 256)
