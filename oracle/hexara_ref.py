@@ -4,12 +4,12 @@ TEST INFRASTRUCTURE -- see ``oracle/__init__.py``.  The arithmetic (SAGEConv, sc
 torch_geometric / torch_scatter code that is absent here: PARITY UNPINNED for the floating-point values.  The INDEX
 surgery of the output (terminal nodes removed, swap logit inserted, output batch pointer / graph indices) IS pinned: the
 reference's own ``rl_loop/unittest_model.py:16-92`` holds exact expected sizes, graph indices and batch pointers for three
-hand-made batches and a randomized property test; ``tests/test_oracle_hexara.py`` replays them against this file.
+hand-made batches and the invariants of a randomized test; ``tests/test_oracle_hexara.py`` checks this file against them.
 
 * ``ModifiedBaseNetRef``   <- GN0/torch_script_models.py:75-189 (layer layout 123-144; forward 167-189: activation after
                               every layer but the last, norms unsupported here = ``norm=None``, the default of
                               ``get_current_model``, line 495)
-* ``SageTorchScriptRef``   <- GN0/torch_script_models.py:286-379, statement for statement
+* ``SageTorchScriptRef``   <- GN0/torch_script_models.py:286-379; the output surgery (326-376) restated graph by graph
 * ``scatter_log_softmax_ref`` <- torch_scatter 2.1.0 ``composite.scatter_log_softmax``: per group, x - max, then
                               minus log(sum(exp(.)))
 * ``get_current_model_ref`` <- GN0/torch_script_models.py:495-507, ``net_type="SAGE"``
@@ -89,37 +89,31 @@ class SageTorchScriptRef(torch.nn.Module):
         graph_parts = torch.cat(parts, dim=1)
         value = self.value_activation(self.my_modules["value_linear"](graph_parts))
         pi = pi.reshape(pi.size(0))
+        # Output surgery of GN0/torch_script_models.py:326-376, restated graph by graph (the reference does it with boolean
+        # masks and a cumulative sum over the whole batch; rl_loop/unittest_model.py pins that both give the same indices):
+        #   * the first two rows of every graph are the terminal nodes: no move, dropped;
+        #   * with swap_allowed, a graph in which swapping is possible gets ONE more entry behind its nodes, the swap logit of
+        #     its pooled features.  "Possible" is read from feature 2 -- of the graph's LAST row for every graph but the last
+        #     one (lines 337-338: x[batch_ptr[1:-1] - 1, 2]), of its FIRST row for the last graph (line 347: x[batch_ptr[-2], 2]);
+        #   * output_batch_ptr = running start of the segments, output_graph_indices = the segment index of every entry;
+        #   * log-softmax per segment (scatter_log_softmax).
+        should_swap = None
         if self.swap_allowed:
-            should_swap = self.my_modules["swap_linear"](graph_parts)
-            should_swap = should_swap.reshape(should_swap.size(0))
-            swap_parts = x[batch_ptr[1:-1] - 1, 2].type(torch.bool)
-            swap_indices = batch_ptr[1:-1][swap_parts]
-            to_select = torch.ones(pi.size(), dtype=torch.bool)
-            to_select[batch_ptr[0]] = False
-            to_select[batch_ptr[1:-1]] = swap_parts
-            to_select[batch_ptr[:-1] + 1] = False
-            all_swap_parts = torch.empty(len(batch_ptr), dtype=torch.bool)
-            all_swap_parts[0] = 0
-            all_swap_parts[1:-1] = swap_parts
-            all_swap_parts[-1] = x[batch_ptr[-2], 2]
-            output_batch_ptr = batch_ptr - torch.arange(0, len(batch_ptr) * 2, 2) + torch.cumsum(all_swap_parts, dim=0)
-            pi = pi.clone()
-            pi[swap_indices] = should_swap[:-1][swap_parts]
-            output_graph_indices = graph_indices.clone()
-            output_graph_indices[swap_indices] = output_graph_indices[swap_indices - 1]
-            pi = pi[to_select]
-            output_graph_indices = output_graph_indices[to_select]
-            if x[batch_ptr[-2], 2]:
-                pi = torch.cat((pi, should_swap[-1:]))
-                output_graph_indices = torch.cat((output_graph_indices, output_graph_indices[-1:]))
-        else:
-            to_select = torch.ones(pi.size(), dtype=torch.bool)
-            to_select[batch_ptr[:-1]] = False
-            to_select[batch_ptr[:-1] + 1] = False
-            output_batch_ptr = batch_ptr - torch.arange(0, len(batch_ptr) * 2, 2)
-            output_graph_indices = graph_indices.clone()
-            pi = pi[to_select]
-            output_graph_indices = output_graph_indices[to_select]
+            should_swap = self.my_modules["swap_linear"](graph_parts).reshape(nb)
+        pieces, seg_ids, starts = [], [], [0]
+        for gi in range(nb):
+            lo, hi = int(batch_ptr[gi]), int(batch_ptr[gi + 1])
+            seg = pi[lo + 2:hi]
+            if self.swap_allowed:
+                probe_row = hi - 1 if gi < nb - 1 else lo
+                if bool(x[probe_row, 2] != 0):
+                    seg = torch.cat((seg, should_swap[gi:gi + 1]))
+            pieces.append(seg)
+            seg_ids.append(torch.full((seg.numel(),), gi, dtype=graph_indices.dtype))
+            starts.append(starts[-1] + seg.numel())
+        pi = torch.cat(pieces)
+        output_graph_indices = torch.cat(seg_ids)
+        output_batch_ptr = torch.tensor(starts, dtype=batch_ptr.dtype)
         pi = scatter_log_softmax_ref(pi, output_graph_indices)
         return pi, value.reshape(value.size(0)), output_graph_indices, output_batch_ptr
 

@@ -1,8 +1,6 @@
 """The HexAra policy/value network SAGE_torch_script on the device (GN0/torch_script_models.py:286-379).
 Index surgery against the reference's own known answers (rl_loop/unittest_model.py:16-92, replayed through
 tests/test_oracle_hexara.py's fixtures), values and every gradient against the oracle restatement."""
-import random
-
 import numpy as np
 import pytest
 import torch
@@ -40,25 +38,18 @@ def test_reference_unittest_fixtures_on_device(name):
 
 
 def test_reference_randomized_property_on_device():
-    """rl_loop/unittest_model.py:54-92 (random multigraphs, random swap flags): sizes, segment structure, pointer arithmetic
-    and sum(exp(pi)) == 1 per graph -- on the device model, plus agreement with the oracle."""
-    rng = random.Random(42)
-    nprng = np.random.RandomState(4)
-    torch.manual_seed(1)
+    """The invariants of rl_loop/unittest_model.py:54-92 (random multigraphs, random swap flags): sizes, segment structure,
+    pointer arithmetic and sum(exp(pi)) == 1 per graph -- on the device model, plus agreement with the oracle."""
+    gen = np.random.default_rng(7)
     hip, ref = _pair(12, 3, 2, 2, True, seed=1)
-    done = 0
-    for _ in range(25):
-        case = random_case(rng, nprng)
-        if int((case[3][1:] - case[3][:-1]).min()) <= 2:
-            continue
+    for _ in range(15):
+        case = random_case(gen)
         with torch.no_grad():
             check_random_case(lambda x, ei, gi, bp: tuple(t.cpu() for t in hip(x.cuda(), ei.cuda(), gi.cuda(), bp.cuda())), case)
             pi, value, ogi, obp = hip(*[t.cuda() for t in case[:4]])
             pi_r, value_r, ogi_r, obp_r = ref(*case[:4])
         assert torch.equal(ogi.cpu(), ogi_r) and torch.equal(obp.cpu(), obp_r)
         assert (pi.cpu() - pi_r).abs().max().item() < 2e-4 and (value.cpu() - value_r).abs().max().item() < TOL
-        done += 1
-    assert done >= 10
 
 
 def _loss(pi, value, gen_pi, tv):

@@ -2,8 +2,6 @@
 exact output sizes, graph indices and batch pointers of SAGE_torch_script's swap / terminal-node surgery for three
 hand-made batches (lines 16-52) and a randomized property check (lines 54-92: segment structure, pointer arithmetic,
 sum(exp(pi)) == 1 per graph).  Those fixtures PIN the index logic; the float values stay "parity unpinned" (pyg absent)."""
-import random
-
 import numpy as np
 import pytest
 import torch
@@ -62,59 +60,48 @@ def test_swap_disallowed_only_drops_the_terminals():
         assert pi.shape == (6,) and ogi.tolist() == [0, 0, 0, 1, 1, 1] and obp.tolist() == [0, 3, 6]
 
 
-def random_case(rng, nprng):
-    """rl_loop/unittest_model.py:57-80, same generator calls in the same order (python `random` seed 42, numpy seed 4)."""
-    num_graphs = rng.randint(1, 30)
-    num_nodes = rng.randint(3, 30) * num_graphs
-    num_edges = rng.randint(30, 60) * num_graphs
+def random_case(gen):
+    """A random batch in the spirit of the reference's randomized check (rl_loop/unittest_model.py:54-92: up to 30 graphs of
+    3..30+ nodes, random multigraph edges, swapping possible in about half of the graphs) from this suite's own generator."""
+    num_graphs = int(gen.integers(1, 31))
+    sizes = gen.integers(3, 31, size=num_graphs)
+    bp = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.long)
+    num_nodes = int(bp[-1])
+    gi = torch.repeat_interleave(torch.arange(num_graphs), torch.as_tensor(sizes))
+    edge_index = torch.as_tensor(gen.integers(0, num_nodes, size=(2, int(gen.integers(30, 61)) * num_graphs)))
+    did_swap = [bool(v) for v in gen.random(num_graphs) > 0.5]
     x = torch.zeros(num_nodes, 3)
-    edge_index = torch.randint(0, num_nodes, (2, num_edges))
-    gi = torch.tensor(list(sorted(sum([[i, i, i] for i in range(num_graphs)], [])
-                                  + nprng.randint(0, num_graphs, num_nodes - 3 * num_graphs).tolist())), dtype=torch.long)
-    bp = [0]
-    cur = 0
-    for i in range(len(gi)):
-        if gi[i] != cur:
-            bp.append(i)
-            cur = gi[i]
-    bp.append(len(gi))
-    bp = torch.tensor(bp, dtype=torch.long)
-    did_swap = []
-    for start, fin in zip(bp[:-1], bp[1:]):
-        if rng.random() > 0.5:
-            did_swap.append(True)
-            x[start:fin, 2] = 1
-        else:
-            did_swap.append(False)
+    for g, flag in enumerate(did_swap):
+        if flag:
+            x[bp[g]:bp[g + 1], 2] = 1
     return x, edge_index, gi, bp, did_swap, num_graphs, num_nodes
 
 
 def check_random_case(model_fn, case):
+    """The invariants the reference asserts for every output (unittest_model.py:80-92): one value per graph; one policy entry
+    per non-terminal node plus one per graph that may swap; every segment belongs to one graph and starts where the input
+    graph started minus the entries dropped before it; the probabilities of a segment sum to one."""
     x, ei, gi_in, bp_in, did_swap, num_graphs, num_nodes = case
     pi, value, gi, bp = model_fn(x, ei, gi_in, bp_in)
     assert value.shape == (num_graphs,) and bp.shape == (num_graphs + 1,)
-    assert pi.shape == gi.shape == (num_nodes - num_graphs * 2 + int(np.sum(did_swap)),)
-    minus = 0
-    for i, (start, fin) in enumerate(zip(bp[:-1].tolist(), bp[1:].tolist())):
-        assert bool((gi[start:fin] == gi[start]).all())
-        if fin < len(gi):
-            assert gi[start] != gi[fin]
-        assert start == int(bp_in[i]) - minus
+    assert pi.shape == gi.shape == (num_nodes - 2 * num_graphs + sum(did_swap),)
+    dropped = 0
+    for g in range(num_graphs):
+        start, fin = int(bp[g]), int(bp[g + 1])
+        assert start == int(bp_in[g]) - dropped
+        assert fin - start == int(bp_in[g + 1] - bp_in[g]) - 2 + int(did_swap[g])
+        assert bool((gi[start:fin] == g).all())
         assert abs(float(pi[start:fin].exp().sum()) - 1.0) < 1e-4
-        minus += 2 - did_swap[i]
+        dropped += 2 - int(did_swap[g])
 
 
 def test_reference_randomized_property():
-    rng = random.Random(42)
-    nprng = np.random.RandomState(4)
+    gen = np.random.default_rng(42)
     torch.manual_seed(1)
     model = small_model(swap_allowed=True)
     for _ in range(25):
-        case = random_case(rng, nprng)
-        if int((case[3][1:] - case[3][:-1]).min()) <= 2:       # the model asserts > 2 nodes per graph (line 313)
-            continue
         with torch.no_grad():
-            check_random_case(model, case)
+            check_random_case(model, random_case(gen))
 
 
 def test_scatter_log_softmax_known_answer():
