@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
 _lib = None
-ABI_VERSION = 4          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
+ABI_VERSION = 5          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
 
 vp = C.c_void_p
 ci = C.c_int
@@ -29,6 +29,7 @@ _SIGS = {
     "hexgnn_csr_workspace_bytes": (sz, [ci, ci]),
     "hexgnn_csr_build": (ci, [ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp]),
     "hexgnn_csr_build_grouped": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "hexgnn_csr_build_grouped_pack": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]),
     "hexgnn_graph_ptr": (ci, [ci, ci, vp, vp, vp]),
     "hexgnn_sage_stack_pack_bytes": (sz, [ci, ci, ci]),
     "hexgnn_sage_stack_saved_bytes": (sz, [ci, ci, ci, ci]),

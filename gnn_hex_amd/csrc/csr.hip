@@ -4,6 +4,7 @@
 // Replaces the per-layer edge_index indexing of torch_geometric's propagate (GN0/models.py:276)
 // and torch_geometric Batch.ptr / torch_scatter's segment lookup (GN0/models.py:381,578).
 #include "hexgnn_internal.h"
+#include "hexgnn_pack.h"
 
 namespace hexgnn {
 
@@ -176,12 +177,12 @@ __device__ __forceinline__ void csr_lower_bound2_256(const int64_t* __restrict__
     rb = lo_b;
 }
 
-__global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, const int64_t* __restrict__ src,
-                                                         const int64_t* __restrict__ dst, const int* __restrict__ gptr,
-                                                         const int64_t* __restrict__ ptr64, int* __restrict__ gptr_out,
-                                                         int* __restrict__ rowptr, int* __restrict__ col,
-                                                         int* __restrict__ rowptr_t, int* __restrict__ col_t,
-                                                         float* __restrict__ invdeg, int* __restrict__ status) {
+__device__ __forceinline__ void csr_grouped_body(int n, int e, int b, const int64_t* __restrict__ src,
+                                                 const int64_t* __restrict__ dst, const int* __restrict__ gptr,
+                                                 const int64_t* __restrict__ ptr64, int* __restrict__ gptr_out,
+                                                 int* __restrict__ rowptr, int* __restrict__ col,
+                                                 int* __restrict__ rowptr_t, int* __restrict__ col_t,
+                                                 float* __restrict__ invdeg, int* __restrict__ status) {
     __shared__ int s_start[2][kCsrMaxGraph + 1];   // row starts (local, exclusive prefix), CSR and transpose
     __shared__ int s_cnt[2][kCsrMaxGraph];         // degree histogram, then fill cursors
     __shared__ int s_part[2][256];
@@ -302,6 +303,37 @@ __global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, c
     }
 }
 
+__global__ __launch_bounds__(256) void csr_grouped_kernel(int n, int e, int b, const int64_t* __restrict__ src,
+                                                         const int64_t* __restrict__ dst, const int* __restrict__ gptr,
+                                                         const int64_t* __restrict__ ptr64, int* __restrict__ gptr_out,
+                                                         int* __restrict__ rowptr, int* __restrict__ col,
+                                                         int* __restrict__ rowptr_t, int* __restrict__ col_t,
+                                                         float* __restrict__ invdeg, int* __restrict__ status) {
+    csr_grouped_body(n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg, status);
+}
+
+// The same build + the weight pack of the forward call that follows, in ONE launch: workgroups [0, b) build the CSR of one
+// graph each, the rest pack (the two do not depend on each other; as two launches the 5-us pack sat between the CSR build and
+// the first kernel of the network on every step).
+constexpr int kPackPer = 8;
+struct CsrArgs {
+    int n, e, b;
+    const int64_t* src; const int64_t* dst; const int* gptr; const int64_t* ptr64;
+    int* gptr_out; int* rowptr; int* col; int* rowptr_t; int* col_t; float* invdeg; int* status;
+};
+__global__ __launch_bounds__(256) void csr_grouped_pack_kernel(CsrArgs c, PackArgs pa, char* __restrict__ wpack, int nbx) {
+    if ((int)blockIdx.x < c.b) {
+        csr_grouped_body(c.n, c.e, c.b, c.src, c.dst, c.gptr, c.ptr64, c.gptr_out, c.rowptr, c.col, c.rowptr_t, c.col_t, c.invdeg,
+                         c.status);
+    } else {
+        // (this kernel's static LDS allows few workgroups per CU: a pack workgroup takes kPackPer of the pack kernel's blocks, so
+        // that CSR + pack workgroups are resident in one round)
+        const int i0 = ((int)blockIdx.x - c.b) * kPackPer, tot = nbx * pa.L;
+        for (int i = i0; i < min(i0 + kPackPer, tot); ++i) sage_pack_body(pa, wpack, i % nbx, i / nbx, nbx);
+    }
+
+}
+
 }  // namespace hexgnn
 
 using namespace hexgnn;
@@ -387,6 +419,30 @@ int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int6
         (void)hipMemsetAsync(rowptr_t, 0, sizeof(int) * (size_t)(n + 1), stream);
         if (gptr_out) (void)hipMemsetAsync(gptr_out, 0, sizeof(int), stream);
     }
+    return check_launch();
+}
+
+int hexgnn_csr_build_grouped_pack(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                                  const int64_t* ptr64, int* gptr_out, int* rowptr, int* col, int* rowptr_t, int* col_t,
+                                  float* invdeg, int* status, int c_in, int hidden, int num_layers,
+                                  const float* const* wl, const float* const* bl, const float* const* wr, void* wpack,
+                                  hexgnn_stream_t stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n < 0 || e < 0 || b < 1 || !rowptr || !rowptr_t || !status || (!gptr && !ptr64) || (ptr64 && !gptr_out) ||
+        (n > 0 && !invdeg) || !wl || !bl || !wr || !wpack)
+        return HEXGNN_EINVAL;
+    if (e > 0x1fffffff) return HEXGNN_EUNSUPPORTED;
+    if (e > 0 && (!src || !dst || !col || !col_t)) return HEXGNN_EINVAL;
+    StackPlan p;
+    int rc = make_plan(n, c_in, hidden, num_layers, &p);
+    if (rc != HEXGNN_OK) return rc;
+    PackArgs pa;
+    rc = fill_pack_args(p, c_in, hidden, wl, bl, wr, &pa);
+    if (rc != HEXGNN_OK) return rc;
+    const CsrArgs c{n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg, status};
+    const int nbx = 2 * p.nt * p.nt;
+    KernelTimer kt(HEXGNN_K_CSR, stream);
+    csr_grouped_pack_kernel<<<b + (nbx * p.L + kPackPer - 1) / kPackPer, 256, 0, stream>>>(c, pa, (char*)wpack, nbx);
     return check_launch();
 }
 

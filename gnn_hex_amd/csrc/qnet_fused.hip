@@ -199,7 +199,9 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     QPlan qp;
     int rc = make_qplan(n, b, c_in, hidden, total_layers, &qp);
     if (rc != HEXGNN_OK) return rc;
-    if (!gptr || !wl || !bl || !wr || !lin_w || !lin_b || !wpack || !saved || !status) return HEXGNN_EINVAL;
+    // (wl = bl = wr = NULL: the weights were packed by hexgnn_csr_build_grouped_pack of this forward; exact fp32 only)
+    const bool packed = !wl && !bl && !wr && math == 0;
+    if (!gptr || (!packed && (!wl || !bl || !wr)) || !lin_w || !lin_b || !wpack || !saved || !status) return HEXGNN_EINVAL;
     if (mode != 2 && (!v0_w || !v0_b || !v1_w || !v1_b)) return HEXGNN_EINVAL;
     if (mode == 1 && !out_v) return HEXGNN_EINVAL;
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts || !q)) return HEXGNN_EINVAL;

@@ -14,15 +14,10 @@
 #include <type_traits>
 #include <utility>
 #include "hexgnn_internal.h"
+#include "hexgnn_pack.h"
 #include "hexgnn_memops.h"
 
 namespace hexgnn {
-
-struct LayerPtrs {
-    const float* wl[kMaxLayers];
-    const float* bl[kMaxLayers];
-    const float* wr[kMaxLayers];
-};
 
 int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
     const int hp = padded_width(hidden);
@@ -53,64 +48,10 @@ int make_plan(int n, int c_in, int hidden, int L, StackPlan* p) {
     return HEXGNN_OK;
 }
 
-// ---- weight packing (one launch per stack call; grid.y = layer) ------------------------------------
-struct PackArgs {
-    LayerPtrs p;
-    size_t fwd_off[kMaxLayers], bwd_off[kMaxLayers], bias_off[kMaxLayers];
-    size_t flag_off;
-    int hp, nt, L, c_in, hidden, small_first;
-};
-
+// ---- weight packing (one launch per stack call; grid.y = layer): body in hexgnn_pack.h -------------------------------------
 __global__ void sage_pack_kernel(PackArgs a, char* __restrict__ wpack) {
-    const int l = blockIdx.y;
-    const int hp = a.hp, nt = a.nt, H = a.hidden;
-    const float* wl = a.p.wl[l];
-    const float* wr = a.p.wr[l];
-    const float* bl = a.p.bl[l];
-    float* bias = (float*)(wpack + a.bias_off[l]);
-    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < hp) bias[tid] = tid < H ? bl[tid] : 0.f;
-    // progress counters of the one-launch stack kernels (forward + backward) start every forward call at zero
-    if (l == 0) {
-        unsigned* flags = reinterpret_cast<unsigned*>(wpack + a.flag_off);
-        for (int i = tid; i < 2 * kStackFlagWords; i += gridDim.x * blockDim.x) flags[i] = 0u;
-    }
-    if (l == 0 && a.small_first) {
-        float* w0 = (float*)(wpack + a.fwd_off[l]);
-        const int tot = hp * kSmallCin;
-        if (tid < tot) {
-            const int o = tid / kSmallCin, q = tid % kSmallCin;
-            const bool ok = o < H && q < a.c_in;
-            w0[tid] = ok ? wl[o * a.c_in + q] : 0.f;
-            w0[tot + tid] = ok ? wr[o * a.c_in + q] : 0.f;
-        }
-        return;
-    }
-    const int in = H;  // hidden -> hidden
-    const int tot = 2 * nt * nt * 256;
-    if (tid >= tot) return;
-    float* pf = (float*)(wpack + a.fwd_off[l]);
-    float* pb = (float*)(wpack + a.bwd_off[l]);
-    {   // forward pack  P[c][t][lane][j], c < 2NT (k chunk of [agg|x]), t < NT (output tile)
-        const int c = tid / (nt * 256), rem = tid % (nt * 256);
-        const int t = rem / 256, lj = rem % 256, lane = lj >> 2, j = lj & 3;
-        const int g = lane >> 4, cx = lane & 15;
-        const int k = 16 * (c % nt) + 4 * g + j, o = 16 * t + cx;
-        const float* w = c < nt ? wl : wr;
-        pf[tid] = (k < in && o < H) ? w[o * in + k] : 0.f;
-    }
-    {   // backward pack PB[h][c][t][lane][j]: h = 0 the W_l part (dAgg), 1 the W_r part (dXs), each a contiguous half;
-        // c < NT (k chunk over outputs o), t < NT (tile of input features)
-        const int h = tid / (nt * nt * 256), rem0 = tid % (nt * nt * 256);
-        const int c = rem0 / (nt * 256), rem = rem0 % (nt * 256);
-        const int t = rem / 256, lj = rem % 256, lane = lj >> 2, j = lj & 3;
-        const int g = lane >> 4, cx = lane & 15;
-        const int o = 16 * c + 4 * g + j, i = 16 * t + cx;
-        const float* w = h == 0 ? wl : wr;
-        pb[tid] = (o < H && i < in) ? w[o * in + i] : 0.f;
-    }
+    sage_pack_body(a, wpack, blockIdx.x, blockIdx.y, gridDim.x);
 }
-
 
 // ---- split-precision packing for the fused kernels (math mode 1, "f16x3"): every fp32 weight w of a layer is scaled
 //      by the layer's power of two s_W (max |w| * s_W in [2^14, 2^15)) and stored as two fp16 planes hi = f16(w s_W),
@@ -1797,16 +1738,25 @@ void make_bwd_plan(int n, const StackPlan& p, BwdPlan* b) {
     b->total = off;
 }
 
-int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
-                const float* const* wr, void* wpack, hipStream_t st, int math, unsigned* zero_maxima) {
-    PackArgs pa;
+int fill_pack_args(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
+                   const float* const* wr, PackArgs* pa) {
     for (int l = 0; l < p.L; ++l) {
         if (!wl[l] || !bl[l] || !wr[l]) return HEXGNN_EINVAL;
-        pa.p.wl[l] = wl[l]; pa.p.bl[l] = bl[l]; pa.p.wr[l] = wr[l];
-        pa.fwd_off[l] = p.fwd_off[l]; pa.bwd_off[l] = p.bwd_off[l]; pa.bias_off[l] = p.bias_off[l];
+        pa->p.wl[l] = wl[l]; pa->p.bl[l] = bl[l]; pa->p.wr[l] = wr[l];
+        pa->fwd_off[l] = p.fwd_off[l]; pa->bwd_off[l] = p.bwd_off[l]; pa->bias_off[l] = p.bias_off[l];
     }
-    pa.hp = p.hp; pa.nt = p.nt; pa.L = p.L; pa.c_in = c_in; pa.hidden = hidden; pa.small_first = p.small_first;
-    pa.flag_off = p.flag_off;
+    pa->hp = p.hp; pa->nt = p.nt; pa->L = p.L; pa->c_in = c_in; pa->hidden = hidden; pa->small_first = p.small_first;
+    pa->flag_off = p.flag_off;
+    return HEXGNN_OK;
+}
+
+int launch_pack(const StackPlan& p, int c_in, int hidden, const float* const* wl, const float* const* bl,
+                const float* const* wr, void* wpack, hipStream_t st, int math, unsigned* zero_maxima) {
+    if (!wl && !bl && !wr && math == 0) return HEXGNN_OK;      // packed already (hexgnn_csr_build_grouped_pack of this forward)
+    if (!wl || !bl || !wr) return HEXGNN_EINVAL;
+    PackArgs pa;
+    const int rcp = fill_pack_args(p, c_in, hidden, wl, bl, wr, &pa);
+    if (rcp != HEXGNN_OK) return rcp;
     const int pack_elems = 2 * p.nt * p.nt * 256;
     sage_pack_kernel<<<dim3((pack_elems + 255) / 256, p.L), 256, 0, st>>>(pa, (char*)wpack);
     if (math == 1) {   // overwrite the hidden layers' weight packs with the split-f16 layout (biases / raw layer stay fp32)
@@ -1904,12 +1854,12 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     }
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
-    if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
+    if (!wpack || ((!wl || !bl || !wr) && (wl || bl || wr))) return HEXGNN_EINVAL;
     if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts)) return HEXGNN_EINVAL;
     if (need_backward && !saved) return HEXGNN_EINVAL;
     if (p.small_first ? x_stride < c_in : x_stride != p.hp) return HEXGNN_EINVAL;
 
-    rc = launch_pack(p, c_in, hidden, wl, bl, wr, wpack, st, 0);
+    rc = launch_pack(p, c_in, hidden, wl, bl, wr, wpack, st, 0);     // (all three arrays NULL: packed by the CSR call already)
     if (rc != HEXGNN_OK) return rc;
     if (n == 0) return check_launch();
 

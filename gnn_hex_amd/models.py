@@ -577,6 +577,7 @@ class DuellingTwoHeaded(torch.nn.Module):
         x2 = x[:, :2]
 
         gs = getattr(edge_index, "_hex_csr", None)          # CSR emitted by the env builder, if any
+        deferred = None
         # edge_index CSR-sorted once per batch; collated batches (edges grouped by graph) take the one-launch build
         grouped = (gs is None or gs.n != n) and getattr(edge_index, "_hex_grouped", False) \
             and max_nodes is not None and max_nodes <= 2048
@@ -584,7 +585,9 @@ class DuellingTwoHeaded(torch.nn.Module):
             b = int(ptr.numel()) - 1            # the build reads the int64 ptr itself and emits the int32 copy
             if b > 0 and edge_index.dtype == torch.int64 and edge_index.dim() == 2 and edge_index.is_contiguous() \
                     and edge_index.is_cuda:
-                gs = ops.GraphStructure.grouped(edge_index, n, b, ptr)      # one allocation for all index arrays
+                # built below: together with the weight pack when the direct path takes the call (one launch), else right away
+                gs = None
+                deferred = (edge_index, n, b, ptr)
                 gptr = None                                                 # (gs.gptr: a view made on demand)
             else:
                 gptr = torch.empty(b + 1, dtype=torch.int32, device=x.device)
@@ -619,7 +622,9 @@ class DuellingTwoHeaded(torch.nn.Module):
                 if not cache.valid():
                     cache.refresh()
                 if cache.direct_ok or not grad_on:
-                    fargs = (cache, x2, gs, gptr, b, c_in, h, n_body, n_head, mode, grad_on, layered)
+                    # (a deferred grouped CSR build goes in as the tuple: built WITH the weight pack, in one launch)
+                    fargs = (cache, x2, gs if gs is not None else deferred, gptr, b, c_in, h, n_body, n_head, mode, grad_on,
+                             layered)
                     if grad_on:
                         anchor = self.__dict__.get("_hex_anchor")
                         if anchor is None or anchor.device != x.device:
@@ -642,6 +647,8 @@ class DuellingTwoHeaded(torch.nn.Module):
                     return q
             if layered:
                 fused = False       # (frozen / hooked parameters: the per-module composition below)
+        if gs is None:              # every other path: the structure now
+            gs = ops.GraphStructure.grouped(*deferred)
         if fused:
             grad_on = torch.is_grad_enabled()
             params = ent[1]

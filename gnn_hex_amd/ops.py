@@ -141,7 +141,7 @@ class GraphStructure:
                                       _stream()), "hexgnn_csr_build")
 
     @classmethod
-    def grouped(cls, edge_index: torch.Tensor, num_nodes: int, b: int, ptr64: torch.Tensor):
+    def grouped(cls, edge_index: torch.Tensor, num_nodes: int, b: int, ptr64: torch.Tensor, pack=None):
         """The one-launch build for a collated batch (edges grouped by graph, int64 ``ptr`` on the device) with ONE int32
         allocation [rowptr | rowptr_t | col | col_t | gptr] + one for 1/deg instead of six, and the raw pointers kept in
         ``_ptrs`` = (rowptr, col, rowptr_t, col_t, invdeg, gptr, status) so that the fused calls need no ``data_ptr()``: the
@@ -161,6 +161,14 @@ class GraphStructure:
         self._ibuf, self._offs = ibuf, (o1, o2, o3, o4)
         self.invdeg, self.status = invdeg, status
         self._ptrs = (base, base + 4 * o2, base + 4 * o1, base + 4 * o3, invdeg.data_ptr(), base + 4 * o4, status.data_ptr())
+        if pack is not None:
+            # + the weight pack of the network call that follows, in the same launch: pack = (c_in, hidden, layers, wl, bl, wr
+            # pointer arrays, wpack address); that call is then given no weight arrays
+            _lib.check(_lib.lib().hexgnn_csr_build_grouped_pack(
+                n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,
+                base + 4 * o3, self._ptrs[4], self._ptrs[6], pack[0], pack[1], pack[2], pack[3], pack[4], pack[5], pack[6],
+                _stream()), "hexgnn_csr_build_grouped_pack")
+            return self
         _lib.check(_lib.lib().hexgnn_csr_build_grouped(
             n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,
             base + 4 * o3, self._ptrs[4], self._ptrs[6], _stream()), "hexgnn_csr_build_grouped")
@@ -1017,6 +1025,13 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     base = buf.data_ptr()
     q = torch.empty(n, dtype=torch.float32, device=dev)
     out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+    wl, bl, wr = cache.wl, cache.bl, cache.wr
+    if type(gs) is tuple:       # deferred grouped build (models.py): CSR + weight pack in one launch, now that wpack exists
+        if _MATH == 0:
+            gs = GraphStructure.grouped(gs[0], gs[1], gs[2], gs[3], pack=(c_in, hidden, tot, wl, bl, wr, base + a_bytes))
+            wl = bl = wr = None
+        else:
+            gs = GraphStructure.grouped(*gs)
     gp = gs._ptrs
     if gp is None:
         gp = (gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.invdeg.data_ptr(),
@@ -1024,7 +1039,7 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     t = cache.tail
     stream = _stream()
     _lib.check(L.hexgnn_qnet_forward(
-        n, b, c_in, hidden, tot, mode, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, cache.wl, cache.bl, cache.wr,
+        n, b, c_in, hidden, tot, mode, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl, wr,
         t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), body_layers - 1,
         _MATH, q.data_ptr(), out_v.data_ptr() if out_v is not None else None, gp[6], stream), "hexgnn_qnet_forward")
     call = _QNetCall()
@@ -1065,14 +1080,21 @@ def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: 
     base = buf.data_ptr()
     q = torch.empty(n, dtype=torch.float32, device=dev)
     out_v = torch.empty(b, dtype=torch.float32, device=dev) if mode == 1 else None
+    wl, bl, wr = cache.wl, cache.bl, cache.wr
+    if type(gs) is tuple:       # deferred grouped build: CSR + weight pack in one launch (hidden <= 128: the packed layout)
+        if hidden <= 128:
+            gs = GraphStructure.grouped(gs[0], gs[1], gs[2], gs[3], pack=(c_in, hidden, tot, wl, bl, wr, base + a_bytes))
+            wl = bl = wr = None
+        else:
+            gs = GraphStructure.grouped(*gs)
     gp = gs._ptrs
     if gp is None:
         gp = (gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.rowptr_t.data_ptr(), gs.col_t.data_ptr(), gs.invdeg.data_ptr(),
               gptr.data_ptr(), gs.status.data_ptr())
     t = cache.tail
     stream = _stream()
-    _lib.check(L.hexgnn_sage_stack_forward(n, c_in, hidden, tot, gp[0], gp[1], gp[4], x.data_ptr(), x_stride, cache.wl, cache.bl,
-                                           cache.wr, base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), 0, stream),
+    _lib.check(L.hexgnn_sage_stack_forward(n, c_in, hidden, tot, gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl,
+                                           wr, base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), 0, stream),
                "hexgnn_sage_stack_forward")
     h_top = base + 4 * (tot - 1) * n * hp
     _lib.check(L.hexgnn_head_forward(n, b, hidden, mode, gp[5], h_top, t[0], t[1], t[2], t[3], t[4], t[5], q.data_ptr(),

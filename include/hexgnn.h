@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HEXGNN_ABI_VERSION 4
+#define HEXGNN_ABI_VERSION 5
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
@@ -68,6 +68,15 @@ int hexgnn_csr_build(int n, int e, const int64_t* src, const int64_t* dst,
 int hexgnn_csr_build_grouped(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
                              const int64_t* ptr64, int* gptr_out, int* rowptr, int* col, int* rowptr_t, int* col_t,
                              float* invdeg, int* status, hexgnn_stream_t stream);
+
+/* hexgnn_csr_build_grouped + the weight pack of the network call that follows (hexgnn_qnet_forward /
+ * hexgnn_sage_stack_forward over the same c_in / hidden / num_layers and the same wpack) in ONE launch: the two do not depend on
+ * each other.  The forward call is then given wl = bl = wr = NULL ("packed already").  b >= 1; exact fp32 math only. */
+int hexgnn_csr_build_grouped_pack(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                                  const int64_t* ptr64, int* gptr_out, int* rowptr, int* col, int* rowptr_t, int* col_t,
+                                  float* invdeg, int* status, int c_in, int hidden, int num_layers,
+                                  const float* const* wl, const float* const* bl, const float* const* wr, void* wpack,
+                                  hexgnn_stream_t stream);
 
 /* Replaces the segment lookup inside torch_scatter.scatter(x, graph_indices) (GN0/models.py:381,578)
  * and torch_geometric Batch.ptr: batch (int64, sorted ascending, values in [0,b)) -> gptr[b+1]. */
