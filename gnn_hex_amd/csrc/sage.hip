@@ -1468,10 +1468,9 @@ struct DwReduceArgs {
 };
 
 // out element space per layer: [hidden][2*hidden + 1]; fixed summation order over slices (deterministic)
-__global__ void sage_dw_reduce_kernel(DwReduceArgs a, const float* __restrict__ part) {
-    const int li = blockIdx.y;
+__device__ __forceinline__ void sage_dw_reduce_body(const DwReduceArgs& a, const float* __restrict__ part, int bx, int li) {
     const int H = a.hidden, hp = a.hp;
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = bx * 256 + (int)threadIdx.x;
     const int per = 2 * H + 1;
     if (idx >= H * per) return;
     const int o = idx / per, c = idx % per;
@@ -1495,15 +1494,18 @@ __global__ void sage_dw_reduce_kernel(DwReduceArgs a, const float* __restrict__ 
     else if (c < 2 * H) a.dwr[li][o * H + (c - H)] = sum;
     else a.dbl[li][o] = sum;
 }
+__global__ __launch_bounds__(256) void sage_dw_reduce_kernel(DwReduceArgs a, const float* __restrict__ part) {
+    sage_dw_reduce_body(a, part, blockIdx.x, blockIdx.y);
+}
 
 // ---- raw first layer weight gradient: partial [S][hp][17] = sum_rows G[row][o] * (agg0[row][0..7] | x0[row][0..7] | 1) ----
-__global__ __launch_bounds__(256) void sage_first_dw_kernel(
-    int n, int c_in, int hp, int rows_per_slice /* == 128 */, const float* __restrict__ g, const float* __restrict__ agg0,
-    const float* __restrict__ x, int x_stride, float* __restrict__ part) {
+__device__ __forceinline__ void sage_first_dw_body(
+    int n, int c_in, int hp, int rows_per_slice /* <= 128 */, const float* __restrict__ g, const float* __restrict__ agg0,
+    const float* __restrict__ x, int x_stride, float* __restrict__ part, int bx) {
     __shared__ float s_in[128][16];   // per row: agg0[0..7] | x0[0..7]
     __shared__ float red[128 * 17];
     const int tid = threadIdx.x, o = tid & 127, ph = tid >> 7;
-    const int r_beg = blockIdx.x * rows_per_slice, r_end = min(n, r_beg + rows_per_slice);
+    const int r_beg = bx * rows_per_slice, r_end = min(n, r_beg + rows_per_slice);
     const int rows = r_end - r_beg;
     for (int i = tid; i < 128 * 16; i += 256) {
         const int rr = i >> 4, q = i & 15;
@@ -1544,10 +1546,26 @@ __global__ __launch_bounds__(256) void sage_first_dw_kernel(
     }
     __syncthreads();
     if (ph == 0 && o < hp) {
-        float* out = part + ((size_t)blockIdx.x * hp + o) * 17;
+        float* out = part + ((size_t)bx * hp + o) * 17;
 #pragma unroll
         for (int q = 0; q < 17; ++q) out[q] = acc[q] + red[o * 17 + q];
     }
+}
+__global__ __launch_bounds__(256) void sage_first_dw_kernel(
+    int n, int c_in, int hp, int rows_per_slice, const float* __restrict__ g, const float* __restrict__ agg0,
+    const float* __restrict__ x, int x_stride, float* __restrict__ part) {
+    sage_first_dw_body(n, c_in, hp, rows_per_slice, g, agg0, x, x_stride, part, blockIdx.x);
+}
+// the slab reduce of the hidden layers and the raw first layer's partial sums are independent: ONE launch, workgroups
+// [0, nrb * nh) reduce, the rest take one row slice of the first layer each
+__global__ __launch_bounds__(256) void sage_dw_reduce_first_kernel(DwReduceArgs a, const float* __restrict__ part, int nrb, int nh,
+                                                                  int n, int c_in, int rows_per_slice,
+                                                                  const float* __restrict__ g0, const float* __restrict__ agg0,
+                                                                  const float* __restrict__ x, int x_stride,
+                                                                  float* __restrict__ part0) {
+    const int bx = blockIdx.x;
+    if (bx < nrb * nh) sage_dw_reduce_body(a, part, bx % nrb, bx / nrb);
+    else sage_first_dw_body(n, c_in, a.hp, rows_per_slice, g0, agg0, x, x_stride, part0, bx - nrb * nh);
 }
 
 __global__ __launch_bounds__(64) void sage_first_dw_reduce_kernel(
@@ -1784,6 +1802,7 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
     const int lo = layer_lo < 0 ? (p.small_first ? 1 : 0) : layer_lo;
     const int first_hidden = lo;                    // first layer of this launch (hidden-input layers only)
     const int nh = (layer_hi < 0 ? p.L : layer_hi) - lo;
+    bool first_done = false;
     if (nh > 0) {
         DwArgs da;
         DwReduceArgs ra;
@@ -1808,11 +1827,21 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
             HEXGNN_NT_SWITCH(p.nt, (launch_dw<NT_>(da, nh, part, st)));
         }
         const int tot = hidden * (2 * hidden + 1);
-        if (!hidden_only_no_reduce) sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
+        if (!hidden_only_no_reduce) {
+            if (p.small_first && layer_lo < 0) {       // + the raw first layer's row-slice partials in the same launch
+                const int nrb = (tot + 255) / 256;
+                sage_dw_reduce_first_kernel<<<nrb * nh + b.S0, 256, 0, st>>>(ra, part, nrb, nh, n, c_in, b.rps0, G,
+                                                                            (const float*)(sv + p.agg_off[0]), x, x_stride, part0);
+                first_done = true;
+            } else {
+                sage_dw_reduce_kernel<<<dim3((tot + 255) / 256, nh), 256, 0, st>>>(ra, part);
+            }
+        }
     }
     if (p.small_first && !hidden_only_no_reduce && layer_lo < 0) {
-        sage_first_dw_kernel<<<b.S0, 256, 0, st>>>(n, c_in, p.hp, b.rps0, G, (const float*)(sv + p.agg_off[0]), x,
-                                                   x_stride, part0);
+        if (!first_done)
+            sage_first_dw_kernel<<<b.S0, 256, 0, st>>>(n, c_in, p.hp, b.rps0, G, (const float*)(sv + p.agg_off[0]), x,
+                                                       x_stride, part0);
         const int tot = hidden * (2 * c_in + 1);
         sage_first_dw_reduce_kernel<<<tot, 64, 0, st>>>(b.S0, p.hp, hidden, c_in, part0, d_wl[0], d_bl[0], d_wr[0]);
     }
