@@ -11,6 +11,7 @@
 // its row r, the feature chunks {16c+4g .. 16c+4g+3} of every in-neighbour straight into registers; these
 // four floats are the k-slices of four consecutive v_mfma_f32_16x16x4_f32 (the K order is permuted
 // consistently on the packed-weight side).  fp32 in / fp32 accumulate: exact fmaf chains, deterministic.
+#include <mutex>
 #include <type_traits>
 #include <utility>
 #include "hexgnn_internal.h"
@@ -1623,7 +1624,9 @@ static void launch_bwd(int n, const int* rowptr_t, const int* col_t, const float
 static int g_cu_count = 0;
 static int* g_stack_status = nullptr;
 static bool persist_ready(hipStream_t st) {
+    static std::mutex mu;                      // (two host threads may issue their first stack call at the same time)
     static int state = 0;                      // 0 = not tried yet, 1 = ready, -1 = unavailable
+    std::lock_guard<std::mutex> lock(mu);
     if (state != 0) return state > 0;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) {
