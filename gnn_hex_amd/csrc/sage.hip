@@ -781,12 +781,14 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     //           self half, where they wait for their pieces -- the other four waves keep the matrix pipe busy meanwhile);
     //           nobody enters an aggregate half before all four have.
     // The progress counter of the block (global) is raised at the same point, after the wave's stores are acknowledged,
-    // and only then does a wave that reads other blocks' rows wait for those blocks (publishing first: two neighbouring
-    // blocks wait for each other); the global half of the gather starts kGo gaps into the self half for that reason.
-    // Rows of OTHER blocks are fetched in the TAIL of the self half (behind its last MFMA group, a ring of three landing
-    // buffers -- the LDS landing buffer is free by then): a neighbour block's counter needs a write-through acknowledge, an
-    // atomic and a poll round trip (8-10 k ticks after the layer started, profiles/r03/pstamps_*.txt); waiting for it a few
-    // groups into the self half made the edge waves of every block the slow ones of every layer.
+    // and only later does a wave that reads other blocks' rows wait for those blocks (publishing first: two neighbouring
+    // blocks wait for each other).
+    // Rows of OTHER blocks are fetched in the TAIL of the self half (behind its last MFMA group; a ring of four landing
+    // buffers: the three of the gather -- the LDS one is free by then -- and the registers of the self rows, dead there): a
+    // neighbour block's counter needs a write-through acknowledge, an atomic and a poll round trip (8-10 k ticks after the
+    // layer started, profiles/r03/stack_stamps_MIX_v3_remote_wait_at_gap3.txt); waiting for it a few groups into the self half
+    // made the edge waves of every block the slow ones of every layer.  W_l and the bias are requested at the TOP of the next
+    // layer (behind the second barrier), not between the barriers.
     constexpr bool kV3 = RL::on && !BWD;      // (backward: the plain hand-over measured faster, 349 vs 357 us per MIX launch)
     constexpr int kGo = kV3 ? 4 : 0;              // gap of the publish hook + 1
     constexpr int kGt = kV3 ? (GatherLds<NT>::G > GatherLds<NT>::add_gap(kEll - 1) + 1 ? GatherLds<NT>::G
