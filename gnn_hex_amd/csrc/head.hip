@@ -285,12 +285,37 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
         if (row - r0 < 1024) s_dar[row - r0] = dar;
     }
     __syncthreads();
-    // dh rows: four lanes per row (64 rows per pass), 16-byte stores; advantage-linear gradient below: column c = tid&127
+    // dh rows: four lanes per row (64 rows per pass), 16-byte stores; advantage-linear gradient below: column c = tid&127.
+    // Per column ONE 16-byte LDS read (linear weight | pooled-sum + mean part | max part | min part) and one 8-byte read
+    // (rows of the maximum / minimum) instead of seven 4-byte ones; the mask rows of a pass are requested before its
+    // arithmetic (eight loads in flight instead of one round trip per column group).
     {
+        __shared__ f32x4 s_c4[128];
+        __shared__ int s_i2[128][2];
+        if (tid < 128) {
+            const int c = tid;
+            f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
+            int ia = -1, ib = -1;
+            if (c < H) {
+                v[0] = s_lw[c];
+                if (has_value) { v[1] = s_dp[c] + s_dp[3 * H + c] * inv_cnt; v[2] = s_dp[H + c]; v[3] = s_dp[2 * H + c]; ia = s_ax[c]; ib = s_an[c]; }
+            }
+            s_c4[c] = v;
+            s_i2[c][0] = ia; s_i2[c][1] = ib;
+        }
+        __syncthreads();
         const int sub = tid & 3, q4n = hp / 4;
         for (int row = r0 + (tid >> 2); row < r1; row += 64) {
             const float dar = (row - r0 < 1024) ? s_dar[row - r0] : dadv[row];
             f32x4* dr = reinterpret_cast<f32x4*>(dh + (size_t)row * hp);
+            f32x4 hv[8];
+            if (mask_dh) {      // dh * [h > 0]: the gradient the ReLU layer underneath receives
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int q = sub + 4 * u;
+                    hv[u] = q < q4n ? reinterpret_cast<const f32x4*>(h + (size_t)row * hp)[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int q = sub + 4 * u;
@@ -299,21 +324,18 @@ __global__ __launch_bounds__(256) void head_bwd_kernel(
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const int c = 4 * q + j;
-                        float t = 0.f;
-                        if (c < H) {
-                            t = dar * s_lw[c];
-                            if (has_value) {
-                                t += s_dp[c] + s_dp[3 * H + c] * inv_cnt;
-                                if (s_ax[c] == row) t += s_dp[H + c];
-                                if (s_an[c] == row) t += s_dp[2 * H + c];
-                            }
+                        const f32x4 k4 = s_c4[c];
+                        float t = dar * k4[0];                   // (pad columns: all four constants are zero)
+                        if (has_value) {
+                            t += k4[1];
+                            if (s_i2[c][0] == row) t += k4[2];
+                            if (s_i2[c][1] == row) t += k4[3];
                         }
                         v[j] = t;
                     }
-                    if (mask_dh) {      // dh * [h > 0]: the gradient the ReLU layer underneath receives
-                        const f32x4 hv = reinterpret_cast<const f32x4*>(h + (size_t)row * hp)[q];
+                    if (mask_dh) {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = hv[j] > 0.f ? v[j] : 0.f;
+                        for (int j = 0; j < 4; ++j) v[j] = hv[u][j] > 0.f ? v[j] : 0.f;
                     }
                     dr[q] = v;
                 }
