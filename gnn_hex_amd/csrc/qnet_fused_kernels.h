@@ -758,6 +758,13 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     int* s_an = reinterpret_cast<int*>(sc + 2304);   // [3][128]
     const int H2 = H / 2, H4 = 4 * H;
     if (tid < 128) s_w[tid] = tid < H ? a.lin_w[tid] : 0.f;
+    // the tail's small global operands are requested here, one round trip for all of them, instead of one each at the point
+    // of use (four exposed round trips on a path with no other work to hide them)
+    const float lin_b0 = a.lin_b[0];
+    const int vk_ = tid >> 3;
+    const float v0b_k = (a.mode != 2 && vk_ < H2) ? a.v0_b[vk_] : 0.f;
+    const float v1w_l = (a.mode != 2 && wave == 0 && lane < H2) ? a.v1_w[lane] : 0.f;
+    const float v1b_0 = a.mode != 2 ? a.v1_b[0] : 0.f;
     __syncthreads();
     // advantages from the registers: partial dot over this lane's chunks, reduce over the 4 lanes of the row
     float adv = 0.f;
@@ -768,7 +775,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     }
     adv += __shfl_xor(adv, 16);
     adv += __shfl_xor(adv, 32);
-    adv += a.lin_b[0];
+    adv += lin_b0;
     const float tadv = 2.f * tanhf(adv);
     if (g == 0 && rvalid) {
         a.adv_raw[grow] = adv;
@@ -841,17 +848,17 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         float p = (p4[0] + p4[1]) + (p4[2] + p4[3]);
         p = oct_sum(p);          // over the 8 lanes that share the hidden unit
         if (vpart == 0 && vk < H2) {
-            const float zz = fmaxf(p + a.v0_b[vk], 0.f);
+            const float zz = fmaxf(p + v0b_k, 0.f);
             s_z[vk] = zz;
             a.z[(size_t)gi * H2 + vk] = zz;
         }
     }
     __syncthreads();
     if (wave == 0) {
-        float p = lane < H2 ? a.v1_w[lane] * s_z[lane] : 0.f;
+        float p = lane < H2 ? v1w_l * s_z[lane] : 0.f;
         p = wsum64(p);
         if (lane == 0) {
-            const float v = p + a.v1_b[0];
+            const float v = p + v1b_0;
             a.vraw[gi] = v;
             s_misc[0] = tanhf(v);
         }
