@@ -271,6 +271,44 @@ __device__ __forceinline__ NbrRegs load_nbrs(const unsigned short* __restrict__ 
     nb.wlong = m > 8;
     return nb;
 }
+// The same registers when the graph's CSR does not fit the LDS arrays (more than col_cap edges: never a Hex board): ids and
+// bounds come from the global CSR, eb / ee stay relative to the graph's first edge e0.
+template <int XS>
+__device__ __forceinline__ NbrRegs load_nbrs_global(const int* __restrict__ rowptr, const int* __restrict__ col, int r0, int cnt,
+                                                    int e0, int lrow, bool rvalid, int g) {
+    NbrRegs nb;
+    const int eb = rvalid ? rowptr[r0 + lrow] - e0 : 0;
+    nb.ee = rvalid ? rowptr[r0 + lrow + 1] - e0 : 0;
+    const int deg = nb.ee - eb;
+    nb.eb = min(eb + 8, nb.ee);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) nb.off[k] = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        int j = kRows;
+        if (k < deg) { j = col[e0 + eb + k] - r0; if (j < 0 || j >= cnt) j = kRows; }
+        nb.off[k >> 1] |= (unsigned)(j * (XS * 4) + 16 * g) << (16 * (k & 1));
+    }
+    int m = deg;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) m = max(m, __shfl_xor(m, o));
+    m = __builtin_amdgcn_readfirstlane(m);
+    nb.wmax = min(m, 8);
+    nb.wlong = m > 8;
+    return nb;
+}
+// neighbours beyond the eighth, ids from the global CSR (the rare path of the rare case)
+template <int NT, int XS>
+__device__ __forceinline__ void gather_global_tail(const float* __restrict__ rows, const int* __restrict__ col, int r0, int cnt,
+                                                   int e_abs_b, int e_abs_e, int g, f32x4 (&ag)[NT]) {
+    for (int e = e_abs_b; e < e_abs_e; ++e) {
+        const int j = col[e] - r0;
+        if (j < 0 || j >= cnt) continue;
+        const f32x4* xj = reinterpret_cast<const f32x4*>(rows + j * XS) + g;
+#pragma unroll
+        for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
+    }
+}
 // ---- filler-carrying contraction ---------------------------------------------------------------------------------
 // A wave's non-MFMA work issued under its PARTNER's MFMA stream runs ~3x slower (measured: gathers, epilogues, even
 // vector-memory issue), but small groups of instructions placed between a wave's OWN MFMAs are nearly free.  So each K-half
@@ -302,7 +340,9 @@ template <int NT, int MATH> struct Gaps {
 //   MATH 1: split precision ("f16x3"): W s_W = Whi + Wlo, x s = xhi + xlo in fp16 (s = this row's power-of-two scale),
 //           acc += Wlo*xhi + Whi*xlo + Whi*xhi on v_mfma_f32_16x16x32_f16 (chunk pairs) / v_mfma_f32_16x16x16_f16
 //           (odd last chunk), fp32 accumulate; the caller multiplies by 1/(s s_W).
-template <int NT, int MATH, typename F>
+//   ZC (exact fp32 only): the accumulators start from zero -- the first MFMA of every tile takes the constant 0 as its
+//   srcC instead of a zero-filled register set (VALU moves cost MFMA time).
+template <int NT, int MATH, bool ZC = false, typename F>
 __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ whalf, int lane, const f32x4 (&x)[NT],
                                                    f32x4 (&acc)[NT], const float scale, F&& fill) {
     // The scheduling barriers pin the fillers between the MFMA groups, so the weight fragments of the next group are
@@ -322,7 +362,8 @@ __device__ __forceinline__ void contract_half_fill(const f32x4* __restrict__ wha
                 // (left to itself hipcc permutes a group, and the same tile can close one group and open the next)
 #pragma unroll
                 for (int t = 0; t < NT; ++t) {
-                    acc[t] = mfma16x16x4(w[t][j], x[c][j], acc[t]);
+                    if constexpr (ZC && c == 0 && j == 0) acc[t] = mfma16x16x4(w[t][j], x[c][j], f32x4{0.f, 0.f, 0.f, 0.f});
+                    else acc[t] = mfma16x16x4(w[t][j], x[c][j], acc[t]);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if constexpr (NT < 3) mfma_drain();
@@ -421,6 +462,13 @@ template <int MATH> __device__ __forceinline__ void load_guard() {
 template <int NT, int MATH> struct GatherLand {
     static constexpr int value = (MATH == 0 && (NT == 3 || NT == 4)) ? 3 : 1;
 };
+// Round 4: v_mfma_f32_16x16x4_f32 does not overlap VALU work on its SIMD (every VALU instruction adds ~3 cycles to the MFMA
+// stream: tools/microbench/mfma_valu_overlap.hip), so the gather is kept to the adds it needs: neighbour 0 lands in the
+// sums directly (no zero fill, no `0 + x` add), and an empty asm in every wave-uniform `if (k < wmax)` block keeps hipcc from
+// turning it into "add, then select per element" (it did for a third of the adds: 92 v_cndmask per layer).
+__device__ __forceinline__ void no_ifcvt() { asm volatile("" ::: "memory"); }
+// max(x, 0) as ONE instruction: on an MFMA result fmaxf() costs two (hipcc canonicalises a value it cannot prove quiet first)
+__device__ __forceinline__ float relu_raw(float x) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x)); return r; }
 template <int NT, int Q, int G, int MATH, int KL>
 __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb, f32x4 (&ag)[NT], f32x4 (&tbs)[KL][NT]) {
     const char* base = reinterpret_cast<const char*>(rows);
@@ -429,13 +477,21 @@ __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb,
         if constexpr (Q >= 2 && Q < 10) {
             constexpr int k = Q - 2;
             if (k < nb.wmax) {       // wave-uniform
+                no_ifcvt();
 #pragma unroll
-                for (int c = 0; c < NT; ++c) ag[c] += tbs[k % 3][c];
+                for (int c = 0; c < NT; ++c) {
+                    if constexpr (k == 0) ag[c] = tbs[0][c];
+                    else ag[c] += tbs[k % 3][c];
+                }
+            } else if constexpr (k == 0) {
+#pragma unroll
+                for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
         if constexpr (Q < 8) {
             constexpr int k = Q;
             if (k < nb.wmax) {
+                no_ifcvt();
                 const unsigned o = nb.off[k >> 1];
                 gather_read<NT>(base, (k & 1) ? (o >> 16) : (o & 0xffffu), tbs[k % 3]);
             }
@@ -451,7 +507,20 @@ __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb,
         constexpr int gap = (m * G + kShift) / 32;
         if constexpr (gap == Q) {
             constexpr int k = m / 4, part = m % 4;
-            if (k < nb.wmax) {       // wave-uniform
+            if constexpr (k == 0) {
+                // neighbour 0 (a row without neighbours reads the all-zero row): straight into the sums, no adds
+                if constexpr (part == 0) {
+                    if (0 < nb.wmax) {
+                        no_ifcvt();
+                        load_guard<MATH>();
+                        gather_read<NT>(base, nb.off[0] & 0xffffu, ag);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    }
+                }
+            } else if (k < nb.wmax) {       // wave-uniform
+                no_ifcvt();
                 if constexpr (part == 0) {
                     load_guard<MATH>();
                     const unsigned o = nb.off[k >> 1];
@@ -514,6 +583,9 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
 #pragma unroll
         for (int t = 0; t < NT; ++t) b0v[t] = b0[4 * t + g];
     }
+    // (exact fp32: the first hidden layer's bias row, which its accumulators start from)
+    f32x4 b1stg = f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (MATH == 0) { if (a.L > 1 && tid < HP / 4) b1stg = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[1])[tid]; }
     const int e0 = a.rowptr[r0], ne = a.rowptr[r1] - e0;
     const bool csr_lds = load_csr<NT>(lds, a.rowptr, a.col, r0, cnt, e0, ne, a.status);
     float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
@@ -538,7 +610,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             s_f[rr * 16 + 8 + qq] = (rr < cnt && qq < a.c_in) ? a.x[(size_t)(r0 + rr) * a.x_stride + qq] : 0.f;
         }
         __syncthreads();
-        nbr = load_nbrs<XS>(s_rp, s_col, lrow, rvalid && csr_lds, g);
+        nbr = csr_lds ? load_nbrs<XS>(s_rp, s_col, lrow, rvalid, g)
+                      : load_nbrs_global<XS>(a.rowptr, a.col, r0, cnt, e0, lrow, rvalid, g);
         if (tid < kRows) {
             float ag0[kSmallCin];
 #pragma unroll
@@ -606,7 +679,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         // (layer 0's rows go to global memory with the first hidden layer's fillers, like every other layer's: a store
         // here would be waited for at the barrier below)
     }
-    __syncthreads();   // xbuf + half B visible; half A (scratch) free
+    if constexpr (MATH == 0) { if (tid < HP / 4) reinterpret_cast<f32x4*>(lds + LD::off_bias)[tid] = b1stg; }
+    __syncthreads();   // xbuf + half B (+ the first hidden layer's bias row) visible; half A (scratch) free
 
     // ---- hidden layers ----
     const size_t slab = (size_t)a.n * HP;
@@ -622,6 +696,8 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     constexpr int kFill = kDma + NT;                         // filler slots used per phase
     constexpr int kTail = kFill > kGaps ? kGaps : kFill;     // narrow widths: the slots past the last gap run after the MFMAs
     float* s_bias = reinterpret_cast<float*>(lds + LD::off_bias);
+    // where this lane's accumulators start (exact fp32): the bias row, or the all-zero row for a pad row
+    const f32x4* binit = reinterpret_cast<const f32x4*>(rvalid ? s_bias : xbuf + kRows * XS) + g;
     const unsigned lds_w = (unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds + LD::off_w);
     const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
     const unsigned lane16 = 16 * lane;
@@ -642,13 +718,43 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         QSTAMP(0, l, 0);
         if (l > 1) publish_xmax(l - 1);
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[l]);
+        const bool more = l + 1 < a.L;
+        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[more ? l + 1 : l]) + kHalf;
+        // exact fp32: the NEXT layer's bias row is staged (its accumulators start from it); split math: this layer's
         f32x4 bstg = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (tid < HP / 4) bstg = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[l])[tid];
+        if (tid < HP / 4) bstg = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[(MATH == 0 && more) ? l + 1 : l])[tid];
+        auto dmaS = [&](auto qq) {
+            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
+        };
+        auto dmaA = [&](auto qq) {
+            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+        };
+        if (!wactive) {
+            // a wave without rows only moves its weight pieces (its own straight path: the active path below then has no
+            // `if (wactive)` regions whose merges cost register copies -- VALU instructions are MFMA time here)
+            static_for<0, kDma>(dmaS);
+            wait_vmem();
+            if constexpr (MATH == 1) { if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg; }
+            lds_barrier();
+            if constexpr (MATH == 0) { if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg; }
+            static_for<0, kDma>(dmaA);
+            wait_vmem();
+            lds_barrier();
+            continue;
+        }
         f32x4 acc[NT], ag[NT];
+        if constexpr (MATH == 0) {
+            // the accumulators start from the bias row (an LDS read instead of 14 zero moves + 14 adds in the epilogue);
+            // pad rows start from the all-zero row and stay exactly zero through the ReLU
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[t] = acc[t]; }
+            for (int t = 0; t < NT; ++t) acc[t] = binit[4 * t];
+        } else {
+#pragma unroll
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         float rs = 1.f, rinv = 1.f, mx = 0.f;
-        const bool fastg = csr_lds && wactive;
         f32x4 tb[GatherLand<NT, MATH>::value][NT];
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(xs, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
@@ -656,34 +762,25 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         const unsigned yprev_off = acts_off(l - 1);
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
-            if (fastg) gather_gap<NT, Q, kGaps, MATH>(xbuf, nbr, ag, tb);
-            if constexpr (Q < kDma) {
-                const int p = dma_share<NT>(wave, Q);
-                if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
-            } else if constexpr (Q < kDma + NT) {
-                buf_store(xs[Q - kDma], yprev, yprev_off + 64 * (Q - kDma));
-            }
+            gather_gap<NT, Q, kGaps, MATH>(xbuf, nbr, ag, tb);
+            if constexpr (Q < kDma) dmaS(qq);
+            else if constexpr (Q < kDma + NT) buf_store(xs[Q - kDma], yprev, yprev_off + 64 * (Q - kDma));
         };
-        if (wactive) { contract_half_fill<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs, fillS); static_for<kTail, kFill>(fillS); }
-        else static_for<0, kDma>(fillS);      // idle waves still move their weight pieces
-        if (wactive && rvalid) {
-            if (csr_lds) {
-                if (nbr.wlong) gather_lds<NT, XS>(xbuf, s_col, nbr.eb, nbr.ee, g, ag);
-            } else {
-                for (int e = a.rowptr[grow]; e < a.rowptr[grow + 1]; ++e) {
-                    const f32x4* xj = reinterpret_cast<const f32x4*>(xbuf + (a.col[e] - r0) * XS) + g;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) ag[c] += xj[4 * c];
-                }
-            }
+        contract_half_fill<NT, MATH>(wbuf + kHalf, lane, xs, acc, rs, fillS);
+        static_for<kTail, kFill>(fillS);
+        if (nbr.wlong) {      // (wave-uniform; pad rows: eb == ee)
+            if (csr_lds) gather_lds<NT, XS>(xbuf, s_col, nbr.eb, nbr.ee, g, ag);
+            else gather_global_tail<NT, XS>(xbuf, a.col, r0, cnt, e0 + nbr.eb, e0 + nbr.ee, g, ag);
         }
 #pragma unroll
         for (int c = 0; c < NT; ++c) ag[c] *= idg;          // idg == 0 on pad rows
         QSTAMP(0, l, 1);
         wait_vmem();
-        if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg;
+        if constexpr (MATH == 1) { if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg; }
         QSTAMP(0, l, 3);
-        lds_barrier();     // barrier 1: half A = W_l(l) + bias row; every gather of this layer is done; half B is free
+        lds_barrier();     // barrier 1: half A = W_l(l) (+ bias row, split math); every gather of this layer is done; half B is free
+        // (exact fp32: every wave has read this layer's bias row into its accumulators by now: the next layer's may land)
+        if constexpr (MATH == 0) { if (tid < HP / 4) reinterpret_cast<f32x4*>(s_bias)[tid] = bstg; }
         QSTAMP(0, l, 4);
         // ---- phase A ----
         float rsa = 1.f;
@@ -700,33 +797,26 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
             for (int t = 0; t < NT; ++t) acc[t] *= carry;
             rinv = rinva * (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
         }
-        const bool more = l + 1 < a.L;
-        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[more ? l + 1 : l]) + kHalf;
         const __amdgpu_buffer_rsrc_t ao = slab_rsrc(a.saved + a.agg_off[l]);
         const unsigned ao_off = (rvalid && a.need_backward) ? rowoff : kOob;
         auto fillA = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
-            if constexpr (Q < kDma) {
-                const int p = dma_share<NT>(wave, Q);
-                if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
-            } else if constexpr (Q < kDma + NT) {
-                buf_store(ag[Q - kDma], ao, ao_off + 64 * (Q - kDma));
-            }
+            if constexpr (Q < kDma) dmaA(qq);
+            else if constexpr (Q < kDma + NT) buf_store(ag[Q - kDma], ao, ao_off + 64 * (Q - kDma));
         };
-        if (wactive) { contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA); static_for<kTail, kFill>(fillA); }
-        else static_for<0, kDma>(fillA);
+        contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA);
+        static_for<kTail, kFill>(fillA);
         QSTAMP(0, l, 5);
-        if (wactive) {   // epilogue: bias, ReLU, new rows -> registers and LDS
+        {   // epilogue: (bias,) ReLU, new rows -> registers and LDS
             f32x4* xr = reinterpret_cast<f32x4*>(xbuf + lrow * XS) + g;
             const f32x4* bl = reinterpret_cast<const f32x4*>(s_bias) + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 f32x4 v = acc[t];
-                if constexpr (MATH == 1) v *= rinv;
-                v += bl[4 * t];
+                if constexpr (MATH == 1) { v *= rinv; v += bl[4 * t]; }
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) v[q4] = fmaxf(v[q4], 0.f);
-                v *= validf;              // pad rows stay exactly zero
+                for (int q4 = 0; q4 < 4; ++q4) v[q4] = relu_raw(v[q4]);
+                if constexpr (MATH == 1) v *= validf;              // pad rows stay exactly zero
                 xs[t] = v;
                 xr[4 * t] = v;
             }
@@ -1007,7 +1097,8 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         s_dar[tid] = dar;
     }
     __syncthreads();
-    const NbrRegs nbr = load_nbrs<XS>(s_rp, s_col, lrow, rvalid && csr_lds, g);
+    const NbrRegs nbr = csr_lds ? load_nbrs<XS>(s_rp, s_col, lrow, rvalid, g)
+                                : load_nbrs_global<XS>(a.rowptr_t, a.col_t, r0, cnt, e0, lrow, rvalid, g);
 
     // gradient w.r.t. the top layer's output, in the chained lane layout; advantage-linear partial alongside
     f32x4 gx[NT];
@@ -1073,21 +1164,21 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     // registers (a loop-carried prefetch made hipcc wait for the load in place).  store_G() then writes G_l for the
     // weight-gradient GEMM; it is a separate step so that the weight-half LDS writes can sit between the two (see the
     // forward kernel: a wait for staged loads placed after global stores also waits for the stores).
+    const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
+    const unsigned lane16 = 16 * lane;
+    const unsigned rowoff_v = rvalid ? rowoff : kOob;    // pad rows: stores dropped, loads return zeros
+    // (no `if (rvalid)` region: a pad row's y loads return zeros, so the mask alone zeroes its gradient, and the tap store
+    // drops out of range -- a divergent region around the mask cost a select or a copy per register at its merge)
     auto mask_rows = [&](const int l, const f32x4 (&yv)[NT]) {
-        if (rvalid) {
-            if (a.d_embeds && l == a.body_layers - 1) {
-                f32x4* de = reinterpret_cast<f32x4*>(a.d_embeds + (size_t)grow * HP) + g;
+        if (a.d_embeds && l == a.body_layers - 1) {
+            const __amdgpu_buffer_rsrc_t de = slab_rsrc(a.d_embeds);
 #pragma unroll
-                for (int t = 0; t < NT; ++t) de[4 * t] = gx[t];
-            }
+            for (int t = 0; t < NT; ++t) buf_store(gx[t], de, rowoff_v + 64 * t);
+        }
 #pragma unroll
-            for (int t = 0; t < NT; ++t) {
+        for (int t = 0; t < NT; ++t) {
 #pragma unroll
-                for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[t][q4] > 0.f ? gx[t][q4] : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int t = 0; t < NT; ++t) gx[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int q4 = 0; q4 < 4; ++q4) gx[t][q4] = yv[t][q4] > 0.f ? gx[t][q4] : 0.f;
         }
         if (l > 0) {
             f32x4* dr = reinterpret_cast<f32x4*>(dbuf + lrow * XS) + g;
@@ -1101,9 +1192,6 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             }
         }
     };
-    const unsigned rowoff = (unsigned)grow * (HP * 4) + 16 * g;      // byte offset of this lane's slot inside a [n][HP] slab
-    const unsigned lane16 = 16 * lane;
-    const unsigned rowoff_v = rvalid ? rowoff : kOob;    // pad rows: stores dropped, loads return zeros
     auto store_G = [&](const int l, const int t) {       // chunk t of this lane's row of G_l (held in gx)
         buf_store(gx[t], slab_rsrc(a.G + slab * l), rowoff_v + 64 * t);
     };
@@ -1128,6 +1216,8 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     for (int l = L - 1; l >= 1; --l) {
         QSTAMP(1, l, 0);
         const f32x4* wsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[l]);
+        const bool more = l - 1 >= 1;
+        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[more ? l - 1 : l]) + kHalf;
         if constexpr (MATH == 1) {
             if (a.gmax && tid == 0) {   // layer maximum of |G_l| over this graph -> global (order-independent)
                 float mm = 0.f;
@@ -1136,11 +1226,29 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 atomicMax(a.gmax + l, __builtin_bit_cast(unsigned, mm));
             }
         }
+        auto dmaS = [&](auto qq) {
+            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
+        };
+        auto dmaA = [&](auto qq) {
+            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+        };
+        if (!wactive) {      // a wave without rows only moves its weight pieces (own straight path, as in the forward kernel)
+            static_for<0, kDma>(dmaS);
+            wait_vmem();
+            lds_barrier();
+            static_for<0, kDma>(dmaA);
+            wait_vmem();
+            lds_barrier();
+            continue;
+        }
         f32x4 acc[NT], ag[NT];
+        if constexpr (MATH == 1) {
 #pragma unroll
-        for (int t = 0; t < NT; ++t) { acc[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ag[t] = acc[t]; }
+            for (int t = 0; t < NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         float rs = 1.f, rinv = 1.f, mx = 0.f;
-        const bool fastg = csr_lds && wactive;
         f32x4 tb[GatherLand<NT, MATH>::value][NT];
         if constexpr (MATH == 1) { mx = row_max4(frag_absmax<NT>(gx, 0.f)); row_scale(mx, rs, rinv); }
         // ---- phase S ----
@@ -1148,26 +1256,15 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
         const unsigned gcur_off = l < L - 1 ? rowoff_v : kOob;      // the top layer's G was stored ahead of the loop
         auto fillS = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
-            if (fastg) gather_gap<NT, Q, kGaps, MATH>(dbuf, nbr, ag, tb);
-            if constexpr (Q < kDma) {
-                const int p = dma_share<NT>(wave, Q);
-                if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
-            } else if constexpr (Q < kDma + NT) {
-                buf_store(gx[Q - kDma], gcur, gcur_off + 64 * (Q - kDma));
-            }
+            gather_gap<NT, Q, kGaps, MATH>(dbuf, nbr, ag, tb);
+            if constexpr (Q < kDma) dmaS(qq);
+            else if constexpr (Q < kDma + NT) buf_store(gx[Q - kDma], gcur, gcur_off + 64 * (Q - kDma));
         };
-        if (wactive) { contract_half_fill<NT, MATH>(wbuf + kHalf, lane, gx, acc, rs, fillS); static_for<kTail, kFill>(fillS); }
-        else static_for<0, kDma>(fillS);      // idle waves still move their weight pieces
-        if (wactive && rvalid) {
-            if (csr_lds) {
-                if (nbr.wlong) gather_lds<NT, XS>(dbuf, s_col, nbr.eb, nbr.ee, g, ag);
-            } else {
-                for (int e = a.rowptr_t[grow]; e < a.rowptr_t[grow + 1]; ++e) {
-                    const f32x4* dj = reinterpret_cast<const f32x4*>(dbuf + (a.col_t[e] - r0) * XS) + g;
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) ag[c] += dj[4 * c];
-                }
-            }
+        contract_half_fill<NT, MATH, MATH == 0>(wbuf + kHalf, lane, gx, acc, rs, fillS);
+        static_for<kTail, kFill>(fillS);
+        if (nbr.wlong) {      // (wave-uniform; pad rows: eb == ee)
+            if (csr_lds) gather_lds<NT, XS>(dbuf, s_col, nbr.eb, nbr.ee, g, ag);
+            else gather_global_tail<NT, XS>(dbuf, a.col_t, r0, cnt, e0 + nbr.eb, e0 + nbr.ee, g, ag);
         }
         QSTAMP(1, l, 1);
         wait_vmem();
@@ -1186,8 +1283,6 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             for (int t = 0; t < NT; ++t) acc[t] *= carry;
             rinv = rinva * (reinterpret_cast<const float*>(a.wpack + a.bias_off[l]) + HP)[1];
         }
-        const bool more = l - 1 >= 1;
-        const f32x4* nsrc = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[more ? l - 1 : l]) + kHalf;
         const __amdgpu_buffer_rsrc_t yr = slab_rsrc(a.acts + slab * (l - 1));
         f32x4 yl[NT];        // y_{l-1} rows for this iteration's closing mask
         auto fillA = [&](auto qq) {
@@ -1196,18 +1291,15 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
                 load_guard<MATH>();
                 yl[Q] = buf_load(yr, rowoff_v + 64 * Q);
             } else if constexpr (Q < NT + kDma) {
-                const int p = dma_share<NT>(wave, Q - NT);
-                if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+                dmaA(std::integral_constant<int, Q - NT>{});
             }
         };
-        if (wactive) { contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA); static_for<kTail, kFill>(fillA); }
-        else static_for<NT, NT + kDma>(fillA);
+        contract_half_fill<NT, MATH>(wbuf, lane, ag, acc, rsa, fillA);
+        static_for<kTail, kFill>(fillA);
         QSTAMP(1, l, 5);
-        if (wactive) {
 #pragma unroll
-            for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
-            mask_rows(l - 1, yl);
-        }
+        for (int t = 0; t < NT; ++t) gx[t] = MATH == 1 ? acc[t] * rinv : acc[t];
+        mask_rows(l - 1, yl);
         wait_vmem();
         QSTAMP(1, l, 6);
         lds_barrier();     // barrier 2: G_{l-1} rows + half B visible; half A free

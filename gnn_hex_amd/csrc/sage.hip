@@ -17,6 +17,7 @@
 #include "hexgnn_internal.h"
 #include "hexgnn_pack.h"
 #include "hexgnn_memops.h"
+#include "sage_dw_kernel.h"
 
 namespace hexgnn {
 
@@ -1172,142 +1173,7 @@ __global__ void sage_combine_kernel(int n, int hp, const int* __restrict__ rowpt
     reinterpret_cast<f32x4*>(out + (size_t)row * hp)[p] = v;
 }
 
-// ---- batched weight gradient: dW[o][i'] = sum_rows G[row][o] * [agg|x][row][i'], db[o] = sum_rows G[row][o] -----
-// grid (S slices, number of hidden-input layers); NT waves; wave w owns output channels 16w..16w+15.
-struct DwArgs {
-    const float* xin[kMaxLayers];
-    const float* agg[kMaxLayers];
-    const float* g[kMaxLayers];
-    int n, rows_per_slice, S;
-};
-
-// Waves per workgroup: for NT >= 4 one EXTRA wave owns the last two input-feature tiles for all NT output tiles, the NT
-// regular waves the other 2NT-2: 8 waves of 12|14 MFMAs per k-step load the four SIMDs 24/24/24/26 instead of 7 waves
-// of 14 loading them 28/28/28/14 (the fp32 MFMA pipe is the bound of this kernel).
-template <int NT> struct DwShape {
-    static constexpr bool kBal = NT >= 4;
-    static constexpr int kWaves = kBal ? NT + 1 : NT;
-    static constexpr int kRegB = kBal ? 2 * NT - 2 : 2 * NT;     // input-feature tiles of a regular wave
-};
-
-template <int NT>
-__global__ __launch_bounds__(64 * DwShape<NT>::kWaves) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
-    constexpr int HP = 16 * NT;
-#ifndef HEXGNN_DW_RH
-#define HEXGNN_DW_RH 16
-#endif
-    constexpr int RH = HEXGNN_DW_RH;                    // rows per chunk (a multiple of 4); two chunk buffers
-    constexpr int AS = 2 * HP + 16;                     // == 16 (mod 32): conflict-free fragment reads
-    constexpr int GS = (NT % 2 == 1) ? HP : HP + 16;
-    constexpr int NTHR = 64 * DwShape<NT>::kWaves;
-    constexpr int NB = DwShape<NT>::kRegB;
-    __shared__ __attribute__((aligned(16))) float As[2 * RH * AS];
-    __shared__ __attribute__((aligned(16))) float Gs[2 * RH * GS];
-    const int li = blockIdx.y, s = blockIdx.x;
-    const float* __restrict__ xin = a.xin[li];
-    const float* __restrict__ agg = a.agg[li];
-    const float* __restrict__ gg = a.g[li];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int m = lane & 15, kq = lane >> 4;
-    const bool extra = DwShape<NT>::kBal && w == NT;     // wave-uniform
-    const int r_beg = s * a.rows_per_slice;
-    const int r_end = min(a.n, r_beg + a.rows_per_slice);
-
-    f32x4 acc[2 * NT];       // regular wave: tile t < NB; extra wave: [2 * t + tb]
-#pragma unroll
-    for (int t = 0; t < 2 * NT; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float bsum = 0.f;
-
-    // Double-buffered RH-row chunks (two workgroups per CU as before), ONE barrier per chunk: the global loads of chunk i+2 are
-    // in flight and the LDS writes of chunk i+1 are issued ahead of chunk i's MFMAs and complete under them.  (Single-buffered
-    // 32-row chunks, two barriers each, left the pipe idle while a workgroup staged: 216 -> 210 us at RH = 16.)
-    constexpr int Q = NT * 4;
-    constexpr int kPer = (RH * Q + NTHR - 1) / NTHR;
-    f32x4 ra[kPer], rx[kPer], rg[kPer];
-    auto issue = [&](int rc) {
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int p = tid + NTHR * k;
-            const int rr = p / Q, q = p % Q;
-            const int row = rc + rr;
-            ra[k] = f32x4{0.f, 0.f, 0.f, 0.f}; rx[k] = ra[k]; rg[k] = ra[k];
-            if (p < RH * Q && row < r_end) {
-                ra[k] = reinterpret_cast<const f32x4*>(agg + (size_t)row * HP)[q];
-                rx[k] = reinterpret_cast<const f32x4*>(xin + (size_t)row * HP)[q];
-                rg[k] = reinterpret_cast<const f32x4*>(gg + (size_t)row * HP)[q];
-            }
-        }
-    };
-    auto stage = [&](int buf) {
-#pragma unroll
-        for (int k = 0; k < kPer; ++k) {
-            const int p = tid + NTHR * k;
-            if (p < RH * Q) {
-                const int rr = p / Q, q = p % Q;
-                *reinterpret_cast<f32x4*>(&As[(buf * RH + rr) * AS + 4 * q]) = ra[k];
-                *reinterpret_cast<f32x4*>(&As[(buf * RH + rr) * AS + HP + 4 * q]) = rx[k];
-                *reinterpret_cast<f32x4*>(&Gs[(buf * RH + rr) * GS + 4 * q]) = rg[k];
-            }
-        }
-    };
-    if (r_beg < r_end) {
-        issue(r_beg);
-        stage(0);
-        if (r_beg + RH < r_end) issue(r_beg + RH);
-    }
-    __syncthreads();
-    int buf = 0;
-    for (int rc = r_beg; rc < r_end; rc += RH, buf ^= 1) {
-        if (rc + RH < r_end) stage(buf ^ 1);                 // chunk i+1 -> the other buffer (its readers passed the last barrier)
-        if (rc + 2 * RH < r_end) issue(rc + 2 * RH);
-        const float* Ab = As + buf * RH * AS;
-        const float* Gb = Gs + buf * RH * GS;
-        if (!extra) {
-#pragma unroll
-            for (int ks = 0; ks < RH / 4; ++ks) {
-                const float av = Gb[(4 * ks + kq) * GS + 16 * w + m];
-                bsum += av;
-#pragma unroll
-                for (int t = 0; t < NB; ++t) {
-                    const float bv = Ab[(4 * ks + kq) * AS + 16 * t + m];
-                    acc[t] = mfma16x16x4(av, bv, acc[t]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < RH / 4; ++ks) {
-                const float bv0 = Ab[(4 * ks + kq) * AS + 16 * NB + m];
-                const float bv1 = Ab[(4 * ks + kq) * AS + 16 * (NB + 1) + m];
-#pragma unroll
-                for (int t = 0; t < NT; ++t) {
-                    const float av = Gb[(4 * ks + kq) * GS + 16 * t + m];
-                    acc[2 * t] = mfma16x16x4(av, bv0, acc[2 * t]);
-                    acc[2 * t + 1] = mfma16x16x4(av, bv1, acc[2 * t + 1]);
-                }
-            }
-        }
-        __syncthreads();
-    }
-    // slab [HP][2HP] then bias [HP]
-    float* slab = part + ((size_t)li * a.S + s) * ((size_t)HP * (2 * HP + 1));
-    if (!extra) {
-#pragma unroll
-        for (int t = 0; t < NB; ++t)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) slab[(size_t)(16 * w + 4 * kq + q) * (2 * HP) + 16 * t + m] = acc[t][q];
-        bsum += __shfl_xor(bsum, 16);
-        bsum += __shfl_xor(bsum, 32);
-        if (kq == 0) slab[(size_t)HP * 2 * HP + 16 * w + m] = bsum;
-    } else {
-#pragma unroll
-        for (int t = 0; t < NT; ++t)
-#pragma unroll
-            for (int tb = 0; tb < 2; ++tb)
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    slab[(size_t)(16 * t + 4 * kq + q) * (2 * HP) + 16 * (NB + tb) + m] = acc[2 * t + tb][q];
-    }
-}
+// ---- batched weight gradient (exact fp32): sage_dw_kernel.h -----------------------------------------------
 
 // ---- the same batched weight gradient in split precision ("f16x3", math 1) ---------------------------------
 // The contraction runs over ROWS, so both MFMA operands need 8 consecutive rows of one column per lane.  Every thread
