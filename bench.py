@@ -182,6 +182,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one all-reduce after the backward instead of the staged backward whose first gradient "
                          "segment is reduced while the rest of the weight-gradient GEMM computes")
+    ap.add_argument("--no-td-step", action="store_true",
+                    help="issue the step as model(...), ops.td_loss, ops.backward (three calls, a TD-loss launch between the "
+                         "network's two) instead of ops.td_step, which forms the same loss in the forward kernel's tail")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective-probe", action="store_true",
                     help="N = 1: skip the 1-rank RCCL all-reduce latency probe of the gradient bucket (config.collective)")
@@ -255,14 +258,19 @@ def main():
     gfactor = 1 if strong else world          # graphs per step over all ranks = B * gfactor
 
     plist = list(hip.parameters())
+    td_fused = not args.no_td_step and not overlap
 
     def step(i):
         bt = batches[i & 1]
         for p in plist:              # optimizer.zero_grad(set_to_none=True) over a cached parameter list
             p.grad = None
-        q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
-        loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"], bt["w"])
-        hexops.backward(loss)       # == loss.backward(), minus autograd's ones-fill and the TD scatter launch (ops.backward)
+        if td_fused:
+            # the same three calls in their fused form (ops.td_step: the loss is formed in the forward kernel's tail)
+            hexops.td_step(hip, bt["x"], bt["ei"], bt["bv"], bt["ptr"], sel=bt["sel"], target=bt["tgt"], weights=bt["w"])
+        else:
+            q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
+            loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"], bt["w"])
+            hexops.backward(loss)   # == loss.backward(), minus autograd's ones-fill and the TD scatter launch (ops.backward)
         if world > 1:
             sync.all_reduce()
 
@@ -273,6 +281,9 @@ def main():
             def fn():
                 for p in plist:
                     p.grad = None
+                if td_fused:
+                    return hexops.td_step(hip, bt["x"], bt["ei"], bt["bv"], bt["ptr"], sel=bt["sel"], target=bt["tgt"],
+                                          weights=bt["w"])[0]
                 q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
                 loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"], bt["w"])
                 hexops.backward(loss)
@@ -485,7 +496,9 @@ def main():
                                    % (label, "start-position" if args.data == "D0" else "random-playout",
                                       batches[0]["graphs"], batches[0]["n"], batches[0]["e"]),
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * gfactor,
-                       "graphs_per_gpu": batches[0]["graphs"]},
+                       "graphs_per_gpu": batches[0]["graphs"],
+                       "step_issue": "ops.td_step (model forward, TD loss in its tail, backward)" if td_fused else
+                                     "model(...), ops.td_loss, ops.backward"},
             "roofline": roof, "cpu_baseline": cpu, "split_precision_mode": split, "other_configs": others,
         }
         if probe is not None:

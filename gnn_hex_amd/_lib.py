@@ -15,7 +15,7 @@ import torch  # noqa: F401  (must precede CDLL, see module docstring)
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhexgnn.so")
 _lib = None
-ABI_VERSION = 5          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
+ABI_VERSION = 6          # HEXGNN_ABI_VERSION of include/hexgnn.h this binding was written against
 
 vp = C.c_void_p
 ci = C.c_int
@@ -75,6 +75,10 @@ _SIGS = {
                                          vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, sz, vp, ci, ci, ci, vp]),
     "hexgnn_qnet_backward_flat": (ci, [ci, ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp,
                                        vp, vp, vp, vp, vp, sz, vp, ci, ci, ci, vp]),
+    "hexgnn_qnet_forward_td": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,
+                                    vp, vp, vp, vp, vp, ci, vp, vp, vp, vp]),
+    "hexgnn_qnet_backward_flat_td": (ci, [ci, ci, ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp,
+                                          vp, vp, sz, vp, ci, ci, ci, vp, vp, vp]),
     "hexgnn_env_create": (ci, [ci, ci, vp]),
     "hexgnn_env_destroy": (None, [vp]),
     "hexgnn_env_num_vertices": (ci, [vp]),

@@ -42,6 +42,9 @@ struct GradReduceArgs {
     const float* dz; const float* dvr; const float* pooled; const float* z;
     float* d_v0_w; float* d_v0_b; float* d_v1_w; float* d_v1_b;
     int n0, n1, n2, n3, nbx3;
+    // R4 (one block, hexgnn_qnet_backward_flat_td): loss = (sum over the b graphs of loss_part) / b, in td_loss_fwd_kernel's
+    // reduction shape (thread t sums entries t, t + 256, ...; tree over the 256 threads): its bits
+    const float* loss_part; float* loss;
 };
 
 __device__ __forceinline__ float wsum_all(float v) {
@@ -55,6 +58,19 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(GradReduceArgs a)
     int blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, hp = a.hp;
+    if (blk == a.n0 + a.n1 + a.n2 + a.n3) {      // ---- R4: the TD loss's mean over the graphs
+        __shared__ float lred[256];
+        float acc = 0.f;
+        for (int j = tid; j < a.b; j += 256) acc += a.loss_part[j];
+        lred[tid] = acc;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) lred[tid] += lred[tid + o];
+            __syncthreads();
+        }
+        if (tid == 0) a.loss[0] = lred[0] / (float)(a.b > 0 ? a.b : 1);
+        return;
+    }
     if (blk < a.n0) {                     // ---- R0: slice slabs -> dW_l / dW_r / db of one hidden layer
         // one thread per float4 of the [hp][2hp] slab (+ the bias row), S independent 16-byte loads in flight
         const int li = blk / a.blk_per_layer, idx = (blk % a.blk_per_layer) * 256 + tid;
@@ -187,13 +203,14 @@ size_t hexgnn_qnet_saved_bytes(int n, int b, int c_in, int hidden, int total_lay
     return q.saved_total;
 }
 
-int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,
-                        const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
-                        const float* const* wl, const float* const* bl, const float* const* wr,
-                        const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
-                        const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
-                        int need_backward, int acts_layer, int math, float* q, float* out_v, int* status,
-                        hexgnn_stream_t stream_) {
+static int qnet_forward_impl(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,
+                             const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
+                             const float* const* wl, const float* const* bl, const float* const* wr,
+                             const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
+                             const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
+                             int need_backward, int acts_layer, int math, float* q, float* out_v, int* status,
+                             const int64_t* td_sel, const float* td_target, const float* td_weights, int td_loss_fn,
+                             float* td_dq, float* td_out, float* td_loss_part, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 0 || b < 0 || mode < 0 || mode > 2 || math < 0 || math > 1) return HEXGNN_EINVAL;
     QPlan qp;
@@ -228,6 +245,8 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     a.z = (float*)(hsv + qp.hs.z_off); a.vraw = (float*)(hsv + qp.hs.v_off);
     a.q = q; a.out_v = out_v; a.status = status;
     a.xmax = maxima;
+    a.td_sel = (const long long*)td_sel; a.td_tgt = td_target; a.td_w = td_weights; a.td_loss_fn = td_loss_fn;
+    a.td_dq = td_dq; a.td_out = td_out; a.td_loss_part = td_loss_part;
     {
         KernelTimer kt(HEXGNN_K_QNET_FWD, st);
         rc = launch_qfwd_math(qp.sp.nt, math, a, st);
@@ -236,20 +255,47 @@ int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, in
     return check_launch();
 }
 
+int hexgnn_qnet_forward(int n, int b, int c_in, int hidden, int total_layers, int mode, const int* gptr,
+                        const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
+                        const float* const* wl, const float* const* bl, const float* const* wr,
+                        const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
+                        const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
+                        int need_backward, int acts_layer, int math, float* q, float* out_v, int* status,
+                        hexgnn_stream_t stream_) {
+    return qnet_forward_impl(n, b, c_in, hidden, total_layers, mode, gptr, rowptr, col, invdeg, x, x_stride, wl, bl, wr, lin_w,
+                             lin_b, v0_w, v0_b, v1_w, v1_b, wpack, acts, saved, need_backward, acts_layer, math, q, out_v,
+                             status, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, stream_);
+}
+
+int hexgnn_qnet_forward_td(int n, int b, int c_in, int hidden, int total_layers, const int* gptr,
+                           const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
+                           const float* const* wl, const float* const* bl, const float* const* wr,
+                           const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
+                           const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
+                           int math, float* q, int* status, const int64_t* sel, const float* target,
+                           const float* weights, int loss_fn, float* dq, float* td, float* loss_part,
+                           hexgnn_stream_t stream_) {
+    if (!sel || !target || !dq || !td || !loss_part || loss_fn < 0 || loss_fn > 1) return HEXGNN_EINVAL;
+    return qnet_forward_impl(n, b, c_in, hidden, total_layers, 0, gptr, rowptr, col, invdeg, x, x_stride, wl, bl, wr, lin_w,
+                             lin_b, v0_w, v0_b, v1_w, v1_b, wpack, acts, saved, 1, -1, math, q, nullptr, status, sel, target,
+                             weights, loss_fn, dq, td, loss_part, stream_);
+}
+
 size_t hexgnn_qnet_backward_workspace_bytes(int n, int b, int c_in, int hidden, int total_layers) {
     QPlan q;
     if (n < 0 || b < 0 || make_qplan(n, b, c_in, hidden, total_layers, &q) != HEXGNN_OK) return 0;
     return q.ws_total;
 }
 
-int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+static int qnet_backward_staged_impl(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
                                 const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
                                 const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
                                 const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
                                 const float* d_out_v, float* d_embeds, float* const* d_wl, float* const* d_bl,
                                 float* const* d_wr, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b,
                                 float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
-                                int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream_) {
+                                int stages, int layer_lo, int layer_hi, const float* loss_part, float* loss,
+                                hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     if (n < 0 || b < 0 || mode < 0 || mode > 2 || math < 0 || math > 1 || body_layers < 1 || body_layers > total_layers)
         return HEXGNN_EINVAL;
@@ -335,13 +381,29 @@ int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_la
         r.n2 = st_small ? (hidden + 1 + 3) / 4 : 0;
         r.nbx3 = (4 * hidden + 63) / 64;
         r.n3 = (st_small && mode != 2 && hidden / 2 > 0) ? r.nbx3 * (hidden / 2) : 0;
-        if (r.n0 + r.n1 + r.n2 + r.n3 > 0) qnet_grad_reduce_kernel<<<r.n0 + r.n1 + r.n2 + r.n3, 256, 0, st>>>(r);
+        r.loss_part = loss_part; r.loss = loss;
+        const int n4 = (st_small && loss_part && loss) ? 1 : 0;      // (the block behind the last role: the TD loss's mean)
+        if (r.n0 + r.n1 + r.n2 + r.n3 + n4 > 0) qnet_grad_reduce_kernel<<<r.n0 + r.n1 + r.n2 + r.n3 + n4, 256, 0, st>>>(r);
     } else if (st_small) {
         launch_head_param_grads(b, hidden, mode, a.dz, a.dvr, (const float*)(hsv + qp.hs.pooled_off),
                                 (const float*)(hsv + qp.hs.z_off), a.lin_part, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w,
                                 d_v1_b, st);
     }
     return check_launch();
+}
+
+int hexgnn_qnet_backward_staged(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
+                                const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                                const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
+                                const float* d_out_v, float* d_embeds, float* const* d_wl, float* const* d_bl,
+                                float* const* d_wr, float* d_lin_w, float* d_lin_b, float* d_v0_w, float* d_v0_b,
+                                float* d_v1_w, float* d_v1_b, void* workspace, size_t workspace_bytes, int* status,
+                                int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream_) {
+    return qnet_backward_staged_impl(n, b, c_in, hidden, total_layers, body_layers, mode, math, gptr, rowptr_t, col_t, invdeg,
+                                     x, x_stride, acts, saved, wpack, lin_w, v0_w, v1_w, dq, d_out_v, d_embeds, d_wl, d_bl,
+                                     d_wr, d_lin_w, d_lin_b, d_v0_w, d_v0_b, d_v1_w, d_v1_b, workspace, workspace_bytes,
+                                     status, stages, layer_lo, layer_hi, nullptr, nullptr, stream_);
 }
 
 int hexgnn_qnet_backward(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int mode, int math,
@@ -378,6 +440,26 @@ int hexgnn_qnet_backward_flat(int n, int b, int c_in, int hidden, int total_laye
                                        d_wl, d_bl, d_wr, flat + t[0], flat + t[1], vh ? flat + t[2] : nullptr,
                                        vh ? flat + t[3] : nullptr, vh ? flat + t[4] : nullptr, vh ? flat + t[5] : nullptr,
                                        workspace, workspace_bytes, status, stages, layer_lo, layer_hi, stream_);
+}
+
+int hexgnn_qnet_backward_flat_td(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int math,
+                                 const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                 const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                                 const float* lin_w, const float* v0_w, const float* v1_w, const float* dq,
+                                 float* d_embeds, float* flat, const int64_t* offsets, void* workspace,
+                                 size_t workspace_bytes, int* status, int stages, int layer_lo, int layer_hi,
+                                 const float* loss_part, float* loss, hexgnn_stream_t stream_) {
+    if (!flat || !offsets || total_layers < 1 || total_layers > kMaxLayers || !loss_part || !loss) return HEXGNN_EINVAL;
+    float* d_wl[kMaxLayers]; float* d_bl[kMaxLayers]; float* d_wr[kMaxLayers];
+    for (int l = 0; l < total_layers; ++l) {
+        d_wl[l] = flat + offsets[3 * l]; d_bl[l] = flat + offsets[3 * l + 1]; d_wr[l] = flat + offsets[3 * l + 2];
+    }
+    const int64_t* t = offsets + 3 * total_layers;      // lin_w, lin_b, v0_w, v0_b, v1_w, v1_b
+    return qnet_backward_staged_impl(n, b, c_in, hidden, total_layers, body_layers, 0, math, gptr, rowptr_t, col_t, invdeg, x,
+                                     x_stride, acts, saved, wpack, lin_w, v0_w, v1_w, dq, nullptr, d_embeds, d_wl, d_bl,
+                                     d_wr, flat + t[0], flat + t[1], flat + t[2], flat + t[3], flat + t[4], flat + t[5],
+                                     workspace, workspace_bytes, status, stages, layer_lo, layer_hi, loss_part, loss,
+                                     stream_);
 }
 
 #ifdef HEXGNN_STAMPS

@@ -46,6 +46,10 @@ struct QFwdArgs {
     float* q; float* out_v; int* status;
     unsigned* xmax;   // [L] bit patterns of max |[agg|x]| per layer (math 1 + need_backward: feeds the f16 dW scales)
     int acts_layer;   // inference (need_backward == 0): store only this layer's activations (-1: every layer's)
+    // TD loss of the DQN update folded into the tail (mode 0, hexgnn_qnet_forward_td): graph g's selected node td_sel[g] (a
+    // global row of THAT graph), target and importance weight -> td error, the graph's loss term, d loss / d Q of its rows
+    const long long* td_sel; const float* td_tgt; const float* td_w; int td_loss_fn;
+    float* td_dq; float* td_out; float* td_loss_part;
 };
 
 struct QBwdArgs {
@@ -561,8 +565,15 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     if (cnt > kRows) {
         // a graph that does not fit the tile reached this kernel (stale size hint): flag it AND poison its outputs, so
         // the failure is visible in the data even if nobody reads the status word
-        if (tid == 0) { atomicOr(a.status, 2); if (a.out_v) a.out_v[gi] = __builtin_nanf(""); }
-        for (int i = tid; i < cnt; i += 512) a.q[r0 + i] = __builtin_nanf("");
+        if (tid == 0) {
+            atomicOr(a.status, 2);
+            if (a.out_v) a.out_v[gi] = __builtin_nanf("");
+            if (a.td_sel && a.mode == 0) { a.td_out[gi] = __builtin_nanf(""); a.td_loss_part[gi] = __builtin_nanf(""); }
+        }
+        for (int i = tid; i < cnt; i += 512) {
+            a.q[r0 + i] = __builtin_nanf("");
+            if (a.td_sel && a.mode == 0) a.td_dq[r0 + i] = __builtin_nanf("");
+        }
         return;
     }
     const int H = a.H;
@@ -855,6 +866,10 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const float v0b_k = (a.mode != 2 && vk_ < H2) ? a.v0_b[vk_] : 0.f;
     const float v1w_l = (a.mode != 2 && wave == 0 && lane < H2) ? a.v1_w[lane] : 0.f;
     const float v1b_0 = a.mode != 2 ? a.v1_b[0] : 0.f;
+    const bool td_on = a.td_sel != nullptr && a.mode == 0;
+    const long long td_s = td_on ? a.td_sel[gi] : -1;
+    const float td_t = td_on ? a.td_tgt[gi] : 0.f;
+    const float td_wg = (td_on && a.td_w) ? a.td_w[gi] : 1.f;
     __syncthreads();
     // advantages from the registers: partial dot over this lane's chunks, reduce over the 4 lanes of the row
     float adv = 0.f;
@@ -960,7 +975,29 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const float mean_adv = adv_total / (float)max(cnt, 1);
     const float V = s_misc[0];
     if (a.mode == 1 && tid == 0) a.out_v[gi] = V;
-    if (g == 0 && rvalid) a.q[grow] = (a.mode == 0 ? V : 0.f) + tadv - mean_adv;
+    const float qv = (a.mode == 0 ? V : 0.f) + tadv - mean_adv;
+    if (g == 0 && rvalid) a.q[grow] = qv;
+    if (td_on) {
+        // loss = mean_g w_g l(Q[sel_g] - target_g): the same per-entry expressions as td_loss_fused_kernel (head.hip), so dq
+        // and td have its bits; the mean over the graphs is summed from td_loss_part by the backward's reduce launch
+        if (g == 0 && rvalid) {
+            float d = 0.f;
+            if ((long long)grow == td_s) {
+                const float e = qv - td_t, ae = fabsf(e);
+                a.td_out[gi] = e;
+                a.td_loss_part[gi] = td_wg * (a.td_loss_fn == 0 ? e * e : (ae <= 1.f ? 0.5f * e * e : ae - 0.5f));
+                const float dl = a.td_loss_fn == 0 ? 2.f * e : fminf(fmaxf(e, -1.f), 1.f);
+                d = (1.f / (float)a.b) * td_wg * dl;
+            }
+            a.td_dq[grow] = d;
+        }
+        if (tid == 0 && (td_s < (long long)r0 || td_s >= (long long)r1)) {
+            // the selected node is not a row of this graph (contract of the fused form): flag AND poison
+            atomicOr(a.status, 16);
+            a.td_out[gi] = __builtin_nanf("");
+            a.td_loss_part[gi] = __builtin_nanf("");
+        }
+    }
     QSTAMP(0, 0, 2);
 }
 

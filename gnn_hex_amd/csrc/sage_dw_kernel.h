@@ -98,7 +98,6 @@ __global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_ker
         loffG[k] = rr * GS + 4 * q;
     }
     f32x4 ra[kPer], rx[kPer], rg[kPer];
-    typedef unsigned u32x4d __attribute__((ext_vector_type(4)));
     auto issue = [&](int rc) {
         const unsigned base = (unsigned)rc * (HP * 4);
 #pragma unroll

@@ -7,6 +7,7 @@ runs in the hand-written kernels under gnn_hex_amd/csrc; there is no eager/PyTor
 from __future__ import annotations
 
 import ctypes as C
+import threading
 from typing import List, Optional, Sequence
 
 import torch
@@ -196,7 +197,7 @@ class GraphStructure:
                 self.status.zero_()
             raise IndexError("invalid batch structure (status=%d): 1 = node id outside [0,n), 2 = graph larger than "
                              "128 nodes reached the fused kernel, 4 = an edge connects two graphs (or a batch passed as grouped is "
-                             "not), 8 = graph above 2048 nodes in the grouped build.  This batch has n = %d; the word is shared "
+                             "not), 8 = graph above 2048 nodes in the grouped build, 16 = td_step: a selected node outside its graph.  This batch has n = %d; the word is shared "
                              "by every batch of this device since the last check(), so the error may stem from an EARLIER "
                              "batch (it is cleared now)" % (code, self.n))
 
@@ -988,7 +989,7 @@ class QNetParamCache:
 
 class _QNetCall:
     """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
-    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered")
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered", "td")
 
 
 _HP_CACHE = {}
@@ -1038,10 +1039,26 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
               gptr.data_ptr(), gs.status.data_ptr())
     t = cache.tail
     stream = _stream()
-    _lib.check(L.hexgnn_qnet_forward(
-        n, b, c_in, hidden, tot, mode, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl, wr,
-        t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), body_layers - 1,
-        _MATH, q.data_ptr(), out_v.data_ptr() if out_v is not None else None, gp[6], stream), "hexgnn_qnet_forward")
+    td = None
+    tda = getattr(_TD_STEP, "args", None)
+    if tda is not None and mode == 0 and need_bwd and b > 0 and n > 0:
+        # td_step(): the update's loss is formed in the forward kernel's tail (one selected node per graph)
+        sel, tgt, w, lfn = tda
+        if sel.numel() == b:
+            # one buffer: dq [n] | td [b] | loss terms [b] | loss [1]
+            tb = torch.empty(n + 2 * b + 1, dtype=torch.float32, device=dev)
+            tp = tb.data_ptr()
+            _lib.check(L.hexgnn_qnet_forward_td(
+                n, b, c_in, hidden, tot, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl, wr,
+                t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes, _MATH, q.data_ptr(), gp[6],
+                sel.data_ptr(), tgt.data_ptr(), w.data_ptr() if w is not None else None, lfn, tp, tp + 4 * n,
+                tp + 4 * (n + b), stream), "hexgnn_qnet_forward_td")
+            td = (tb, n, b)
+    if td is None:
+        _lib.check(L.hexgnn_qnet_forward(
+            n, b, c_in, hidden, tot, mode, gp[5], gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl, wr,
+            t[0], t[1], t[2], t[3], t[4], t[5], base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), body_layers - 1,
+            _MATH, q.data_ptr(), out_v.data_ptr() if out_v is not None else None, gp[6], stream), "hexgnn_qnet_forward")
     call = _QNetCall()
     call.cache, call.gs, call.gptr, call.x = cache, gs, gptr, x
     call.dims = (n, b, c_in, hidden, tot, body_layers, mode, hp, x_stride, a_bytes, w_bytes, ws_bytes)
@@ -1049,6 +1066,7 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     call.sink = None
     call.done = False
     call.layered = False
+    call.td = td
     return q, out_v, call
 
 
@@ -1107,6 +1125,7 @@ def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: 
     call.sink = None
     call.done = False
     call.layered = True
+    call.td = None
     return q, out_v, call
 
 
@@ -1223,7 +1242,23 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
               d_v.data_ptr() if d_v is not None else None, d_emb.data_ptr() if d_emb is not None else None,
               flat.data_ptr(), cache.offsets, ws.data_ptr(), ws_bytes, gp[6])
     hook = _GRAD_STAGE_HOOK
-    if hook is None or tot < 3 or mode == 2:
+    td = call.td
+    if td is not None and dq.data_ptr() == td[0].data_ptr():
+        # td_step(): d loss / d Q came from the forward launch; the reduce launch also writes the loss (mean of the graphs' terms)
+        tb, tn, tbb = td
+        tp = tb.data_ptr()
+        ctd = common[:6] + common[7:21] + common[22:]          # (no mode, no d_out_v: mode 0)
+        if hook is None or tot < 3:
+            _lib.check(L.hexgnn_qnet_backward_flat_td(*ctd, 7, 1, tot, tp + 4 * (tn + tbb), tp + 4 * (tn + 2 * tbb), _stream()),
+                       "hexgnn_qnet_backward_flat_td")
+        else:
+            mid, cut = 1 + tot // 2, cache.cut
+            _lib.check(L.hexgnn_qnet_backward_flat_td(*ctd, 7, mid, tot, tp + 4 * (tn + tbb), tp + 4 * (tn + 2 * tbb), _stream()),
+                       "hexgnn_qnet_backward_flat_td")
+            hook(flat, cut, cache.total)
+            _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
+            hook(flat, 0, cut)
+    elif hook is None or tot < 3 or mode == 2:
         _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, 1, tot, _stream()), "hexgnn_qnet_backward_flat")
     else:
         mid, cut = 1 + tot // 2, cache.cut
@@ -1353,6 +1388,50 @@ def backward(loss: torch.Tensor) -> None:
         torch.autograd.backward((loss,), (one,))
     finally:
         _UNIT_GRAD = False
+
+
+_TD_STEP = threading.local()      # .args = (sel, target, weights, loss_fn) while td_step() runs the model's forward
+
+
+def td_step(model, x: torch.Tensor, edge_index, graph_indices=None, ptr=None, *, sel: torch.Tensor, target: torch.Tensor,
+            weights: Optional[torch.Tensor] = None, loss_fn: str = "mse"):
+    """One DQN update on a batch in its fused form: ``q = model(x, edge_index, graph_indices, ptr)``,
+    ``loss, td = td_loss(q, sel, target, weights, loss_fn)``, ``backward(loss)`` -- returns ``(loss, td, q)`` with every
+    parameter's ``.grad`` set, same values as those three calls (``td`` and the gradients bit-identical).
+
+    When the update selects ONE node per graph, ``sel[g]`` a node of graph g (the action of the sampled transition: what the
+    RainbowDQN step gathers, README.md:5,7) and the batch runs on the fused per-graph kernels, the loss is graph-local and the
+    forward kernel forms it in its tail: no launch between the network's forward and backward, ``loss`` is written by the
+    backward's reduce launch (``hexgnn_qnet_forward_td`` / ``hexgnn_qnet_backward_flat_td``).  A ``sel[g]`` outside graph g
+    makes ``loss`` / ``td[g]`` NaN and raises at the next ``GraphStructure.check()`` (status 16).  Anything else (several
+    selections per graph, graphs above 128 nodes, frozen parameters, ``--noisy_dqn``) runs the three calls."""
+    if not x.is_cuda:
+        raise _lib.HexGnnError("td_step runs only on the MI355X HIP path (no CPU fallback)")
+    dev = x.device
+    if sel.dtype != torch.long or sel.device != dev or not sel.is_contiguous():
+        sel = sel.to(device=dev, dtype=torch.long).contiguous()
+    if target.dtype != torch.float32 or target.device != dev or not target.is_contiguous():
+        target = target.to(device=dev, dtype=torch.float32).contiguous()
+    if weights is not None and (weights.dtype != torch.float32 or weights.device != dev or not weights.is_contiguous()):
+        weights = weights.to(device=dev, dtype=torch.float32).contiguous()
+    if target.numel() != sel.numel() or (weights is not None and weights.numel() != sel.numel()):
+        raise ValueError("sel / target / weights must have the same length")
+    lfn = {"mse": 0, "huber": 1}[loss_fn]
+    _TD_STEP.args = (sel, target, weights, lfn)
+    try:
+        q = model(x, edge_index, graph_indices, ptr)
+    finally:
+        _TD_STEP.args = None
+    call = getattr(q, "_hex_call", None)
+    td = call.td if call is not None else None
+    if td is None:
+        loss, tde = td_loss(q, sel, target, weights, loss_fn)
+        backward(loss)
+        return loss, tde, q
+    tb, n, b = td
+    qnet_direct_backward(call, tb[:n], None)
+    call.done = True
+    return tb[n + 2 * b], tb[n:n + b], q
 
 
 def greedy_nodes(q: torch.Tensor, ptr: torch.Tensor) -> torch.Tensor:

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define HEXGNN_ABI_VERSION 5
+#define HEXGNN_ABI_VERSION 6
 
 #define HEXGNN_OK 0
 #define HEXGNN_EINVAL (-1)       /* bad argument (null pointer, negative size, ...) */
@@ -337,6 +337,33 @@ int hexgnn_qnet_backward_flat(int n, int b, int c_in, int hidden, int total_laye
                               float* flat, const int64_t* offsets /* HOST */,
                               void* workspace, size_t workspace_bytes, int* status,
                               int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream);
+
+/* The DQN update's loss folded into the network calls (ABI 6): `loss = loss_fn(Q[sel], target)` of the RainbowDQN training step
+ * (README.md:5,7: --loss_fn=mse, --prioritized_er=True importance weights; the step of SURVEY.md 8d) is graph-local when the
+ * update selects ONE node per graph, sel[g] a row of graph g (the action taken in the sampled transition), so the forward
+ * kernel's tail forms it for its own graph: td[g] = Q[sel[g]] - target[g], loss_part[g] = weights[g] * l(td[g]) and
+ * dq = d loss / d Q ([n], zero except at the selected rows) -- no hexgnn_td_loss_forward_backward launch between the two
+ * network launches.  Same per-entry expressions as that launch (bit-identical td and dq).  A sel[g] outside graph g sets
+ * status |= 16 and poisons td[g] / loss_part[g] with NaN.  mode 0, need_backward 1; loss_fn 0 = mse, 1 = Huber(1).
+ * hexgnn_qnet_backward_flat_td is hexgnn_qnet_backward_flat (mode 0) whose reduce launch also writes
+ * loss[0] = sum(loss_part) / b in hexgnn_td_loss_forward's reduction shape (its bits), when stages has HEXGNN_QBWD_SMALL. */
+int hexgnn_qnet_forward_td(int n, int b, int c_in, int hidden, int total_layers, const int* gptr,
+                           const int* rowptr, const int* col, const float* invdeg, const float* x, int x_stride,
+                           const float* const* wl, const float* const* bl, const float* const* wr,
+                           const float* lin_w, const float* lin_b, const float* v0_w, const float* v0_b,
+                           const float* v1_w, const float* v1_b, void* wpack, float* acts, void* saved,
+                           int math, float* q /*[n]*/, int* status,
+                           const int64_t* sel /*[b]*/, const float* target /*[b]*/, const float* weights /*[b] or NULL*/,
+                           int loss_fn, float* dq /*[n]*/, float* td /*[b]*/, float* loss_part /*[b]*/,
+                           hexgnn_stream_t stream);
+int hexgnn_qnet_backward_flat_td(int n, int b, int c_in, int hidden, int total_layers, int body_layers, int math,
+                                 const int* gptr, const int* rowptr_t, const int* col_t, const float* invdeg,
+                                 const float* x, int x_stride, const float* acts, const void* saved, const void* wpack,
+                                 const float* lin_w, const float* v0_w, const float* v1_w,
+                                 const float* dq, float* d_embeds, float* flat, const int64_t* offsets /* HOST */,
+                                 void* workspace, size_t workspace_bytes, int* status,
+                                 int stages, int layer_lo, int layer_hi,
+                                 const float* loss_part /*[b]*/, float* loss /*[1]*/, hexgnn_stream_t stream);
 
 /* ---- batched board-graph builder: num_envs lock-stepped Hex / Shannon node-switching games on the device.
  *      Replaces Hex_game / Node_switching_game (graph_game/graph_tools_games.py:20-29,

@@ -22,7 +22,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(raw, name), "libhexgnn.so does not export %s" % name
     assert set(declared) == set(_lib.exported_symbols()), "ctypes signature table out of sync with the header"
-    assert L.hexgnn_abi_version() == _lib.ABI_VERSION == 5
+    assert L.hexgnn_abi_version() == _lib.ABI_VERSION == 6
     assert L.hexgnn_padded_width(110) == 112 and L.hexgnn_padded_width(35) == 48 and L.hexgnn_padded_width(129) == 144
     assert L.hexgnn_padded_width(256) == 256 and L.hexgnn_padded_width(257) < 0
     assert L.hexgnn_strerror(-3).decode() == "workspace too small"
