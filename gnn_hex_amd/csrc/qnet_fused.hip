@@ -36,7 +36,7 @@ int launch_qbwd_math(int nt, int math, const QBwdArgs& a, hipStream_t st) {
 // Every sum has a fixed shape => bit-reproducible.  Replaces five launches of the layered path.
 struct GradReduceArgs {
     float* dwl[kMaxLayers]; float* dbl[kMaxLayers]; float* dwr[kMaxLayers];   // hidden layers (index = hidden layer)
-    const float* part; int S, hp, H, nh, blk_per_layer;
+    const float* part; int S, hp, H, nh, blk_per_layer, per;
     const float* first_part; int b, c_in; float* dwl0; float* dbl0; float* dwr0;
     const float* lin_part; float* d_lin_w; float* d_lin_b;
     const float* dz; const float* dvr; const float* pooled; const float* z;
@@ -73,9 +73,11 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(GradReduceArgs a)
     }
     if (blk < a.n0) {                     // ---- R0: slice slabs -> dW_l / dW_r / db of one hidden layer
         // one thread per float4 of the [hp][2hp] slab (+ the bias row), S independent 16-byte loads in flight
-        const int li = blk / a.blk_per_layer, idx = (blk % a.blk_per_layer) * 256 + tid;
+        // (blk_per_layer x hidden layers ~ two workgroups per CU, every one with the same share `per` of the slab: 400 blocks
+        // of 256 float4 left 144 CUs with twice the bytes of the other 112, and the kernel is bound by bytes per CU)
+        const int li = blk / a.blk_per_layer, idx = (blk % a.blk_per_layer) * a.per + tid;
         const int q_row = 2 * hp / 4, q_w = hp * q_row, q_all = q_w + hp / 4;
-        if (idx >= q_all) return;
+        if (tid >= a.per || idx >= q_all) return;
         const size_t slab_sz = (size_t)hp * (2 * hp + 1);
         const f32x4* p = reinterpret_cast<const f32x4*>(a.part + (size_t)li * a.S * slab_sz) + idx;   // slab_sz % 4 == 0
         f32x4 sum = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -371,7 +373,14 @@ static int qnet_backward_staged_impl(int n, int b, int c_in, int hidden, int tot
         GradReduceArgs r;
         for (int i = 0; i < nh; ++i) { r.dwl[i] = d_wl[lo + i]; r.dbl[i] = d_bl[lo + i]; r.dwr[i] = d_wr[lo + i]; }
         r.part = spart; r.S = dw_slices_for(n, nh, math, qp.sp.L - (qp.sp.small_first ? 1 : 0)); r.hp = qp.sp.hp; r.H = hidden; r.nh = nh;
-        r.blk_per_layer = (qp.sp.hp * (2 * qp.sp.hp + 1) / 4 + 255) / 256;      // one thread per float4 of a slab
+        {   // one thread per float4 of a slab; blocks per layer so that all layers together make ~512 equal blocks
+            const int q_all = qp.sp.hp * (2 * qp.sp.hp + 1) / 4;
+            int bpl = (q_all + 255) / 256;
+            if (nh > 0 && bpl * nh < 512) bpl = (512 + nh - 1) / nh;
+            if (bpl > (q_all + 31) / 32) bpl = (q_all + 31) / 32;
+            r.blk_per_layer = bpl;
+            r.per = (q_all + bpl - 1) / bpl;
+        }
         r.first_part = a.first_part; r.b = b; r.c_in = c_in; r.dwl0 = d_wl[0]; r.dbl0 = d_bl[0]; r.dwr0 = d_wr[0];
         r.lin_part = a.lin_part; r.d_lin_w = d_lin_w; r.d_lin_b = d_lin_b;
         r.dz = a.dz; r.dvr = a.dvr; r.pooled = (const float*)(hsv + qp.hs.pooled_off); r.z = (const float*)(hsv + qp.hs.z_off);

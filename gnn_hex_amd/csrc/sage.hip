@@ -11,6 +11,7 @@
 // its row r, the feature chunks {16c+4g .. 16c+4g+3} of every in-neighbour straight into registers; these
 // four floats are the k-slices of four consecutive v_mfma_f32_16x16x4_f32 (the K order is permuted
 // consistently on the packed-weight side).  fp32 in / fp32 accumulate: exact fmaf chains, deterministic.
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -697,7 +698,8 @@ struct StackKArgs {
     float* tap_out;
     unsigned* flags;                   // [blocks] progress counters, zero at launch
     int* status;
-};
+    unsigned skew;                     // test aid (HEXGNN_STACK_SKEW): != 0 delays every block by a pseudo-random time per layer;
+};                                     // 0xDE00bbbb: block bbbb never publishes its progress (its readers must time out)
 constexpr unsigned kBarMaxPolls = 1u << 21;
 
 constexpr int kAuxSc1 = 16;
@@ -707,23 +709,33 @@ __device__ __forceinline__ f32x4 buf_load_coh(__amdgpu_buffer_rsrc_t r, unsigned
 __device__ __forceinline__ void buf_store_coh(const f32x4 v, __amdgpu_buffer_rsrc_t r, unsigned off) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4b, v), r, off, 0, kAuxSc1);
 }
-// wave-wide wait: blocks lo..hi except `self` have all finished `target / 8` layers (lane t polls block lo + t, + 64, ...)
-__device__ __forceinline__ void wait_blocks(const unsigned* flags, int lo, int hi, int self, unsigned target, int* status) {
+// wave-wide wait: blocks lo..hi except `self` have all finished `target / 8` layers (lane t polls block lo + t, + 64, ...).
+// The poll is a relaxed agent-scope load (global_load_dword sc1); the rows it guards are then read by THIS wave with sc1
+// loads, after its poll has matched (MI355X guide, inter-workgroup visibility, first row of the sc1-loads table: one lane of
+// each storing workgroup signals for all its stores -- see the publish points below).  Returns true when the poll budget
+// ran out (never expected: every workgroup is resident): the caller then poisons what it stores, so that the call's output
+// cannot pass for a result, and the status word says HEXGNN_ETIMEOUT.
+__device__ __forceinline__ bool wait_blocks(const unsigned* flags, int lo, int hi, int self, unsigned target, int* status) {
     const int lane = threadIdx.x & 63;
+    bool timed_out = false;
     for (int b0 = lo; b0 <= hi; b0 += 64) {
         const int j = b0 + lane;
         const bool mine = j <= hi && j != self;
         unsigned polls = 0;
         while (true) {
             const unsigned v = mine ? __hip_atomic_load(flags + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : target;
-            if (__ballot(v < target) == 0ull) break;
+            if (__ballot((int)(v - target) < 0) == 0ull) break;          // (counters are compared modulo 2^32)
             __builtin_amdgcn_s_sleep(4);
-            if (++polls > kBarMaxPolls) {          // never expected: every workgroup is resident
+            if (++polls > kBarMaxPolls) {
                 if (status && lane == 0) *status = HEXGNN_ETIMEOUT;
+                timed_out = true;
                 break;
             }
         }
     }
+    // the relaxed poll orders nothing for the compiler: keep every later load (the other blocks' rows) behind the loop
+    asm volatile("" ::: "memory");
+    return timed_out;
 }
 
 template <int NT, bool BWD>
@@ -799,7 +811,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     float* bias_lds = reinterpret_cast<float*>(ctl + 16);         // forward: the layer's bias, 1 KiB (one LDS-DMA piece)
     const unsigned lds_b = lds_w + (unsigned)(2 * NT * NT * 1024 + 129 * RL::XS * 4 + 64);
     if constexpr (kV3) {
-        if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; ctl[2] = kCtlWaves; }
+        if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; ctl[2] = kCtlWaves; ctl[3] = 0u; }
         if constexpr (!BWD) {
             if (wave == 4) dma_piece(a.b0, 16 * lane, lds_b);     // (reads past the 4 * HP bias bytes, inside the pack buffer)
         }
@@ -879,10 +891,33 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     // start is everybody's starting value
     const unsigned fbase = __builtin_amdgcn_readfirstlane(
         __hip_atomic_load(a.flags + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    // (read by every wave before the workgroup's first publish: two workgroup barriers lie between this read and that add)
+    asm volatile("" ::: "memory");
 
+    // One signal per workgroup and layer, for ALL its stores: every wave drains its own stores (s_waitcnt vmcnt(0)), then adds to
+    // an LDS counter, and the wave whose add is the eighth of the layer raises the block's global counter by 8 (the hand-over
+    // without a barrier), or one lane does behind the workgroup barrier (the plain hand-over).  Until round 4 every wave added
+    // 1 for itself right behind its own wait -- a form the guide's table lists only together with a workgroup barrier between the
+    // consumer's poll and its loads and with whole 128-byte lines per store instruction (rows of 448 B: a store instruction
+    // here writes 64 B per row).
+    const bool muted = (a.skew >> 24) == 0xDEu && (int)(a.skew & 0xffffu) == blk;      // (test aid)
+    auto publish_block = [&]() {
+        asm volatile("" ::: "memory");
+        if (lane == 0 && !muted) {
+            const unsigned c = __hip_atomic_fetch_add(ctl + 3, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((c & 7u) == 7u) __hip_atomic_fetch_add(a.flags + blk, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    bool dead = false;                 // wave-uniform: a wait of this wave timed out -> everything it stores from now on is NaN
+    const f32x4 kNan4 = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
     const float* xin = a.in0;
     for (int it = 0; it < a.n_layers; ++it) {
         const int l = BWD ? a.l_first - it : a.l_first + it;
+        if (a.skew && (a.skew >> 24) != 0xDEu) {      // test aid: uneven progress of the blocks (stress test of the hand-over)
+            unsigned h = (a.skew + 0x9e3779b9u * (unsigned)(blk + 1)) ^ (0x85ebca6bu * (unsigned)(it + 1));
+            h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+            for (unsigned k = h & 63u; k > 0; --k) __builtin_amdgcn_s_sleep(64);
+        }
         float* out = BWD ? (l >= 1 ? a.slabs + a.slab * (size_t)(l - 1) : a.dx) : a.slabs + a.slab * (size_t)l;
         const float* ymask = BWD ? (l >= 1 ? a.masks + a.slab * (size_t)(l - 1) : nullptr) : nullptr;
         float* side = BWD ? ((a.tap_out && l - 1 == a.tap_layer) ? a.tap_out : nullptr)
@@ -913,7 +948,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         float rs[kRing] = {0.f, 0.f, 0.f, 0.f};   // backward, LDS path: 1 / deg of the rows in the global landing ring
         (void)rs;
         if constexpr (!kV3) {
-            if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, blk, fbase + 8u * (unsigned)it, a.status);
+            if (it > 0 && remote && !dead) dead |= wait_blocks(a.flags, dlo, dhi, blk, fbase + 8u * (unsigned)it, a.status);
         }
         auto filler_lds = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
@@ -922,12 +957,12 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 if (it > 0) {
                     wait_vmem();                  // previous layer's rows written through; waves 0-3: their W_l pieces landed
                     if (wave < (int)kCtlWaves) lds_bump(2);
-                    if (lane == 0) __hip_atomic_fetch_add(a.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    publish_block();
                 }
                 PSTAMP(KS, 1);
             }
             if constexpr (kV3 && Q == kGt) {
-                if (it > 0 && remote) wait_blocks(a.flags, dlo, dhi, self_excl, fbase + 8u * (unsigned)it, a.status);
+                if (it > 0 && remote && !dead) dead |= wait_blocks(a.flags, dlo, dhi, self_excl, fbase + 8u * (unsigned)it, a.status);
                 PSTAMP(KS, 12);
             }
             static_for_<0, kEll>([&](auto kk) {
@@ -1080,6 +1115,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                     f32x4 v = acc[t] + br[4 * t];
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = (v[q] > 0.f || !relu) ? v[q] : 0.f;
+                    if (dead) v = kNan4;
                     buf_store_coh(v, or_, oo + 64 * t);
                     xs[t] = v;
                 }
@@ -1096,6 +1132,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
 #pragma unroll
                         for (int q = 0; q < 4; ++q) v[q] = ym[t][q] > 0.f ? v[q] : 0.f;
                     }
+                    if (dead) v = kNan4;
                     buf_store_coh(v, or_, oo + 64 * t);
                     xs[t] = v;
                 }
@@ -1135,8 +1172,9 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         rows_to_lds();
         stage_weights(a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)(it + 1)) : (ptrdiff_t)(a.wstride * (size_t)(it + 1))));
         wait_vmem();          // this wave's rows are written through, its weight pieces have landed
-        if (lane == 0) __hip_atomic_fetch_add(a.flags + blk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
+        // ONE lane signals for the whole workgroup, behind the barrier that follows every wave's drained stores
+        if (tid == 0 && !muted) __hip_atomic_fetch_add(a.flags + blk, 8u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         xin = out;
     }
 }
@@ -1517,41 +1555,127 @@ static bool persist_ready(hipStream_t st) {
     state = 1;
     return true;
 }
-// a poll budget exceeded in an EARLIER launch is reported by the next stack call (like hipGetLastError)
+// a poll budget exceeded in an EARLIER launch is reported by the next stack call (like hipGetLastError) or by
+// hexgnn_stack_status() at any synchronisation point of the caller; the launch that timed out has poisoned its own output
+// with NaN (sage_stack_body: `dead`), so its results cannot pass for valid in the meantime
 static int take_stack_status() {
     if (!g_stack_status) return HEXGNN_OK;
     const int c = *reinterpret_cast<volatile int*>(g_stack_status);
     if (c != 0) *g_stack_status = 0;
     return c;
 }
-static bool persist_fits(int n, int nt, int layers, hipStream_t st) {
-    return nt >= 3 && layers >= 2 && n > 0 && persist_ready(st) && (n + 127) / 128 <= g_cu_count &&
-           (n + 127) / 128 <= kStackFlagWords;
+// ---- residency guard of the one-launch kernels ------------------------------------------------------------------------------
+// Every workgroup must be resident at once (a wave polls other blocks' counters).  The launch is refused (-> per-layer launches)
+// unless: the grid fits (occupancy x CUs - the CUs reserved for kernels that run beside it, e.g. RCCL channels while the
+// gradient all-reduce overlaps the backward: hexgnn_stack_reserve_cus); no CU mask is in force; and no one-launch kernel of
+// THIS process is still in flight on another stream (an event recorded behind every such launch; same-stream launches are
+// ordered).  What it cannot see -- another process on the GPU, a kernel of another library that fills the CUs -- ends in the
+// poll budget: NaN output + HEXGNN_ETIMEOUT, never a hang and never a plausible result.
+static std::atomic<int> g_reserved_cus{0};
+static std::atomic<int> g_persist_override{-1};          // -1: HEXGNN_NO_PERSIST decides, 0: per-layer launches, 1: one launch
+static std::mutex g_inflight_mu;
+static hipEvent_t g_inflight_ev = nullptr;
+static hipStream_t g_inflight_stream = nullptr;
+static bool g_inflight_valid = false;
+static bool stream_capturing(hipStream_t st) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); return true; }
+    return cs != hipStreamCaptureStatusNone;
+}
+static bool other_stream_in_flight(hipStream_t st) {
+    std::lock_guard<std::mutex> lock(g_inflight_mu);
+    if (!g_inflight_valid || g_inflight_stream == st) return false;
+    if (stream_capturing(st)) return false;               // (no event query inside a capture; captured steps are stream-ordered)
+    const hipError_t e = hipEventQuery(g_inflight_ev);
+    if (e == hipSuccess) { g_inflight_valid = false; return false; }
+    (void)hipGetLastError();
+    return true;
+}
+static void note_stack_launch(hipStream_t st) {
+    if (stream_capturing(st)) return;
+    std::lock_guard<std::mutex> lock(g_inflight_mu);
+    if (!g_inflight_ev && hipEventCreateWithFlags(&g_inflight_ev, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (hipEventRecord(g_inflight_ev, st) == hipSuccess) { g_inflight_stream = st; g_inflight_valid = true; }
+    else (void)hipGetLastError();
+}
+static bool cu_mask_in_force() {
+    static const bool m = [] {
+        for (const char* k : {"HSA_CU_MASK", "ROC_GLOBAL_CU_MASK", "HSA_CU_MASK_SKIP_INIT"}) { const char* v = getenv(k); if (v && v[0]) return true; }
+        return false;
+    }();
+    return m;
+}
+// test aid: HEXGNN_STACK_SKEW=<seed> (or hexgnn_debug_stack_skew) delays the blocks unevenly, a new pattern per launch
+static std::atomic<unsigned> g_stack_skew_seed{[] { const char* v = getenv("HEXGNN_STACK_SKEW"); return v ? (unsigned)atoi(v) : 0u; }()};
+static unsigned stack_skew() {
+    static std::atomic<unsigned> counter{0};
+    const unsigned seed = g_stack_skew_seed.load();
+    if ((seed >> 24) == 0xDEu) return seed;          // "mute block (seed & 0xffff)": the timeout test
+    return seed ? (seed + 7919u * counter.fetch_add(1)) & 0x00ffffffu : 0u;
+}
+template <int NT> static int stack_blocks_per_cu(bool bwd) {
+    static int occ[2] = {-1, -1};
+    int& o = occ[bwd ? 1 : 0];
+    if (o < 0) {
+        int nb = 0;
+        const size_t lds = 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024;
+        const void* f = bwd ? reinterpret_cast<const void*>(&sage_stack_bwd_kernel<NT>) : reinterpret_cast<const void*>(&sage_stack_fwd_kernel<NT>);
+        (void)hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, f, 512, lds) != hipSuccess) { (void)hipGetLastError(); nb = 0; }
+        o = nb > 1 ? 1 : nb;          // (the protocol budgets one workgroup per CU: 157 KB of LDS at the widths with a row copy)
+    }
+    return o;
+}
+static int stack_occupancy(int nt, bool bwd) {
+    switch (nt) {
+        case 3: return stack_blocks_per_cu<3>(bwd); case 4: return stack_blocks_per_cu<4>(bwd); case 5: return stack_blocks_per_cu<5>(bwd);
+        case 6: return stack_blocks_per_cu<6>(bwd); case 7: return stack_blocks_per_cu<7>(bwd); case 8: return stack_blocks_per_cu<8>(bwd);
+        default: return 0;
+    }
+}
+static bool persist_fits(int n, int nt, int layers, hipStream_t st, bool bwd) {
+    const int ov = g_persist_override.load();
+    if (ov == 0) return false;
+    if (!(nt >= 3 && layers >= 2 && n > 0 && persist_ready(st))) return false;
+    const int blocks = (n + 127) / 128;
+    if (blocks > kStackFlagWords || cu_mask_in_force()) return false;
+    const bool capturing = stream_capturing(st);
+    const int occ = capturing ? 1 : stack_occupancy(nt, bwd);     // (no occupancy query inside a capture: queried by the warm-up)
+    if (blocks > occ * g_cu_count - g_reserved_cus.load()) return false;
+    return !other_stream_in_flight(st);
 }
 
 template <int NT>
-static void launch_stack_fwd(const StackKArgs& a, hipStream_t st) {
+static void launch_stack_fwd(StackKArgs a, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_stack_fwd_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024);
         return true;
     }();
     (void)once;
-    KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
-    if constexpr (NT >= 3)
-        sage_stack_fwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
+    a.skew = stack_skew();
+    {
+        KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
+        if constexpr (NT >= 3)
+            sage_stack_fwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
+    }
+    note_stack_launch(st);
 }
 template <int NT>
-static void launch_stack_bwd(const StackKArgs& a, hipStream_t st) {
+static void launch_stack_bwd(StackKArgs a, hipStream_t st) {
     static bool once = [] {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&sage_stack_bwd_kernel<NT>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024);
         return true;
     }();
     (void)once;
-    KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
-    if constexpr (NT >= 3)
-        sage_stack_bwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
+    a.skew = stack_skew();
+    {
+        KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
+        if constexpr (NT >= 3)
+            sage_stack_bwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
+    }
+    note_stack_launch(st);
 }
 
 template <int NT>
@@ -1769,7 +1893,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     rc = take_stack_status();
     if (rc != HEXGNN_OK) return rc;
     const int fh = p.small_first ? 1 : 0;
-    const bool one_launch = persist_fits(n, p.nt, p.L - fh, st);
+    const bool one_launch = persist_fits(n, p.nt, p.L - fh, st, false);
     for (int l = 0; l < p.L; ++l) {
         float* y = acts + slab * l;
         const float* bias = (const float*)(wp + p.bias_off[l]);
@@ -1885,7 +2009,7 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
     rc = take_stack_status();
     if (rc != HEXGNN_OK) return rc;
     const int lo = (first_hidden == 0 && !dx) ? 1 : first_hidden;        // last layer whose data gradient is wanted
-    const bool one_launch = persist_fits(n, p.nt, p.L - lo, st);
+    const bool one_launch = persist_fits(n, p.nt, p.L - lo, st, true);
     if (one_launch) {
         StackKArgs a{};
         a.n = n; a.l_first = p.L - 1; a.n_layers = p.L - lo;
@@ -2021,6 +2145,47 @@ int hexgnn_sage_norm_stack_backward(int n, int c_in, int hidden, int num_layers,
     }
     rc = launch_weight_grads(n, c_in, hidden, p, b, x, x_stride, acts, sv, G, d_wl, d_bl, d_wr, part, part0, st);
     if (rc != HEXGNN_OK) return rc;
+    return check_launch();
+}
+
+int hexgnn_stack_status(int clear) {
+    if (!g_stack_status) return HEXGNN_OK;
+    const int c = *reinterpret_cast<volatile int*>(g_stack_status);
+    if (c != 0 && clear) *g_stack_status = 0;
+    return c;
+}
+
+int hexgnn_stack_reserve_cus(int cus) {
+    if (cus < 0) return HEXGNN_EINVAL;
+    return g_reserved_cus.exchange(cus);
+}
+
+int hexgnn_debug_stack_mode(int persist, unsigned skew_seed) {
+    if (persist < -1 || persist > 1) return HEXGNN_EINVAL;
+    g_persist_override.store(persist);
+    g_stack_skew_seed.store(skew_seed);
+    return HEXGNN_OK;
+}
+
+namespace hexgnn {
+// test aid: `blocks` workgroups of 1024 threads that keep their CUs' memory pipes busy for ~usec microseconds (a streaming
+// kernel beside the one-launch stack kernels: uneven load for the hand-over's stress test)
+__global__ __launch_bounds__(1024) void debug_occupy_kernel(const f32x4* __restrict__ src, size_t words4, f32x4* __restrict__ sink,
+                                                            unsigned long long ticks) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    size_t i = ((size_t)blockIdx.x * 1024 + threadIdx.x) % words4;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { acc += src[i]; i += 1024 * 61; if (i >= words4) i -= words4; }
+    }
+    if (acc[0] == 1.2345e-30f) sink[0] = acc;      // (never true: keeps the loads)
+}
+}  // namespace hexgnn
+int hexgnn_debug_occupy(int blocks, int usec, const void* buffer, size_t buffer_bytes, void* sink, hexgnn_stream_t stream_) {
+    if (blocks <= 0 || usec <= 0 || !buffer || buffer_bytes < 16 * 1024 * 64 || !sink) return HEXGNN_EINVAL;
+    hexgnn::debug_occupy_kernel<<<blocks, 1024, 0, (hipStream_t)stream_>>>((const f32x4*)buffer, buffer_bytes / 16, (f32x4*)sink,
+                                                                          (unsigned long long)usec * 100ull);   // 100 MHz clock
     return check_launch();
 }
 

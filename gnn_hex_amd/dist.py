@@ -72,8 +72,12 @@ class GradSync:
         over xGMI while the lower layers' weight-gradient GEMM still computes; ``all_reduce()`` then only waits.  With
         RCCL the collective runs on the process group's own stream (async work, 1/world folded in as ReduceOp.AVG); the
         gloo rehearsal backend reduces the segment synchronously through the host (same results, no overlap)."""
-        from . import ops
+        from . import ops, _lib
         ops.set_grad_stage_hook(self._on_segment if enabled else None)
+        # the one-launch SAGE stack kernels need every workgroup resident at once: leave the CUs of the RCCL channels that
+        # run beside the backward to them (the residency guard falls back to per-layer launches when the grid no longer fits)
+        if torch.cuda.is_available():
+            _lib.lib().hexgnn_stack_reserve_cus(64 if enabled else 0)
 
     def _on_segment(self, flat: torch.Tensor, lo: int, hi: int) -> None:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1

@@ -191,7 +191,10 @@ class GraphStructure:
     def check(self) -> None:
         """Host-synchronising validity check (debug aid; not called on the hot path).  Batches built by the one-launch
         CSR build share the device's sticky error word: an error is reported by the first check after it, then cleared."""
-        code = int(self.status.item())
+        code = int(self.status.item())              # (synchronises)
+        rc = _lib.lib().hexgnn_stack_status(1)      # a one-launch stack kernel that ran out of its poll budget since the last check
+        if rc != 0:
+            _lib.check(rc, "a one-launch SAGE stack kernel (its output rows were poisoned with NaN)")
         if code != 0:
             if self.status is _STICKY.get((self.status.device.type, self.status.device.index)):
                 self.status.zero_()

@@ -338,6 +338,21 @@ int hexgnn_qnet_backward_flat(int n, int b, int c_in, int hidden, int total_laye
                               void* workspace, size_t workspace_bytes, int* status,
                               int stages, int layer_lo, int layer_hi, hexgnn_stream_t stream);
 
+/* One-launch SAGE stack kernels behind hexgnn_sage_stack_* (all hidden layers of a stack in one launch when every workgroup can be
+ * resident; GN0/models.py:261-294's layer loop).  Their waits have a poll budget: a launch that exhausts it writes NaN rows
+ * into its own output and sets HEXGNN_ETIMEOUT in a status word that the NEXT stack call returns -- or this query, at any point
+ * where the caller has synchronised (clear != 0 resets it).  hexgnn_stack_reserve_cus: CUs the residency guard leaves to kernels
+ * that run BESIDE a stack kernel (RCCL channels while the gradient all-reduce overlaps the backward); returns the previous
+ * value.  The guard also keeps to per-layer launches while a one-launch kernel of this process is in flight on another stream. */
+int hexgnn_stack_status(int clear);
+int hexgnn_stack_reserve_cus(int cus);
+/* Test aids (tests/test_gpu_stack_stress.py): persist -1 = default (HEXGNN_NO_PERSIST decides), 0 = per-layer launches, 1 = one
+ * launch where the guard allows; skew_seed != 0 delays every workgroup by a pseudo-random time per layer.  hexgnn_debug_occupy:
+ * `blocks` 1024-thread workgroups streaming `buffer` for ~usec microseconds on `stream` (uneven load beside a stack kernel). */
+int hexgnn_debug_stack_mode(int persist, unsigned skew_seed);
+int hexgnn_debug_occupy(int blocks, int usec, const void* buffer, size_t buffer_bytes, void* sink /* >= 16 B */,
+                        hexgnn_stream_t stream);
+
 /* The DQN update's loss folded into the network calls (ABI 6): `loss = loss_fn(Q[sel], target)` of the RainbowDQN training step
  * (README.md:5,7: --loss_fn=mse, --prioritized_er=True importance weights; the step of SURVEY.md 8d) is graph-local when the
  * update selects ONE node per graph, sel[g] a row of graph g (the action taken in the sampled transition), so the forward
