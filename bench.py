@@ -30,7 +30,7 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (6.29 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3
 # useful-FLOP peak of each arithmetic: exact fp32 MFMA; split modes issue 3 (f16x3) f16 MFMAs (2516 TFLOP/s dense) per product
 MFMA_PEAK_TFLOPS = {"fp32": 157.3, "f16x3": 2516.6 / 3}
-PROFILE_ROUND = "r03"
+PROFILE_ROUND = "r04"
 
 CONFIGS = {
     # name: (num_layers, hidden, sizes-per-graph fn, label)
@@ -41,6 +41,9 @@ CONFIGS = {
 
 KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel",
           8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
+# classes 0 / 1 time whichever kernel runs the hidden layers of the layer-major path: one launch per layer, or (batch fits one
+# resident workgroup per CU) ONE launch for all of them -- told apart by the launches per step
+KNAMES_STACK = {0: "sage_stack_fwd_kernel", 1: "sage_stack_bwd_kernel"}
 
 
 def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
@@ -98,6 +101,8 @@ def secondary_config(config, data, B, dev, steps, warmup, preheat_ms):
             def fn():
                 for p in plist:
                     p.grad = None
+                if True:      # (the fused form of the three calls; falls back by itself where it does not apply, e.g. MIX)
+                    return hexops.td_step(hip, bt["x"], bt["ei"], bt["bv"], bt["ptr"], sel=bt["sel"], target=bt["tgt"])[0]
                 q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
                 loss, _ = hexops.td_loss(q, bt["sel"], bt["tgt"])
                 hexops.backward(loss)
@@ -182,9 +187,16 @@ def main():
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: one all-reduce after the backward instead of the staged backward whose first gradient "
                          "segment is reduced while the rest of the weight-gradient GEMM computes")
+    ap.add_argument("--split-graph", action="store_true",
+                    help="capture the step as TWO graphs split at the staged backward's hand-over and start the first gradient "
+                         "segment's all-reduce between their replays (N > 1: the collective overlaps the second graph's "
+                         "weight-gradient GEMM); default: one graph, one all-reduce behind it")
     ap.add_argument("--no-td-step", action="store_true",
                     help="issue the step as model(...), ops.td_loss, ops.backward (three calls, a TD-loss launch between the "
                          "network's two) instead of ops.td_step, which forms the same loss in the forward kernel's tail")
+    ap.add_argument("--plain-autograd", action="store_true",
+                    help="with --eager: the step exactly as an unmodified train.py issues it -- q[sel] by torch indexing, "
+                         "F.mse_loss, loss.backward() through the autograd engine (no gnn_hex_amd.ops call)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-collective-probe", action="store_true",
                     help="N = 1: skip the 1-rank RCCL all-reduce latency probe of the gradient bucket (config.collective)")
@@ -258,13 +270,21 @@ def main():
     gfactor = 1 if strong else world          # graphs per step over all ranks = B * gfactor
 
     plist = list(hip.parameters())
-    td_fused = not args.no_td_step and not overlap
+    td_fused = not args.no_td_step and not overlap and not args.plain_autograd
+    if args.plain_autograd and args.graph:
+        raise SystemExit("--plain-autograd is an --eager measurement (the step an unmodified train.py issues)")
 
     def step(i):
         bt = batches[i & 1]
         for p in plist:              # optimizer.zero_grad(set_to_none=True) over a cached parameter list
             p.grad = None
-        if td_fused:
+        if args.plain_autograd:
+            # an UNMODIFIED train.py: torch indexing, torch's loss, loss.backward() -- no gnn_hex_amd.ops call in the step
+            q = hip(bt["x"], bt["ei"], bt["bv"], bt["ptr"])
+            d = q[bt["sel"]]
+            loss = torch.nn.functional.mse_loss(d, bt["tgt"]) if bt["w"] is None else (bt["w"] * (d - bt["tgt"]) ** 2).mean()
+            loss.backward()
+        elif td_fused:
             # the same three calls in their fused form (ops.td_step: the loss is formed in the forward kernel's tail)
             hexops.td_step(hip, bt["x"], bt["ei"], bt["bv"], bt["ptr"], sel=bt["sel"], target=bt["tgt"], weights=bt["w"])
         else:
@@ -290,14 +310,50 @@ def main():
                 return loss
             return fn
 
-        g0 = GraphedStep(local_step(batches[0]), plist)
-        g1 = GraphedStep(local_step(batches[1]), plist, pool=g0.pool())
-        graphs = (g0, g1)
+        split = args.split_graph
+        if split:
+            # opt-in: the step as TWO graphs split at the staged backward's hand-over, so that the all-reduce of the finished
+            # gradient segment (RCCL, its own stream) travels beside the second graph's weight-gradient GEMM.  Not the default:
+            # measured at N = 1 the split itself costs 0.682 -> 0.725 ms per step (two half-size weight-gradient launches at
+            # twice the slices each, two slab reduces, a second graph launch: profiles/r04), i.e. about what hiding a
+            # latency-bound 2-MB all-reduce can win back -- DESIGN.md section 6
+            from gnn_hex_amd.graphs import GraphedSplitStep
+            from gnn_hex_amd import _lib as hexlib
+            hexlib.lib().hexgnn_stack_reserve_cus(64)      # (the one-launch stack kernels leave the RCCL channels their CUs)
 
-        def step(i):
-            graphs[i & 1].replay()
-            if world > 1:
-                sync.all_reduce()
+            def first_of(bt):
+                def fn():
+                    for p in plist:
+                        p.grad = None
+                    loss, _, _, call = hexops.td_step(hip, bt["x"], bt["ei"], bt["bv"], bt["ptr"], sel=bt["sel"],
+                                                      target=bt["tgt"], weights=bt["w"], defer_lower=True)
+                    return loss, call
+                return fn
+
+            g0 = GraphedSplitStep(first_of(batches[0]), hexops.finish_backward, plist)
+            g1 = GraphedSplitStep(first_of(batches[1]), hexops.finish_backward, plist, pool=g0.pool())
+            graphs = (g0, g1)
+            overlap = world > 1
+
+            def step(i):
+                gr = graphs[i & 1]
+                gr.replay_first()
+                if gr.flat is not None and world > 1:
+                    sync.reduce_segment(gr.flat, gr.cut, gr.total)
+                gr.replay_second()
+                if world > 1:
+                    if gr.flat is not None:
+                        sync.reduce_segment(gr.flat, 0, gr.cut)
+                    sync.all_reduce()
+        else:
+            g0 = GraphedStep(local_step(batches[0]), plist)
+            g1 = GraphedStep(local_step(batches[1]), plist, pool=g0.pool())
+            graphs = (g0, g1)
+
+            def step(i):
+                graphs[i & 1].replay()
+                if world > 1:
+                    sync.all_reduce()
 
     with _stdout_to_stderr():
         init_group()
@@ -410,8 +466,10 @@ def main():
         launches, tot_ms = per_kernel[dom]
         avg_s = tot_ms / max(launches, 1) * 1e-3
         hidden_layers = num_layers + 1          # hidden-input SAGE layers per step: (L-1) body + 2 head
-        if dom in (0, 1):   # gather kernels: HBM roofline on the un-fused aggregation bytes of ONE layer
-            alg = bytes_fwd(n, e, hidden)          # bytes per launch (one layer, one direction)
+        layers_per_launch = 1.0
+        if dom in (0, 1):   # gather kernels: HBM roofline on the un-fused aggregation bytes of the layers ONE launch runs
+            layers_per_launch = max(1.0, round(hidden_layers / max(launches / args.steps, 1e-9)))
+            alg = layers_per_launch * bytes_fwd(n, e, hidden)      # bytes per layer and direction x layers per launch
             roof = dict(bound="hbm", achieved=alg / avg_s / 1e9, peak=HBM_PEAK_GBS, unit="GB/s")
         elif dom in (8, 9):  # fused per-graph kernels: one launch = all layers of one direction
             alg = bytes_fwd(n, e, 2) + hidden_layers * bytes_fwd(n, e, hidden)
@@ -424,7 +482,7 @@ def main():
         # traffic is far below the un-fused algorithmic bytes and the binding roof is the MFMA pipe of the arithmetic in use
         launch_flops = (flops_fwd(n, batches[0]["graphs"], hidden, num_layers) if dom in (8, 9)
                         else 2.0 * n * (2 * hidden) * hidden * (hidden_layers / max(launches / args.steps, 1)) if dom == 2
-                        else 4.0 * n * hidden * hidden)
+                        else 4.0 * n * hidden * hidden * layers_per_launch)
         mfma_peak = MFMA_PEAK_TFLOPS[args.math]
         roof["mfma_tflops"] = launch_flops / avg_s / 1e12
         roof["mfma_peak_tflops"] = mfma_peak
@@ -436,21 +494,27 @@ def main():
         tpath = os.path.join(ROOT, "profiles", PROFILE_ROUND, "traffic_pmc.json")
         if not os.path.exists(tpath):       # counters not re-collected this round yet: the previous round's passes
             tpath = os.path.join(ROOT, "profiles", "r02", "traffic_pmc.json")
-        if args.config == "L256" and args.data == "D0" and B == 256 and os.path.exists(tpath):
+        kname = KNAMES_STACK[dom] if (dom in (0, 1) and layers_per_launch > 1) else KNAMES[dom]
+        if args.data == "D0" and B == 256 and os.path.exists(tpath):
             mid = 1 if args.math == "f16x3" else 0
-            want = {2: "sage_dw16_kernel<" if mid else "sage_dw_kernel<"}.get(dom, "%s<7, %d>" % (KNAMES[dom], mid))
-            for k, v in json.load(open(tpath)).items():
-                if want in k:
+            table = json.load(open(tpath))
+            table = table.get(args.config, table if args.config == "L256" and "L256" not in table else {})   # (r04: per configuration)
+            want = {2: "sage_dw16_kernel<" if mid else "sage_dw_kernel<"}.get(dom, kname + "<")
+            for k, v in table.items():
+                if want in k and (dom == 2 or dom in (0, 1) or k.rstrip(">").endswith(", %d" % mid)):
                     roof["traffic"] = v["hbm_bytes_per_launch"]
         if roof["traffic"]:
             roof["measured_hbm_frac"] = roof["traffic"] / avg_s / 1e9 / HBM_PEAK_GBS
             roof["binding_roof"] = "mfma" if roof["mfma_frac"] >= roof["measured_hbm_frac"] else "hbm"
-        roof["kernel"] = KNAMES[dom]
+        roof["kernel"] = kname
         roof["avg_launch_us"] = avg_s * 1e6
         roof["launches_per_step"] = launches / args.steps
+        roof["layers_per_launch"] = layers_per_launch if dom in (0, 1) else (hidden_layers if dom in (8, 9) else
+                                                                              hidden_layers / max(launches / args.steps, 1))
         step_bytes = 2 * (bytes_fwd(n, e, 2) + (num_layers + 1) * bytes_fwd(n, e, hidden))
         roof["step_aggregation_GBps"] = step_bytes / (ms_per_step * 1e-3) / 1e9
-        roof["kernel_ms_per_step"] = {KNAMES[k]: per_kernel[k][1] / args.steps for k in per_kernel}
+        roof["kernel_ms_per_step"] = {(KNAMES_STACK[k] if (k in (0, 1) and per_kernel[k][0] / args.steps < hidden_layers / 2)
+                                       else KNAMES[k]): per_kernel[k][1] / args.steps for k in per_kernel}
 
         # informational, never `value`: the same steps in the opt-in split-precision arithmetic (three f16 MFMAs per
         # product on power-of-two scaled operands, 22-bit products, fp32 accumulate; tests hold it to the same 1e-4 bar and
@@ -483,7 +547,7 @@ def main():
 
         probe = None
         if world == 1 and not args.no_collective_probe:
-            probe = collective_probe(dev, 4 * sum(p.numel() for p in plist if p.grad is not None))
+            probe = collective_probe_child(4 * sum(p.numel() for p in plist if p.grad is not None))
 
         out = {
             "metric": "board-graphs/sec fwd+bwd", "value": value, "unit": "graphs/s", "n_gpus": world,
@@ -497,7 +561,8 @@ def main():
                                       batches[0]["graphs"], batches[0]["n"], batches[0]["e"]),
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * gfactor,
                        "graphs_per_gpu": batches[0]["graphs"],
-                       "step_issue": "ops.td_step (model forward, TD loss in its tail, backward)" if td_fused else
+                       "step_issue": "model(...), F.mse_loss(q[sel], target), loss.backward()" if args.plain_autograd else
+                                     "ops.td_step (model forward, TD loss in its tail, backward)" if td_fused else
                                      "model(...), ops.td_loss, ops.backward"},
             "roofline": roof, "cpu_baseline": cpu, "split_precision_mode": split, "other_configs": others,
         }
@@ -582,6 +647,21 @@ class _stdout_to_stderr:
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False
+
+
+def collective_probe_child(nbytes, timeout_s=90.0):
+    """The probe below in a FRESH child process (started, never exec'ed, by this one) with a time limit: an RCCL or rendezvous
+    hang cannot take the bench line down, and this process's MASTER_* environment stays untouched.  Never raises."""
+    import subprocess
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-child", str(int(nbytes))], capture_output=True,
+                           text=True, timeout=timeout_s, env=dict(os.environ))
+        for ln in reversed(r.stdout.strip().splitlines()):
+            if ln.startswith("{"):
+                return json.loads(ln)
+        return {"backend": "rccl", "world": 1, "error": "no result (rc %d): %s" % (r.returncode, r.stderr[-200:])}
+    except Exception as exc:  # noqa: BLE001
+        return {"backend": "rccl", "world": 1, "error": "%s: %s" % (type(exc).__name__, exc)}
 
 
 def collective_probe(dev, nbytes, reps=50):
@@ -693,4 +773,9 @@ def cpu_baseline(ref, batches, B, total_budget_s=40.0):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) == 3 and sys.argv[1] == "--probe-child":
+        # child of collective_probe_child(): a 1-rank RCCL all-reduce of the bucket, result as one JSON line
+        import gnn_hex_amd  # noqa: F401
+        print(json.dumps(collective_probe(torch.device("cuda", 0), int(sys.argv[2]))), flush=True)
+        sys.exit(0)
     main()

@@ -539,9 +539,26 @@ __device__ __forceinline__ void gather_gap(const float* rows, const NbrRegs& nb,
     });
 }
 
-// piece index of this wave's q-th share of a weight half (NT*NT pieces over 8 waves); -1: none
-template <int NT> __device__ __forceinline__ int dma_share(int wave, int q) {
+// piece index of this wave's q-th share of a weight half (NT*NT pieces over 8 waves); -1: none.
+// `spare` (workgroup-uniform): the graph has at most 64 rows, waves 4-7 own no rows and share the SIMDs of waves 0-3 -- they
+// then move ALL the pieces (up to two rounds of four inside the kDma filler slots), and the waves with rows issue none (a piece
+// costs its issuing wave 60-150 cycles of SALU + vector-memory issue, and at one active wave per SIMD nothing hides them).
+// (Round 4 also tried handing waves 4-7 the whole non-MFMA side of their partner's layer -- gather, stores, DMA -- through the
+// unused upper half of the row buffer: GNN-S 5.05 k -> 5.9 k ticks per layer.  A helper's VALU instructions issue only between
+// its partner's fp32 MFMAs, one per 32-cycle slot: profiles/r04/helper_waves_experiment.patch, stamps_S256_helper_waves.txt.)
+template <int NT> __device__ __forceinline__ int dma_share(int wave, int q, bool spare = false) {
+    if (spare) {
+        if (wave < 4) return -1;
+        const int p0 = (wave - 4) + 8 * q;                   // two pieces per slot and spare wave: the second is dma_share2's
+        return p0 < NT * NT ? p0 : -1;
+    }
     const int p = wave + 8 * q;
+    return p < NT * NT ? p : -1;
+}
+// the second piece of a slot in `spare` mode (-1: none)
+template <int NT> __device__ __forceinline__ int dma_share2(int wave, int q, bool spare) {
+    if (!spare || wave < 4) return -1;
+    const int p = (wave - 4) + 8 * q + 4;
     return p < NT * NT ? p : -1;
 }
 
@@ -580,6 +597,7 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const int lrow = wave * 16 + r;                 // local row of this lane
     const bool rvalid = lrow < cnt;
     const bool wactive = wave * 16 < cnt;           // wave-uniform
+    const bool spare = cnt <= kRows / 2;            // workgroup-uniform: waves 4-7 own no rows (dma_share)
     const int grow = r0 + lrow;
     // values the prologue needs two or three barriers further down are requested NOW, with the CSR: every global round trip
     // left on the chain gptr -> rowptr -> columns -> ... costs ~0.8 us at kernel start (GNN-S: 12.5 k ticks of prologue)
@@ -735,12 +753,16 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
         f32x4 bstg = f32x4{0.f, 0.f, 0.f, 0.f};
         if (tid < HP / 4) bstg = reinterpret_cast<const f32x4*>(a.wpack + a.bias_off[(MATH == 0 && more) ? l + 1 : l])[tid];
         auto dmaS = [&](auto qq) {
-            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            const int p = dma_share<NT>(wave, decltype(qq)::value, spare);
             if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
+            const int p2 = dma_share2<NT>(wave, decltype(qq)::value, spare);
+            if (p2 >= 0) dma_piece(wsrc + p2 * 64, lane16, lds_w + p2 * 1024);
         };
         auto dmaA = [&](auto qq) {
-            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            const int p = dma_share<NT>(wave, decltype(qq)::value, spare);
             if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+            const int p2 = dma_share2<NT>(wave, decltype(qq)::value, spare);
+            if (more && p2 >= 0) dma_piece(nsrc + p2 * 64, lane16, lds_w + (kHalf + p2 * 64) * 16);
         };
         if (!wactive) {
             // a wave without rows only moves its weight pieces (its own straight path: the active path below then has no
@@ -1027,6 +1049,7 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int lrow = wave * 16 + r;
     const bool rvalid = lrow < cnt;
     const bool wactive = wave * 16 < cnt;
+    const bool spare = cnt <= kRows / 2;            // workgroup-uniform: waves 4-7 own no rows (dma_share)
     const int grow = r0 + lrow;
     const int H2 = H / 2;
     const size_t slab = (size_t)a.n * HP;
@@ -1264,12 +1287,16 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             }
         }
         auto dmaS = [&](auto qq) {
-            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            const int p = dma_share<NT>(wave, decltype(qq)::value, spare);
             if (p >= 0) dma_piece(wsrc + p * 64, lane16, lds_w + p * 1024);
+            const int p2 = dma_share2<NT>(wave, decltype(qq)::value, spare);
+            if (p2 >= 0) dma_piece(wsrc + p2 * 64, lane16, lds_w + p2 * 1024);
         };
         auto dmaA = [&](auto qq) {
-            const int p = dma_share<NT>(wave, decltype(qq)::value);
+            const int p = dma_share<NT>(wave, decltype(qq)::value, spare);
             if (more && p >= 0) dma_piece(nsrc + p * 64, lane16, lds_w + (kHalf + p * 64) * 16);
+            const int p2 = dma_share2<NT>(wave, decltype(qq)::value, spare);
+            if (more && p2 >= 0) dma_piece(nsrc + p2 * 64, lane16, lds_w + (kHalf + p2 * 64) * 16);
         };
         if (!wactive) {      // a wave without rows only moves its weight pieces (own straight path, as in the forward kernel)
             static_for<0, kDma>(dmaS);

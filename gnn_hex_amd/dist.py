@@ -79,6 +79,11 @@ class GradSync:
         if torch.cuda.is_available():
             _lib.lib().hexgnn_stack_reserve_cus(64 if enabled else 0)
 
+    def reduce_segment(self, flat: torch.Tensor, lo: int, hi: int) -> None:
+        """Start the all-reduce of ``flat[lo:hi]`` now (asynchronously with RCCL); ``all_reduce()`` later only waits.  The
+        call a step captured as two graphs makes between its replays (graphs.GraphedSplitStep)."""
+        self._on_segment(flat, lo, hi)
+
     def _on_segment(self, flat: torch.Tensor, lo: int, hi: int) -> None:
         world = dist.get_world_size(self.group) if dist.is_initialized() else 1
         if world <= self._min_world or hi <= lo:

@@ -77,3 +77,54 @@ class GraphedStep:
         return self.out
 
     __call__ = replay
+
+
+class GraphedSplitStep:
+    """A training step captured as TWO HIP graphs split at the staged backward's hand-over (the one exchange per step
+    is the gradient all-reduce, and it should travel while the backward still computes).  ``first()`` issues the step up to the
+    point where the TAIL of the flat gradient buffer is final and returns ``(out, call)``; ``second(call)`` issues the rest
+    (``ops.td_step(..., defer_lower=True)`` / ``ops.finish_backward``).  Between the two replays the caller starts the tail's
+    all-reduce (a collective cannot be issued from inside a captured graph); it then runs on RCCL's stream beside the second
+    graph's weight-gradient GEMM:
+
+        out = step.replay_first(); sync.reduce_segment(step.flat, step.cut, step.total)
+        step.replay_second();     sync.reduce_segment(step.flat, 0, step.cut); sync.all_reduce()
+
+    Both graphs share one memory pool; the buffers the first graph allocates (gradients, workspace) are the second's inputs."""
+
+    def __init__(self, first: Callable[[], tuple], second: Callable[[object], tuple],
+                 params: Optional[Iterable[torch.nn.Parameter]] = None, warmup: int = 3, pool=None):
+        self._call = None
+
+        def fn_first():
+            out, call = first()
+            self._call = call
+            return out
+
+        def fn_second():
+            flat, cut = second(self._call)
+            self._fc = (flat, cut)
+            return None
+
+        self.g1 = GraphedStep(fn_first, params, warmup=warmup, pool=pool)
+        self._fc = (None, 0)
+        self.g2 = GraphedStep(fn_second, None, warmup=warmup, pool=self.g1.pool())
+        self.flat, self.cut = self._fc
+        self.total = int(self.flat.numel()) if self.flat is not None else 0
+        self.out = self.g1.out
+
+    def pool(self):
+        return self.g1.pool()
+
+    def replay_first(self):
+        return self.g1.replay()
+
+    def replay_second(self):
+        self.g2.graph.replay()
+
+    def replay(self):
+        out = self.replay_first()
+        self.replay_second()
+        return out
+
+    __call__ = replay

@@ -992,7 +992,7 @@ class QNetParamCache:
 
 class _QNetCall:
     """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
-    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered", "td")
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered", "td", "pending")
 
 
 _HP_CACHE = {}
@@ -1216,10 +1216,15 @@ class QNetDirectFn(torch.autograd.Function):
         return None, None, None
 
 
-def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
+def qnet_direct_backward(call: "_QNetCall", dq, d_v=None, defer_lower: bool = False) -> None:
     """The fused backward of a direct forward: every parameter gradient into ONE flat buffer, views assigned to ``p.grad``
     (accumulated when a gradient is already there).  Called by autograd (QNetDirectFn.backward, on the engine's device
-    thread) or straight from ``ops.backward(loss)`` on the caller's thread."""
+    thread) or straight from ``ops.backward(loss)`` on the caller's thread.
+
+    ``defer_lower``: only the first stage of the staged backward runs (data chain, small reduces, weight gradients of the upper
+    half of the hidden layers: the TAIL of the flat buffer is final); ``finish_backward(call)`` runs the rest.  A step captured
+    as two HIP graphs split there lets the tail's all-reduce travel while the second graph computes (graphs.GraphedSplitStep)."""
+    call.pending = None
     if call.done:
         raise RuntimeError("this forward's backward already ran through ops.backward(loss) (its graph is spent, as after "
                            "loss.backward() without retain_graph)")
@@ -1251,7 +1256,12 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
         tb, tn, tbb = td
         tp = tb.data_ptr()
         ctd = common[:6] + common[7:21] + common[22:]          # (no mode, no d_out_v: mode 0)
-        if hook is None or tot < 3:
+        if defer_lower and tot >= 3:
+            mid = 1 + tot // 2
+            _lib.check(L.hexgnn_qnet_backward_flat_td(*ctd, 7, mid, tot, tp + 4 * (tn + tbb), tp + 4 * (tn + 2 * tbb), _stream()),
+                       "hexgnn_qnet_backward_flat_td")
+            call.pending = (common, mid, flat, cache.cut, ws, d_emb)
+        elif hook is None or tot < 3:
             _lib.check(L.hexgnn_qnet_backward_flat_td(*ctd, 7, 1, tot, tp + 4 * (tn + tbb), tp + 4 * (tn + 2 * tbb), _stream()),
                        "hexgnn_qnet_backward_flat_td")
         else:
@@ -1261,6 +1271,10 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
             hook(flat, cut, cache.total)
             _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
             hook(flat, 0, cut)
+    elif defer_lower and tot >= 3 and mode != 2:
+        mid = 1 + tot // 2
+        _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, mid, tot, _stream()), "hexgnn_qnet_backward_flat")
+        call.pending = (common, mid, flat, cache.cut, ws, d_emb)
     elif hook is None or tot < 3 or mode == 2:
         _lib.check(L.hexgnn_qnet_backward_flat(*common, 7, 1, tot, _stream()), "hexgnn_qnet_backward_flat")
     else:
@@ -1272,6 +1286,18 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None) -> None:
     _assign_flat_grads(cache, flat, mode)
     if call.sink is not None:
         call.sink(d_emb[:, :hidden])
+
+
+def finish_backward(call: "_QNetCall"):
+    """Second stage of a backward started with ``defer_lower=True``: the weight-gradient GEMM + slab reduce of the lower half of
+    the hidden layers (the head of the flat gradient buffer).  Returns ``(flat, cut)``: the buffer and the position where its
+    two segments meet (None, 0 when nothing was deferred).  May be issued again on the same call (same result)."""
+    pend = call.pending
+    if pend is None:
+        return None, 0
+    common, mid, flat, cut, _ws, _d_emb = pend
+    _lib.check(_lib.lib().hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
+    return flat, cut
 
 
 _LAST_TD = [None]        # d loss / d q of the TdLossFn forward that just ran (picked up by td_loss())
@@ -1397,7 +1423,7 @@ _TD_STEP = threading.local()      # .args = (sel, target, weights, loss_fn) whil
 
 
 def td_step(model, x: torch.Tensor, edge_index, graph_indices=None, ptr=None, *, sel: torch.Tensor, target: torch.Tensor,
-            weights: Optional[torch.Tensor] = None, loss_fn: str = "mse"):
+            weights: Optional[torch.Tensor] = None, loss_fn: str = "mse", defer_lower: bool = False):
     """One DQN update on a batch in its fused form: ``q = model(x, edge_index, graph_indices, ptr)``,
     ``loss, td = td_loss(q, sel, target, weights, loss_fn)``, ``backward(loss)`` -- returns ``(loss, td, q)`` with every
     parameter's ``.grad`` set, same values as those three calls (``td`` and the gradients bit-identical).
@@ -1407,7 +1433,11 @@ def td_step(model, x: torch.Tensor, edge_index, graph_indices=None, ptr=None, *,
     forward kernel forms it in its tail: no launch between the network's forward and backward, ``loss`` is written by the
     backward's reduce launch (``hexgnn_qnet_forward_td`` / ``hexgnn_qnet_backward_flat_td``).  A ``sel[g]`` outside graph g
     makes ``loss`` / ``td[g]`` NaN and raises at the next ``GraphStructure.check()`` (status 16).  Anything else (several
-    selections per graph, graphs above 128 nodes, frozen parameters, ``--noisy_dqn``) runs the three calls."""
+    selections per graph, graphs above 128 nodes, frozen parameters, ``--noisy_dqn``) runs the three calls.
+
+    ``defer_lower=True`` returns ``(loss, td, q, call)`` with only the first stage of the staged backward issued (see
+    ``qnet_direct_backward``); ``finish_backward(call)`` issues the rest (a no-op returning (None, 0) where the step did not
+    take the fused path and ran whole)."""
     if not x.is_cuda:
         raise _lib.HexGnnError("td_step runs only on the MI355X HIP path (no CPU fallback)")
     dev = x.device
@@ -1429,11 +1459,24 @@ def td_step(model, x: torch.Tensor, edge_index, graph_indices=None, ptr=None, *,
     td = call.td if call is not None else None
     if td is None:
         loss, tde = td_loss(q, sel, target, weights, loss_fn)
+        direct = getattr(loss, "_hex_direct", None)
+        if defer_lower and direct is not None and _GRAD_STAGE_HOOK is None and not direct[0].layered:
+            loss.__dict__.pop("_hex_direct", None)
+            qnet_direct_backward(direct[0], direct[1], None, defer_lower=True)
+            direct[0].done = True
+            return loss, tde, q, direct[0]
         backward(loss)
+        if defer_lower:
+            if call is None:
+                call = _QNetCall()
+            call.pending = None
+            return loss, tde, q, call
         return loss, tde, q
     tb, n, b = td
-    qnet_direct_backward(call, tb[:n], None)
+    qnet_direct_backward(call, tb[:n], None, defer_lower=defer_lower and _GRAD_STAGE_HOOK is None)
     call.done = True
+    if defer_lower:
+        return tb[n + 2 * b], tb[n:n + b], q, call
     return tb[n + 2 * b], tb[n:n + b], q
 
 

@@ -6,6 +6,9 @@
 * SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE -> share of LDS-array cycles lost to bank conflicts; SQ_WAIT_ANY / SQ_WAVE_CYCLES
 
 Usage: python profiles/pmc_to_json.py gpurun_out/p_r02 fp32 f16x3 > profiles/r02/traffic_pmc.json
+       python profiles/pmc_to_json.py --by-tag gpurun_out/p_r04 L256 S256 MIX > profiles/r04/traffic_pmc.json
+       (round 4: one entry per bench configuration, {"L256": {kernel: ...}, "S256": ..., "MIX": ...}; bench.py reads the entry of
+       the configuration it runs)
 """
 import collections
 import csv
@@ -14,7 +17,7 @@ import os
 import sys
 
 KERNELS = ("qnet_fwd_kernel", "qnet_bwd_kernel", "sage_dw_kernel", "sage_dw16_kernel", "sage_hidden_fwd_kernel",
-           "sage_hidden_bwd_kernel")
+           "sage_hidden_bwd_kernel", "sage_stack_fwd_kernel", "sage_stack_bwd_kernel")
 N_SIMD = 256 * 4
 
 
@@ -64,6 +67,10 @@ def main(root, mode):
 
 
 if __name__ == "__main__":
+    if sys.argv[1] == "--by-tag":
+        root = sys.argv[2]
+        print(json.dumps({tag: main(root, tag) for tag in sys.argv[3:]}, indent=1))
+        sys.exit(0)
     root = sys.argv[1]
     res = {}
     for mode in sys.argv[2:]:

@@ -13,13 +13,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 @pytest.mark.timeout(600)
-@pytest.mark.parametrize("data,issue", [("D0", "--graph"), ("D1", "--graph"), ("D1", "--eager")])
-def test_bench_two_ranks_gloo_rehearsal(data, issue):
-    """--graph: each rank replays its captured step, one all-reduce after the replay.  --eager: the staged backward hands
-    the two halves of the flat gradient buffer to GradSync from inside loss.backward() (the overlap path; through gloo
-    the segments are reduced synchronously, same arithmetic)."""
+@pytest.mark.parametrize("config,data,issue", [("S256", "D0", "--graph"), ("S256", "D1", "--graph"), ("S256", "D1", "--eager"),
+                                               ("S256", "D1", "--split-graph"), ("MIX", "D0", "--split-graph")])
+def test_bench_two_ranks_gloo_rehearsal(config, data, issue):
+    """--graph (the default): each rank replays its captured step, one all-reduce after the replay.  --split-graph (round 4):
+    the step as TWO captured graphs split at the staged backward's hand-over, the first gradient segment's all-reduce started
+    between their replays.  --eager: the staged backward hands the two halves of the flat gradient buffer to GradSync from
+    inside loss.backward().  Through gloo the segments are reduced synchronously, same arithmetic.  MIX: the ragged batch runs
+    on the layer-major kernels, whose backward is not staged -- the split step degrades to one all-reduce behind the second
+    (empty) graph, and the one-launch stack kernels leave 64 CUs to the collective's kernels (hexgnn_stack_reserve_cus)."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", "S256",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--config", config,
            "--data", data, "--steps", "6", "--warmup", "2", "--preheat-ms", "20", "--no-cpu-baseline", "--no-split", issue]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=540)
     assert r.returncode == 0, r.stderr[-2000:]
@@ -31,8 +35,8 @@ def test_bench_two_ranks_gloo_rehearsal(data, issue):
     assert out["scaling"] == "weak" and out["value"] > 0
     assert abs(out["value"] - 512 / (out["ms_per_step"] * 1e-3)) < 1e-6 * out["value"]
     assert out["config"]["collective"]["backend"].startswith("gloo")
-    assert out["config"]["collective"]["overlapped_with_backward"] == (issue == "--eager")
-    assert out["config"]["hip_graph"] == (issue == "--graph")
+    assert out["config"]["collective"]["overlapped_with_backward"] == (issue != "--graph")
+    assert out["config"]["hip_graph"] == (issue != "--eager")
 
 
 @pytest.mark.timeout(900)

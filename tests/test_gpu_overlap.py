@@ -165,6 +165,30 @@ def test_rccl_call_sequence_on_a_one_rank_group():
         for k, p in hip.named_parameters():
             if g_one[k] is not None:
                 assert torch.equal(p.grad, g_one[k]), k
+        # round 4: the step as TWO captured graphs split at the staged backward's hand-over (what `bench.py --gpus N` replays):
+        # replay 1, all-reduce of the finished tail segment (async, RCCL's stream), replay 2 beside it, all-reduce of the
+        # head segment, wait -- gradients equal the one-graph step's, bit for bit (AVG over one rank)
+        from gnn_hex_amd.graphs import GraphedSplitStep
+
+        def first():
+            for p in params:
+                p.grad = None
+            loss, _, _, call = ops.td_step(hip, xh, data[1], data[2], data[3], sel=data[4], target=data[5], defer_lower=True)
+            return loss, call
+
+        sstep = GraphedSplitStep(first, ops.finish_backward, params)
+        assert sstep.flat is not None and 0 < sstep.cut < sstep.total == n
+        for _ in range(2):
+            sstep.replay_first()
+            sync.reduce_segment(sstep.flat, sstep.cut, sstep.total)
+            sstep.replay_second()
+            sync.reduce_segment(sstep.flat, 0, sstep.cut)
+            assert len(sync._segments) == 2 and all(w is not None for _, _, w in sync._segments)
+            assert sync.all_reduce() == n
+        torch.cuda.synchronize()
+        for k, p in hip.named_parameters():
+            if g_one[k] is not None:
+                assert torch.equal(p.grad, g_one[k]), k
         # --noisy_dqn=True with the overlap switched on: the advantage linear's effective weight mu + sigma * eps
         # is no leaf, its gradient must not be all-reduced in place inside the backward -- the staging is skipped and the
         # finished mu / sigma gradients go through the bucket.  One rank: gradients unchanged, no "more than one backward"
