@@ -924,6 +924,8 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                           : (a.agg0 ? reinterpret_cast<float*>(a.agg0 + a.astride * (size_t)it) : nullptr);
         const float* bias = BWD ? nullptr : reinterpret_cast<const float*>(a.b0 + a.wstride * (size_t)it);
         const int relu = BWD ? 1 : ((l != a.last_of_stack) || a.relu_last);
+        const float relu_lo = relu ? 0.f : -__builtin_inff();
+        (void)relu_lo;
         const __amdgpu_buffer_rsrc_t xr_ = slab_rsrc(xin);
         constexpr int KS = BWD ? 1 : 0;
         (void)KS;
@@ -942,8 +944,12 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 }
             }
         }
+        // (round 4, VALU diet: v_mfma_f32_16x16x4_f32 does not overlap VALU work on its SIMD, every VALU instruction is matrix
+        // time lost.  With the LDS row copy the first neighbour slot lands in the sums directly: no zero fill, no `0 + x` add)
+        if (!RL::on || wmax == 0) {
 #pragma unroll
-        for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         f32x4 tb[RL::on ? 3 : GS::kWin][NT];
         float rs[kRing] = {0.f, 0.f, 0.f, 0.f};   // backward, LDS path: 1 / deg of the rows in the global landing ring
         (void)rs;
@@ -967,8 +973,9 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
             }
             static_for_<0, kEll>([&](auto kk) {
                 constexpr int k = decltype(kk)::value;
-                if constexpr (GL::add_gap(k) == Q) {
+                if constexpr (GL::add_gap(k) == Q && k > 0) {
                     if (k < wmax) {
+                        asm volatile("" ::: "memory");        // (keeps hipcc from turning the block into "add, then select")
 #pragma unroll
                         for (int c = 0; c < NT; ++c) ag[c] += tb[2][c];       // (backward: the LDS rows are pre-scaled)
                     }
@@ -976,6 +983,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 if constexpr ((kV3 ? kGt + k + kRing - 1 : GL::gadd_gap(k)) == Q) {
                     constexpr int rb = kV3 ? k % kRing : k % 2;
                     if (gneed & (1u << k)) {
+                        asm volatile("" ::: "memory");
 #pragma unroll
                         for (int c = 0; c < NT; ++c) {
                             f32x4 v;
@@ -991,10 +999,14 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 constexpr int k = decltype(kk)::value;
                 if constexpr (GL::rd_gap(k) == Q) {
                     if (k < wmax) {
+                        asm volatile("" ::: "memory");
                         const unsigned lo = (k & 1) ? (loff[k >> 1] >> 16) : (loff[k >> 1] & 0xffffu);
                         const f32x4* lr = reinterpret_cast<const f32x4*>(lbase + lo);
 #pragma unroll
-                        for (int c = 0; c < NT; ++c) tb[2][c] = lr[4 * c];
+                        for (int c = 0; c < NT; ++c) {
+                            if constexpr (k == 0) ag[c] = lr[4 * c];          // slot 0 (gap 0, ahead of every add): straight into the sums
+                            else tb[2][c] = lr[4 * c];
+                        }
                     }
                 }
                 if constexpr ((kV3 ? kGt + k : GL::rd_gap(k)) == Q) {
@@ -1114,7 +1126,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 for (int t = 0; t < NT; ++t) {
                     f32x4 v = acc[t] + br[4 * t];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) v[q] = (v[q] > 0.f || !relu) ? v[q] : 0.f;
+                    for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], relu_lo);       // (one v_max; was compare + select)
                     if (dead) v = kNan4;
                     buf_store_coh(v, or_, oo + 64 * t);
                     xs[t] = v;

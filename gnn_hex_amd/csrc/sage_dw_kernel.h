@@ -22,7 +22,7 @@ struct DwArgs {
 // VT > 0: the last VT of a regular wave's input-feature tiles are not run on the matrix pipe but as a register-tiled fp32
 // FMA block on the VALU (4 x VT outputs per lane, operands from the same LDS chunk): the vector pipe is a second fp32 pipe
 // of the same peak that otherwise idles in this kernel, and the k order of every sum is the MFMA's (ascending rows).
-template <int NT, int VT = 0, int E = 2> struct DwShape {
+template <int NT, int VT = 0, int E = 2, int MV = 0> struct DwShape {
     static constexpr bool kBal = NT >= 4;
     static constexpr int kWaves = kBal ? NT + 1 : NT;
     static constexpr int kExt = kBal ? E : 0;                    // input-feature tiles of the extra wave
@@ -37,9 +37,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #define HEXGNN_DW_RH 16
 #endif
 
-template <int NT, int VT = 0, int E = 2>
-__global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
-    using SH = DwShape<NT, VT, E>;
+// MV = 1 (NT >= 4, E = 2): the extra wave hands its last tile (output tile NT-1 x input tile 2NT-1) to wave 2, so that the SIMD
+// pairs (w, w + 4) carry 24 / 24 / 25 / 25 MFMAs per k-step instead of 24 / 24 / 24 / 26.
+template <int NT, int VT = 0, int E = 2, int MV = 0>
+__global__ __launch_bounds__((64 * DwShape<NT, VT, E, MV>::kWaves)) void sage_dw_kernel(DwArgs a, float* __restrict__ part) {
+    using SH = DwShape<NT, VT, E, MV>;
+    constexpr bool kMove = MV == 1 && SH::kBal && E == 2 && VT == 0;
     constexpr int HP = 16 * NT;
     constexpr int RH = HEXGNN_DW_RH;                    // rows per chunk (a multiple of 4); two chunk buffers
     constexpr int AS = 2 * HP + 16;                     // == 16 (mod 32): conflict-free fragment reads
@@ -60,7 +63,7 @@ __global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_ker
     const int r_beg = s * a.rows_per_slice;
     const int r_end = min(a.n, r_beg + a.rows_per_slice);
 
-    constexpr int kAcc = NB > NE * NT ? NB : NE * NT;
+    constexpr int kAcc = (NB + (kMove ? 1 : 0)) > NE * NT ? NB + (kMove ? 1 : 0) : NE * NT;
     f32x4 acc[kAcc];         // regular wave: tile t < NB; extra wave: [NE * t + tb]
 #pragma unroll
     for (int t = 0; t < kAcc; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -141,6 +144,13 @@ __global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_ker
                     const float bv = Ab[(4 * ks + kq) * AS + 16 * t + m];
                     acc[t] = mfma16x16x4(av, bv, acc[t]);
                 }
+                if constexpr (kMove) {
+                    if (w == 2) {      // wave-uniform: the tile handed over by the extra wave
+                        const float av2 = Gb[(4 * ks + kq) * GS + 16 * (NT - 1) + m];
+                        const float bv2 = Ab[(4 * ks + kq) * AS + 16 * (2 * NT - 1) + m];
+                        acc[NB] = mfma16x16x4(av2, bv2, acc[NB]);
+                    }
+                }
                 if constexpr (VT > 0) {
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) {
@@ -170,7 +180,10 @@ __global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_ker
                 for (int t = 0; t < NT; ++t) {
                     const float av = Gb[(4 * ks + kq) * GS + 16 * t + m];
 #pragma unroll
-                    for (int tb = 0; tb < NE; ++tb) acc[NE * t + tb] = mfma16x16x4(av, bv[tb], acc[NE * t + tb]);
+                    for (int tb = 0; tb < NE; ++tb) {
+                        if constexpr (kMove) { if (t == NT - 1 && tb == NE - 1) continue; }
+                        acc[NE * t + tb] = mfma16x16x4(av, bv[tb], acc[NE * t + tb]);
+                    }
                 }
             }
         }
@@ -190,6 +203,12 @@ __global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_ker
                 for (int j = 0; j < VI; ++j)
                     slab[(size_t)(16 * w + 4 * oq + oo) * (2 * HP) + 16 * NB + VT * ig + j] = vacc[oo][j];
         }
+        if constexpr (kMove) {
+            if (w == 2) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) slab[(size_t)(16 * (NT - 1) + 4 * kq + q) * (2 * HP) + 16 * (2 * NT - 1) + m] = acc[NB][q];
+            }
+        }
         bsum += __shfl_xor(bsum, 16);
         bsum += __shfl_xor(bsum, 32);
         if (kq == 0) slab[(size_t)HP * 2 * HP + 16 * w + m] = bsum;
@@ -199,8 +218,10 @@ __global__ __launch_bounds__((64 * DwShape<NT, VT, E>::kWaves)) void sage_dw_ker
 #pragma unroll
             for (int tb = 0; tb < NE; ++tb)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
+                for (int q = 0; q < 4; ++q) {
+                    if constexpr (kMove) { if (t == NT - 1 && tb == NE - 1) continue; }
                     slab[(size_t)(16 * t + 4 * kq + q) * (2 * HP) + 16 * (2 * NT - NE + tb) + m] = acc[NE * t + tb][q];
+                }
     }
 }
 

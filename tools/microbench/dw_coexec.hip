@@ -21,14 +21,14 @@ using namespace hexgnn;
 
 constexpr int NT = 7, HP = 16 * NT, LAYERS = 16, N = 31488, S = 32, RPS = 992;
 
-template <int VT, int E>
+template <int VT, int E, int MV = 0>
 static float run(const DwArgs& a, float* part, int reps, hipStream_t st) {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    for (int i = 0; i < 3; ++i) sage_dw_kernel<NT, VT, E><<<dim3(S, LAYERS), 64 * DwShape<NT, VT, E>::kWaves, 0, st>>>(a, part);
+    for (int i = 0; i < 3; ++i) sage_dw_kernel<NT, VT, E, MV><<<dim3(S, LAYERS), 64 * DwShape<NT, VT, E, MV>::kWaves, 0, st>>>(a, part);
     CK(hipStreamSynchronize(st));
     CK(hipEventRecord(e0, st));
-    for (int i = 0; i < reps; ++i) sage_dw_kernel<NT, VT, E><<<dim3(S, LAYERS), 64 * DwShape<NT, VT, E>::kWaves, 0, st>>>(a, part);
+    for (int i = 0; i < reps; ++i) sage_dw_kernel<NT, VT, E, MV><<<dim3(S, LAYERS), 64 * DwShape<NT, VT, E, MV>::kWaves, 0, st>>>(a, part);
     CK(hipEventRecord(e1, st));
     CK(hipEventSynchronize(e1));
     float ms = 0.f;
@@ -94,6 +94,10 @@ int main(int argc, char** argv) {
         if (round == 0) check("<4,1>");
         t = run<0, 1>(a, part, reps, st); printf("round %d  <VT 0, E 1> %7.1f us  %6.1f TFLOP/s\n", round, t, flop / t * 1e-6);
         if (round == 0) check("<0,1>");
+        CK(hipMemset(part, 0xff, sizeof(float) * pwords));
+        t = run<0, 2, 1>(a, part, reps, st); printf("round %d  <VT 0, E 2, MV 1> %7.1f us  %6.1f TFLOP/s\n", round, t, flop / t * 1e-6);
+        if (round == 0) check("<0,2,1>");
+        t = run<0, 2>(a, part_ref, reps, st); printf("round %d  <VT 0, E 2> again %7.1f us  %6.1f TFLOP/s\n", round, t, flop / t * 1e-6);
     }
     return 0;
 }
