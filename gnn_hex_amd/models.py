@@ -31,7 +31,7 @@ import torch
 from torch import Tensor
 from torch.nn import Linear, ModuleList, Tanh
 
-from . import ops
+from . import ops, qvalues
 from .data import Batch, Data
 
 
@@ -637,6 +637,9 @@ class DuellingTwoHeaded(torch.nn.Module):
                         q, out_v = outs if mode == 1 else (outs, None)
                         if mode == 0:
                             q._hex_call = call          # lets ops.td_loss / ops.backward run this backward directly
+                            # (the loss expression of an unmodified training loop -- q[actions], F.mse_loss, loss.backward()
+                            # -- recognised on the tensor itself: gnn_hex_amd/qvalues.py)
+                            q = qvalues.wrap_q(q)
                     else:
                         q, out_v, call = ops.qnet_direct_forward(*fargs)
                     self.__dict__["_fca"] = call

@@ -1379,6 +1379,7 @@ def td_loss(q: torch.Tensor, sel: torch.Tensor, target: torch.Tensor, weights: O
     ``weights`` is None."""
     if q.device.type != "cuda":
         raise _lib.HexGnnError("td_loss runs only on the MI355X HIP path (no CPU fallback)")
+    q = q.__dict__.get("_hex_plain", q)      # (the model's QValues wrapper: the ordinary tensor underneath, qvalues.py)
     _LAST_TD[0] = None
     out = TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])
     loss = out[0]
@@ -1455,6 +1456,7 @@ def td_step(model, x: torch.Tensor, edge_index, graph_indices=None, ptr=None, *,
         q = model(x, edge_index, graph_indices, ptr)
     finally:
         _TD_STEP.args = None
+    q = q.__dict__.get("_hex_plain", q)      # (td_step hands back the ordinary tensor, not the QValues wrapper)
     call = getattr(q, "_hex_call", None)
     td = call.td if call is not None else None
     if td is None:
