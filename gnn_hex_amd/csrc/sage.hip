@@ -950,7 +950,12 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
 #pragma unroll
             for (int c = 0; c < NT; ++c) ag[c] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        f32x4 tb[RL::on ? 3 : GS::kWin][NT];
+        // landing buffers with the LDS row copy: [ring of the rows fetched from global memory | one for the LDS slots].  The
+        // backward kernel sat at 256 VGPRs + 132 B of scratch per lane with a global ring of two: ONE buffer there (the remote
+        // rows of a wave are few, and their load latency is exposed at the add either way), no spills
+        constexpr int kGRing = kV3 ? 3 : (BWD ? 1 : 2);
+        constexpr int kLb = RL::on ? (kV3 ? 2 : kGRing) : 0;      // the LDS slots' buffer (kV3: shared with the tail ring's third)
+        f32x4 tb[RL::on ? (kV3 ? 3 : kGRing + 1) : GS::kWin][NT];
         float rs[kRing] = {0.f, 0.f, 0.f, 0.f};   // backward, LDS path: 1 / deg of the rows in the global landing ring
         (void)rs;
         if constexpr (!kV3) {
@@ -977,11 +982,11 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                     if (k < wmax) {
                         asm volatile("" ::: "memory");        // (keeps hipcc from turning the block into "add, then select")
 #pragma unroll
-                        for (int c = 0; c < NT; ++c) ag[c] += tb[2][c];       // (backward: the LDS rows are pre-scaled)
+                        for (int c = 0; c < NT; ++c) ag[c] += tb[kLb][c];     // (backward: the LDS rows are pre-scaled)
                     }
                 }
-                if constexpr ((kV3 ? kGt + k + kRing - 1 : GL::gadd_gap(k)) == Q) {
-                    constexpr int rb = kV3 ? k % kRing : k % 2;
+                if constexpr ((kV3 ? kGt + k + kRing - 1 : (BWD ? GL::rd_gap(k) + GL::stride : GL::gadd_gap(k))) == Q) {
+                    constexpr int rb = kV3 ? k % kRing : k % kGRing;
                     if (gneed & (1u << k)) {
                         asm volatile("" ::: "memory");
 #pragma unroll
@@ -1005,12 +1010,12 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
 #pragma unroll
                         for (int c = 0; c < NT; ++c) {
                             if constexpr (k == 0) ag[c] = lr[4 * c];          // slot 0 (gap 0, ahead of every add): straight into the sums
-                            else tb[2][c] = lr[4 * c];
+                            else tb[kLb][c] = lr[4 * c];
                         }
                     }
                 }
                 if constexpr ((kV3 ? kGt + k : GL::rd_gap(k)) == Q) {
-                    constexpr int rb = kV3 ? k % kRing : k % 2;
+                    constexpr int rb = kV3 ? k % kRing : k % kGRing;
                     if (gneed & (1u << k)) {
 #pragma unroll
                         for (int c = 0; c < NT; ++c) {
