@@ -577,6 +577,18 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int gi = blockIdx.x;
     QSTAMP(0, 0, 0);
+    // Requested before anything that depends on the graph (round 4): W_r of the first hidden layer (half B) and the raw first
+    // layer's weights -- their round trips overlap the chain gptr -> rowptr -> columns instead of following it.
+    constexpr int kStage1 = (LD::kHalf + 511) / 512, kStage0 = (2 * HP * kSmallCin / 4 + 511) / 512;
+    f32x4 wstg1[kStage1], wstg0[kStage0];
+    {
+        const f32x4* src1 = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[a.L > 1 ? 1 : 0]) + kHalf;
+#pragma unroll
+        for (int k = 0; k < kStage1; ++k) { const int i = tid + 512 * k; if (a.L > 1 && i < kHalf) wstg1[k] = src1[i]; }
+        const f32x4* src0 = reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[0]);
+#pragma unroll
+        for (int k = 0; k < kStage0; ++k) { const int i = tid + 512 * k; if (i < 2 * HP * kSmallCin / 4) wstg0[k] = src0[i]; }
+    }
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
     if (cnt > kRows) {
@@ -622,17 +634,21 @@ __global__ __launch_bounds__(512) void qnet_fwd_kernel(QFwdArgs a) {
     if (tid < XS) xbuf[kRows * XS + tid] = 0.f;                      // the gather's filler row
 
     // ---- stage W_r of layer 1 into half B (the self half runs first); first-layer scratch lives in half A ----
-    if (a.L > 1)
-        copy_f4_to_lds<(LD::kHalf + 511) / 512>(wbuf + kHalf, reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[1]) + kHalf, kHalf);
+    if (a.L > 1) {
+#pragma unroll
+        for (int k = 0; k < kStage1; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = wstg1[k]; }
+    }
     NbrRegs nbr;
     float* s_w0 = reinterpret_cast<float*>(lds + LD::off_scr_first);  // [2][HP][8]
     float* s_f = s_w0 + 2 * HP * kSmallCin;                          // [kRows][16]: agg0 | x0
     {
         // raw features of the graph's rows -> LDS (x0 half of s_f), first-layer weights -> LDS: all independent
         // global loads, one barrier; the neighbour sums then run on LDS only.
-        copy_f4_to_lds<(2 * HP * kSmallCin / 4 + 511) / 512>(reinterpret_cast<f32x4*>(s_w0),
-                                                              reinterpret_cast<const f32x4*>(a.wpack + a.fwd_off[0]),
-                                                              2 * HP * kSmallCin / 4);
+#pragma unroll
+        for (int k = 0; k < kStage0; ++k) {
+            const int i = tid + 512 * k;
+            if (i < 2 * HP * kSmallCin / 4) reinterpret_cast<f32x4*>(s_w0)[i] = wstg0[k];
+        }
 #pragma unroll
         for (int i = tid; i < kRows * kSmallCin; i += 512) {
             const int rr = i / kSmallCin, qq = i % kSmallCin;
@@ -1042,10 +1058,34 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     const int r = lane & 15, g = lane >> 4;
     const int gi = blockIdx.x;
     QSTAMP(1, 0, 0);
+    const int H = a.H, L = a.L;
+    // Requested before anything that depends on the graph (round 4): the top layer's W_r part (staged into half B below) and this
+    // thread's share of the value MLP's first-layer weights (d pooled = v0_w^T dz, three barriers further down) -- their round
+    // trips then overlap the chain gptr -> rowptr -> columns instead of following it.
+    constexpr int kStage = (kHalf + 511) / 512;
+    f32x4 wstg[kStage];
+    if (L > 1) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]) + kHalf;
+#pragma unroll
+        for (int k = 0; k < kStage; ++k) {
+            const int i = tid + 512 * k;
+            if (i < kHalf) wstg[k] = src[i];
+        }
+    }
+    constexpr int kVW = 14;           // H / 2 <= 56 hidden units over four k phases
+    f32x4 vw[kVW];
+    {
+        const int cq = tid & 127, kg = tid >> 7;
+        const f32x4* wq = reinterpret_cast<const f32x4*>(a.v0_w) + cq;
+#pragma unroll
+        for (int j = 0; j < kVW; ++j) {
+            const int k = kg + 4 * j;
+            vw[j] = (a.mode != 2 && cq < H && k < H / 2) ? wq[(size_t)k * H] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
     const int r0 = a.gptr[gi], r1 = a.gptr[gi + 1];
     const int cnt = r1 - r0;
     if (cnt > kRows) { if (tid == 0) atomicOr(a.status, 2); return; }
-    const int H = a.H, L = a.L;
     const int lrow = wave * 16 + r;
     const bool rvalid = lrow < cnt;
     const bool wactive = wave * 16 < cnt;
@@ -1078,19 +1118,11 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
     float* s_max = reinterpret_cast<float*>(lds + LD::off_max);      // per-wave maxima (math 1)
     if (tid < 16) s_max[tid] = 0.f;
     if (tid < XS) dbuf[kRows * XS + tid] = 0.f;                      // the gather's filler row
-    constexpr int kStage = (kHalf + 511) / 512;
 
     // stage the W_r part of the top layer into half B (the self half runs first; everything else arrives by LDS-DMA)
     if (L > 1) {
-        const f32x4* src = reinterpret_cast<const f32x4*>(a.wpack + a.bwd_off[L - 1]) + kHalf;
-        f32x4 tmp[kStage];
 #pragma unroll
-        for (int k = 0; k < kStage; ++k) {
-            const int i = tid + 512 * k;
-            if (i < kHalf) tmp[k] = src[i];
-        }
-#pragma unroll
-        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = tmp[k]; }
+        for (int k = 0; k < kStage; ++k) { const int i = tid + 512 * k; if (i < kHalf) wbuf[kHalf + i] = wstg[k]; }
     }
 
     // ---- head tail backward; scratch aliases dbuf (not written before the first barrier A) ----
@@ -1133,9 +1165,8 @@ __global__ __launch_bounds__(512) void qnet_bwd_kernel(QBwdArgs a) {
             const int cq = tid & 127, kg = tid >> 7;
             f32x4 p4 = f32x4{0.f, 0.f, 0.f, 0.f};
             if (cq < H) {
-                const f32x4* wq = reinterpret_cast<const f32x4*>(a.v0_w) + cq;
-#pragma unroll 4
-                for (int k = kg; k < H2; k += 4) p4 += wq[(size_t)k * H] * s_dz[k];
+#pragma unroll
+                for (int j = 0; j < kVW; ++j) { const int k = kg + 4 * j; if (k < H2) p4 += vw[j] * s_dz[k]; }
             }
             if (kg > 0 && cq < H) reinterpret_cast<f32x4*>(s_part)[(kg - 1) * HP + cq] = p4;
             __syncthreads();
