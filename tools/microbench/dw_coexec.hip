@@ -19,7 +19,10 @@ using namespace hexgnn;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-constexpr int NT = 7, HP = 16 * NT, LAYERS = 16, N = 31488, S = 32, RPS = 992;
+#ifndef DW_S
+#define DW_S 32
+#endif
+constexpr int NT = 7, HP = 16 * NT, LAYERS = 16, N = 31488, S = DW_S, RPS = ((N + S - 1) / S + 31) / 32 * 32;
 
 template <int VT, int E, int MV = 0>
 static float run(const DwArgs& a, float* part, int reps, hipStream_t st) {
