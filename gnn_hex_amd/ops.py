@@ -979,20 +979,23 @@ class QNetParamCache:
         self.offsets = (C.c_int64 * len(params))(*offs)
         self.total = o
         self.cut = offs[3 * (1 + tot // 2)] if tot >= 3 else 0      # flat position where the staged backward splits
+        # (post-accumulate-grad hooks -- optimizer-in-backward, FSDP-style reducers -- hang off AccumulateGrad, which the direct
+        # path never runs: such parameters take the autograd form, like tensor hooks do)
         self.direct_ok = all(p.is_leaf and p.requires_grad and p.dtype == torch.float32 and p.is_contiguous() and p.is_cuda
-                             and not p._backward_hooks for p in params)
+                             and not p._backward_hooks and not getattr(p, "_post_accumulate_grad_hooks", None) for p in params)
 
     def valid(self) -> bool:
         """Pointers unchanged (parameters updated in place keep them; ``.to()`` / ``p.data = ...`` do not) and the flags
         ``direct_ok`` was derived from still hold (a parameter frozen or given a tensor hook since)."""
         ps = self.params
         return list(map(torch.Tensor.data_ptr, ps)) == self.ptrs and \
-            self.direct_ok == all(p.requires_grad and not p._backward_hooks for p in ps)
+            self.direct_ok == all(p.requires_grad and not p._backward_hooks and
+                                  not getattr(p, "_post_accumulate_grad_hooks", None) for p in ps)
 
 
 class _QNetCall:
     """Everything one fused forward leaves behind for its backward (plain attributes: cheaper than ctx.save_for_backward)."""
-    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered", "td", "pending")
+    __slots__ = ("cache", "gs", "gptr", "dims", "x", "bufs", "math", "sink", "gp", "done", "layered", "td", "pending", "versions")
 
 
 _HP_CACHE = {}
@@ -1070,6 +1073,9 @@ def qnet_direct_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: i
     call.done = False
     call.layered = False
     call.td = td
+    # the backward reads the head tail's weights LIVE (the SAGE layers' from the pack made by this forward): an in-place update
+    # between the two would mix old and new weights without autograd's saved-tensor version check to notice it
+    call.versions = tuple(p._version for p in cache.params[-6:]) if need_bwd else None
     return q, out_v, call
 
 
@@ -1129,6 +1135,7 @@ def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: 
     call.done = False
     call.layered = True
     call.td = None
+    call.versions = tuple(p._version for p in cache.params[-6:]) if need_bwd else None
     return q, out_v, call
 
 
@@ -1225,6 +1232,9 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None, defer_lower: bool = Fa
     half of the hidden layers: the TAIL of the flat buffer is final); ``finish_backward(call)`` runs the rest.  A step captured
     as two HIP graphs split there lets the tail's all-reduce travel while the second graph computes (graphs.GraphedSplitStep)."""
     call.pending = None
+    if call.versions is not None and call.versions != tuple(p._version for p in call.cache.params[-6:]):
+        raise RuntimeError("a head parameter of the model was modified in place between this forward and its backward (the "
+                           "fused backward reads the head tail's weights live); run the backward before optimizer.step()")
     if call.done:
         raise RuntimeError("this forward's backward already ran through ops.backward(loss) (its graph is spent, as after "
                            "loss.backward() without retain_graph)")
@@ -1300,8 +1310,10 @@ def finish_backward(call: "_QNetCall"):
     return flat, cut
 
 
-_LAST_TD = [None]        # d loss / d q of the TdLossFn forward that just ran (picked up by td_loss())
-_UNIT_GRAD = False      # set by backward(): the loss itself is the root of the backward pass, i.e. grad_loss == 1
+# d loss / d q of the TdLossFn forward that just ran on THIS thread (picked up by td_loss()); "the loss is the root of the backward
+# pass" travels on the loss's own autograd node (ctx._hex_unit, set by backward()): TdLossFn.backward runs on the autograd
+# engine's device thread, where neither a module global nor a thread-local of the caller is safe to read
+_TD_TLS = threading.local()
 _ONES = {}
 
 
@@ -1347,7 +1359,7 @@ class TdLossFn(torch.autograd.Function):
                                                 td.data_ptr(), _stream()), "hexgnn_td_loss_forward")
         ctx.save_for_backward(sel, td, w if w is not None else td)
         ctx.dq = dq
-        _LAST_TD[0] = dq
+        _TD_TLS.last = dq
         ctx.has_w, ctx.loss_fn, ctx.shape = w is not None, loss_fn, q.shape
         ctx.mark_non_differentiable(td)
         return loss, td
@@ -1356,7 +1368,7 @@ class TdLossFn(torch.autograd.Function):
     def backward(ctx, gloss, _gtd):
         if gloss is None:
             return None, None, None, None, None
-        if _UNIT_GRAD and ctx.dq is not None:       # the loss is the root: d loss / d q was produced by the forward launch
+        if getattr(ctx, "_hex_unit", False) and ctx.dq is not None:   # the loss is the root: d loss / d q came with the forward launch
             dq, ctx.dq = ctx.dq, None
             return dq.view(ctx.shape), None, None, None, None
         sel, td, w = ctx.saved_tensors
@@ -1380,16 +1392,17 @@ def td_loss(q: torch.Tensor, sel: torch.Tensor, target: torch.Tensor, weights: O
     if q.device.type != "cuda":
         raise _lib.HexGnnError("td_loss runs only on the MI355X HIP path (no CPU fallback)")
     q = q.__dict__.get("_hex_plain", q)      # (the model's QValues wrapper: the ordinary tensor underneath, qvalues.py)
-    _LAST_TD[0] = None
+    _TD_TLS.last = None
     out = TdLossFn.apply(q, sel, target, weights, {"mse": 0, "huber": 1}[loss_fn])
     loss = out[0]
     loss._hex_td_root = True
     call = getattr(q, "_hex_call", None)
-    if call is not None and _LAST_TD[0] is not None and q.dim() == 1 and q.dtype == torch.float32 and q.is_contiguous():
+    last = getattr(_TD_TLS, "last", None)
+    if call is not None and last is not None and q.dim() == 1 and q.dtype == torch.float32 and q.is_contiguous():
         # q is the fused network's own output and d loss / d q exists already: ops.backward(loss) can run the network's
         # backward directly on this thread (no autograd engine, no hop to its device thread and back: ~100 us of host time)
-        loss._hex_direct = (call, _LAST_TD[0])
-    _LAST_TD[0] = None
+        loss._hex_direct = (call, last)
+    _TD_TLS.last = None
     return out
 
 
@@ -1398,7 +1411,6 @@ def backward(loss: torch.Tensor) -> None:
     ``ones_like(loss)`` fill that seeds the pass, and the scaling scatter of ``d loss / d Q`` (the fused forward launch
     already produced it for a unit seed).  Any other tensor falls through to ``loss.backward()``.  Gradients are
     bit-identical to ``loss.backward()``."""
-    global _UNIT_GRAD
     if not getattr(loss, "_hex_td_root", False) or not loss.is_cuda:
         loss.backward()
         return
@@ -1413,11 +1425,14 @@ def backward(loss: torch.Tensor) -> None:
     if one is None:
         one = torch.ones((), dtype=torch.float32, device=loss.device)
         _ONES[key] = one
-    _UNIT_GRAD = True
+    node = loss.grad_fn
+    if node is not None:
+        node._hex_unit = True          # (read by TdLossFn.backward on the engine's thread: this loss IS the root, seed == 1)
     try:
         torch.autograd.backward((loss,), (one,))
     finally:
-        _UNIT_GRAD = False
+        if node is not None:
+            node._hex_unit = False
 
 
 _TD_STEP = threading.local()      # .args = (sel, target, weights, loss_fn) while td_step() runs the model's forward

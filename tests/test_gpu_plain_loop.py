@@ -114,3 +114,29 @@ def test_unrecognised_forms_stay_plain_torch():
         qvalues.set_enabled(True)
     with torch.no_grad():
         assert type(hip(d[0], d[1], d[2], d[3])) is torch.Tensor
+
+
+def test_direct_gradient_guards():
+    """(1) a head parameter updated in place between a forward and its backward is an error (the fused backward reads
+    the head tail's weights live, and nothing else would notice); (2) parameters with post-accumulate-grad hooks
+    (optimizer-in-backward) take the autograd form, where the hook fires."""
+    from gnn_hex_amd import ops
+    hip, d = _setup()
+    q = hip(d[0], d[1], d[2], d[3])
+    loss, _ = ops.td_loss(q, d[4], d[5])
+    with torch.no_grad():
+        hip.maker_head.linear.weight.add_(1e-3)
+    with pytest.raises(RuntimeError, match="modified in place"):
+        ops.backward(loss)
+    # hook -> autograd form, the hook runs
+    fired = []
+    p0 = next(hip.gnn.parameters())
+    h = p0.register_post_accumulate_grad_hook(lambda p: fired.append(p.grad.abs().sum().item()))
+    try:
+        hip.zero_grad(set_to_none=True)
+        q = hip(d[0], d[1], d[2], d[3])
+        F.mse_loss(q[d[4]], d[5]).backward()
+        torch.cuda.synchronize()
+        assert len(fired) == 1 and p0.grad is not None
+    finally:
+        h.remove()
