@@ -54,7 +54,6 @@ __device__ __forceinline__ float wsum_all(float v) {
 }
 
 __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(GradReduceArgs a) {
-    __shared__ float red[3][64];
     int blk = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = a.H, hp = a.hp;
@@ -129,18 +128,26 @@ __global__ __launch_bounds__(256) void qnet_grad_reduce_kernel(GradReduceArgs a)
     }
     blk -= a.n2;
     {                                     // ---- R3
+        // 16 columns x 16 graph phases per block (round 4): with 64 columns x 4 phases a thread walked 64 graphs one dependent
+        // batch of loads after the other, and these blocks -- not the slab sums -- set the length of the launch
         const int H2 = H / 2, H4 = 4 * H;
         const int bx = blk % a.nbx3, k = blk / a.nbx3;
-        const int cl = tid & 63, ph = tid >> 6;
-        const int c = bx * 64 + cl;
+        const int cl = tid & 15, ph = tid >> 4;
+        const int c = bx * 16 + cl;
+        __shared__ float red16[16][17];
         float s = 0.f;
         if (c < H4) {
 #pragma unroll 8
-            for (int g = ph; g < a.b; g += 4) s += a.dz[(size_t)g * H2 + k] * a.pooled[(size_t)g * H4 + c];
+            for (int g = ph; g < a.b; g += 16) s += a.dz[(size_t)g * H2 + k] * a.pooled[(size_t)g * H4 + c];
         }
-        if (ph > 0) red[ph - 1][cl] = s;
+        red16[ph][cl] = s;
         __syncthreads();
-        if (ph == 0 && c < H4) a.d_v0_w[(size_t)k * H4 + c] = s + red[0][cl] + red[1][cl] + red[2][cl];
+        if (ph == 0 && c < H4) {
+            float t = red16[0][cl];
+#pragma unroll
+            for (int j = 1; j < 16; ++j) t += red16[j][cl];          // fixed order: deterministic
+            a.d_v0_w[(size_t)k * H4 + c] = t;
+        }
         if (bx == 0) {
             float p = 0.f;
             if (wave == 0) { for (int g = lane; g < a.b; g += 64) p += a.dz[(size_t)g * H2 + k]; }
@@ -388,7 +395,7 @@ static int qnet_backward_staged_impl(int n, int b, int c_in, int hidden, int tot
         r.n0 = nh * r.blk_per_layer;
         r.n1 = st_small ? (hidden * (2 * c_in + 1) + 3) / 4 : 0;
         r.n2 = st_small ? (hidden + 1 + 3) / 4 : 0;
-        r.nbx3 = (4 * hidden + 63) / 64;
+        r.nbx3 = (4 * hidden + 15) / 16;
         r.n3 = (st_small && mode != 2 && hidden / 2 > 0) ? r.nbx3 * (hidden / 2) : 0;
         r.loss_part = loss_part; r.loss = loss;
         const int n4 = (st_small && loss_part && loss) ? 1 : 0;      // (the block behind the last role: the TD loss's mean)
