@@ -79,6 +79,10 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
         xd._hex_max_nodes = int((ptr[1:] - ptr[:-1]).max())   # largest graph, known from the board size
         eid = ei.to(dev)
         eid._hex_grouped = True           # collated graph by graph (what Batch.from_data_list produces and marks)
+        # ... with the collation's per-graph edge offsets (Batch.from_data_list attaches them; here the graphs were concatenated by
+        # hand): edges are grouped by graph, so graph g's range is the running count of the edges whose source lies in it
+        ecnt = torch.bincount(bv[ei[0]], minlength=int(ptr.numel()) - 1)
+        eid._hex_edge_ptr = torch.cat([torch.zeros(1, dtype=torch.long), ecnt.cumsum(0)]).to(dev)
         batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
                             w=None if wts is None else wts.to(dev), graphs=len(graphs),
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))

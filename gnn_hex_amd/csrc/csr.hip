@@ -182,7 +182,8 @@ __device__ __forceinline__ void csr_grouped_body(int n, int e, int b, const int6
                                                  const int64_t* __restrict__ ptr64, int* __restrict__ gptr_out,
                                                  int* __restrict__ rowptr, int* __restrict__ col,
                                                  int* __restrict__ rowptr_t, int* __restrict__ col_t,
-                                                 float* __restrict__ invdeg, int* __restrict__ status) {
+                                                 float* __restrict__ invdeg, int* __restrict__ status,
+                                                 const int64_t* __restrict__ eptr64 = nullptr) {
     __shared__ int s_start[2][kCsrMaxGraph + 1];   // row starts (local, exclusive prefix), CSR and transpose
     __shared__ int s_cnt[2][kCsrMaxGraph];         // degree histogram, then fill cursors
     __shared__ int s_part[2][256];
@@ -194,7 +195,18 @@ __device__ __forceinline__ void csr_grouped_body(int n, int e, int b, const int6
     if (cnt > kCsrMaxGraph || cnt < 0) { if (tid == 0) atomicOr(status, 8); return; }
     for (int i = tid; i < cnt; i += 256) { s_cnt[0][i] = 0; s_cnt[1][i] = 0; }
     int eb, ee;
-    csr_lower_bound2_256(dst, e, r0, r1, eb, ee);
+    if (eptr64) {
+        // the collation's own edge offsets (what Batch.from_data_list knows when it concatenates the graphs): no search -- three
+        // dependent probe rounds over the edge list otherwise.  The ranges must tile [0, e) in order (checked: status |= 4),
+        // so every edge is seen by exactly one workgroup and validated against that graph's node range below
+        const int64_t a0 = eptr64[g], a1 = eptr64[g + 1];
+        const bool ok = a0 >= 0 && a0 <= a1 && a1 <= (int64_t)e && (g > 0 || a0 == 0) && (g < b - 1 || a1 == (int64_t)e);
+        if (!ok && tid == 0) atomicOr(status, 4);
+        eb = ok ? (int)a0 : 0;
+        ee = ok ? (int)a1 : 0;
+    } else {
+        csr_lower_bound2_256(dst, e, r0, r1, eb, ee);
+    }
     const int ne = ee - eb;
     const bool in_lds = ne <= kCsrLdsEdges;
     __syncthreads();
@@ -320,11 +332,12 @@ struct CsrArgs {
     int n, e, b;
     const int64_t* src; const int64_t* dst; const int* gptr; const int64_t* ptr64;
     int* gptr_out; int* rowptr; int* col; int* rowptr_t; int* col_t; float* invdeg; int* status;
+    const int64_t* eptr64;
 };
 __global__ __launch_bounds__(256) void csr_grouped_pack_kernel(CsrArgs c, PackArgs pa, char* __restrict__ wpack, int nbx) {
     if ((int)blockIdx.x < c.b) {
         csr_grouped_body(c.n, c.e, c.b, c.src, c.dst, c.gptr, c.ptr64, c.gptr_out, c.rowptr, c.col, c.rowptr_t, c.col_t, c.invdeg,
-                         c.status);
+                         c.status, c.eptr64);
     } else {
         // (this kernel's static LDS allows few workgroups per CU: a pack workgroup takes kPackPer of the pack kernel's blocks, so
         // that CSR + pack workgroups are resident in one round)
@@ -427,6 +440,15 @@ int hexgnn_csr_build_grouped_pack(int n, int e, int b, const int64_t* src, const
                                   float* invdeg, int* status, int c_in, int hidden, int num_layers,
                                   const float* const* wl, const float* const* bl, const float* const* wr, void* wpack,
                                   hexgnn_stream_t stream_) {
+    return hexgnn_csr_build_grouped_pack_e(n, e, b, src, dst, gptr, ptr64, nullptr, gptr_out, rowptr, col, rowptr_t, col_t, invdeg,
+                                           status, c_in, hidden, num_layers, wl, bl, wr, wpack, stream_);
+}
+
+int hexgnn_csr_build_grouped_pack_e(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                                    const int64_t* ptr64, const int64_t* edge_ptr64, int* gptr_out, int* rowptr, int* col,
+                                    int* rowptr_t, int* col_t, float* invdeg, int* status, int c_in, int hidden,
+                                    int num_layers, const float* const* wl, const float* const* bl,
+                                    const float* const* wr, void* wpack, hexgnn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (n < 0 || e < 0 || b < 1 || !rowptr || !rowptr_t || !status || (!gptr && !ptr64) || (ptr64 && !gptr_out) ||
         (n > 0 && !invdeg) || !wl || !bl || !wr || !wpack)
@@ -439,7 +461,7 @@ int hexgnn_csr_build_grouped_pack(int n, int e, int b, const int64_t* src, const
     PackArgs pa;
     rc = fill_pack_args(p, c_in, hidden, wl, bl, wr, &pa);
     if (rc != HEXGNN_OK) return rc;
-    const CsrArgs c{n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg, status};
+    const CsrArgs c{n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg, status, edge_ptr64};
     const int nbx = 2 * p.nt * p.nt;
     KernelTimer kt(HEXGNN_K_CSR, stream);
     csr_grouped_pack_kernel<<<b + (nbx * p.L + kPackPer - 1) / kPackPer, 256, 0, stream>>>(c, pa, (char*)wpack, nbx);

@@ -94,6 +94,9 @@ class Batch(Data):
         out.x._hex_max_nodes = max(sizes)
         out.x._hex_hint_version = out.x._version
         out.edge_index._hex_grouped = True      # collated graph by graph: the one-launch CSR build applies
+        # ... and knows every graph's edge range without searching for it (torch_geometric keeps the same slices in _slice_dict)
+        ecnt = torch.tensor([0] + [int(d.edge_index.shape[1]) for d in data_list], dtype=torch.long)
+        out.edge_index._hex_edge_ptr = ecnt.cumsum(0).to(device)
         return out
 
     @property

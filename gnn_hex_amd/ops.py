@@ -7,6 +7,7 @@ runs in the hand-written kernels under gnn_hex_amd/csrc; there is no eager/PyTor
 from __future__ import annotations
 
 import ctypes as C
+import os
 import threading
 from typing import List, Optional, Sequence
 
@@ -16,6 +17,7 @@ from . import _lib
 
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_USE_EDGE_PTR = os.environ.get("HEXGNN_NO_EDGE_PTR", "") in ("", "0")      # (A/B switch: ignore the collation's edge offsets)
 
 
 def _stream() -> int:
@@ -165,10 +167,15 @@ class GraphStructure:
         if pack is not None:
             # + the weight pack of the network call that follows, in the same launch: pack = (c_in, hidden, layers, wl, bl, wr
             # pointer arrays, wpack address); that call is then given no weight arrays
-            _lib.check(_lib.lib().hexgnn_csr_build_grouped_pack(
-                n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,
-                base + 4 * o3, self._ptrs[4], self._ptrs[6], pack[0], pack[1], pack[2], pack[3], pack[4], pack[5], pack[6],
-                _stream()), "hexgnn_csr_build_grouped_pack")
+            # (the collation's per-graph edge offsets, when the batch carries them: Batch.from_data_list attaches them)
+            ep = getattr(edge_index, "_hex_edge_ptr", None) if _USE_EDGE_PTR else None
+            if ep is not None and not (torch.is_tensor(ep) and ep.dtype == torch.long and ep.device == dev and ep.is_contiguous()
+                                       and ep.numel() == int(b) + 1):
+                ep = None
+            _lib.check(_lib.lib().hexgnn_csr_build_grouped_pack_e(
+                n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), ep.data_ptr() if ep is not None else None,
+                base + 4 * o4, base, base + 4 * o2, base + 4 * o1, base + 4 * o3, self._ptrs[4], self._ptrs[6], pack[0], pack[1],
+                pack[2], pack[3], pack[4], pack[5], pack[6], _stream()), "hexgnn_csr_build_grouped_pack_e")
             return self
         _lib.check(_lib.lib().hexgnn_csr_build_grouped(
             n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,

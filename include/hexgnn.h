@@ -77,6 +77,15 @@ int hexgnn_csr_build_grouped_pack(int n, int e, int b, const int64_t* src, const
                                   float* invdeg, int* status, int c_in, int hidden, int num_layers,
                                   const float* const* wl, const float* const* bl, const float* const* wr, void* wpack,
                                   hexgnn_stream_t stream);
+/* The same with the collation's own edge offsets: edge_ptr64 [b+1] (device, int64; graph g's edges are src/dst[edge_ptr64[g] ..
+ * edge_ptr64[g+1]) -- what Batch.from_data_list (torch_geometric 2.2.0's collate, call site GN0/RainbowDQN/evaluate_elo.py:229) knows
+ * when it concatenates the graphs' edge_index).  Spares the three dependent search rounds that locate a graph's edge range; the
+ * ranges must tile [0, e) in order (status |= 4 otherwise).  NULL: as hexgnn_csr_build_grouped_pack. */
+int hexgnn_csr_build_grouped_pack_e(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                                    const int64_t* ptr64, const int64_t* edge_ptr64, int* gptr_out, int* rowptr, int* col,
+                                    int* rowptr_t, int* col_t, float* invdeg, int* status, int c_in, int hidden,
+                                    int num_layers, const float* const* wl, const float* const* bl,
+                                    const float* const* wr, void* wpack, hexgnn_stream_t stream);
 
 /* Replaces the segment lookup inside torch_scatter.scatter(x, graph_indices) (GN0/models.py:381,578)
  * and torch_geometric Batch.ptr: batch (int64, sorted ascending, values in [0,b)) -> gptr[b+1]. */
