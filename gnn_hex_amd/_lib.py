@@ -42,6 +42,8 @@ _SIGS = {
                                             vp, vp, vp, vp, sz, ci, ci, vp, vp]),
     "hexgnn_sage_norm_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp,
                                             vp, vp, sz, ci, vp]),
+    "hexgnn_sage_norm_stack_forward_live": (ci, [ci, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.c_float, vp, vp,
+                                                 vp, vp, vp, vp, sz, ci, vp]),
     "hexgnn_sage_norm_stack_backward_workspace_bytes": (sz, [ci, ci, ci, ci]),
     "hexgnn_sage_norm_stack_backward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp,
                                              vp, vp, vp, vp, vp, sz, vp, sz, vp]),
@@ -52,6 +54,7 @@ _SIGS = {
                                   vp, sz, vp]),
     "hexgnn_graph_layernorm_workspace_bytes": (sz, [ci]),
     "hexgnn_graph_layernorm_forward": (ci, [ci, ci, vp, vp, vp, C.c_float, ci, vp, vp, vp, sz, vp]),
+    "hexgnn_graph_layernorm_forward_live": (ci, [ci, vp, ci, vp, vp, vp, C.c_float, ci, vp, vp, vp, sz, vp]),
     "hexgnn_graph_layernorm_backward": (ci, [ci, ci, vp, vp, vp, vp, vp, C.c_float, ci, vp, vp, vp, vp, sz, vp]),
     "hexgnn_graph_colnorm_workspace_bytes": (sz, [ci]),
     "hexgnn_graph_colnorm_forward": (ci, [ci, ci, vp, vp, vp, vp, C.c_float, ci, ci, vp, vp, vp, sz, vp]),

@@ -37,9 +37,18 @@ __device__ __forceinline__ double block_sum_f64(double v, double* s /*[4]*/) {
 }
 
 // partial[blk] = (sum x, sum x^2) over the block's row range, logical columns only
+// (n_live, when given: a device-side row count, at most n -- a capacity-sized buffer of which only the first *n_live rows are the
+// batch; both kernels then behave exactly as if launched with n = *n_live, partial shapes included)
+__device__ __forceinline__ int live_rows(int n, const int* n_live) {
+    if (!n_live) return n;
+    const int v = *n_live;
+    return v < 0 ? 0 : (v < n ? v : n);
+}
+
 __global__ __launch_bounds__(256) void norm_stats_kernel(int n, int H, int hp, const float* __restrict__ x,
-                                                        double* __restrict__ partial) {
+                                                        double* __restrict__ partial, const int* __restrict__ n_live) {
     __shared__ double s4[4];
+    n = live_rows(n, n_live);
     const int rows_per = (n + kNormBlocks - 1) / kNormBlocks;
     const int r0 = blockIdx.x * rows_per, r1 = min(n, r0 + rows_per);
     const int q4 = hp / 4;
@@ -61,9 +70,11 @@ __global__ __launch_bounds__(256) void norm_stats_kernel(int n, int H, int hp, c
 __global__ __launch_bounds__(256) void norm_apply_kernel(int n, int H, int hp, const float* __restrict__ x,
                                                         const float* __restrict__ w, const float* __restrict__ b,
                                                         float eps, int relu, const double* __restrict__ partial,
-                                                        float* __restrict__ y, float* __restrict__ stats) {
+                                                        float* __restrict__ y, float* __restrict__ stats,
+                                                        const int* __restrict__ n_live) {
     __shared__ double s4[4];
     __shared__ float s_mu, s_r;
+    n = live_rows(n, n_live);
     double s = 0.0, ss = 0.0;
     for (int i = threadIdx.x; i < kNormBlocks; i += 256) { s += partial[2 * i]; ss += partial[2 * i + 1]; }
     s = block_sum_f64(s, s4);
@@ -424,6 +435,13 @@ size_t hexgnn_graph_layernorm_workspace_bytes(int hidden) {
 int hexgnn_graph_layernorm_forward(int n, int hidden, const float* x, const float* weight, const float* bias, float eps,
                                    int relu, float* y, float* stats, void* workspace, size_t workspace_bytes,
                                    hexgnn_stream_t stream_) {
+    return hexgnn_graph_layernorm_forward_live(n, nullptr, hidden, x, weight, bias, eps, relu, y, stats, workspace,
+                                               workspace_bytes, stream_);
+}
+
+int hexgnn_graph_layernorm_forward_live(int n, const int* n_live, int hidden, const float* x, const float* weight,
+                                        const float* bias, float eps, int relu, float* y, float* stats, void* workspace,
+                                        size_t workspace_bytes, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     const int hp = padded_width(hidden);
     if (hp < 0) return HEXGNN_EUNSUPPORTED;
@@ -432,11 +450,11 @@ int hexgnn_graph_layernorm_forward(int n, int hidden, const float* x, const floa
     if (!workspace || workspace_bytes < w.total) return HEXGNN_EWORKSPACE;
     if (n == 0) return HEXGNN_OK;
     double* partial = (double*)((char*)workspace + w.stat_off);
-    norm_stats_kernel<<<kNormBlocks, 256, 0, st>>>(n, hidden, hp, x, partial);
+    norm_stats_kernel<<<kNormBlocks, 256, 0, st>>>(n, hidden, hp, x, partial, n_live);
     const int64_t total = (int64_t)n * (hp / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 2048) grid = 2048;
-    norm_apply_kernel<<<grid, 256, 0, st>>>(n, hidden, hp, x, weight, bias, eps, relu, partial, y, stats);
+    norm_apply_kernel<<<grid, 256, 0, st>>>(n, hidden, hp, x, weight, bias, eps, relu, partial, y, stats, n_live);
     return check_launch();
 }
 

@@ -2072,9 +2072,21 @@ int hexgnn_sage_norm_stack_forward(int n, int c_in, int hidden, int num_layers, 
                                    const float* const* nb, float eps, void* wpack, float* pre, float* acts, void* saved,
                                    float* stats, void* norm_ws, size_t norm_ws_bytes, int need_backward,
                                    hexgnn_stream_t stream_) {
+    return hexgnn_sage_norm_stack_forward_live(n, nullptr, c_in, hidden, num_layers, rowptr, col, invdeg, x, x_stride, wl, bl,
+                                               wr, nw, nb, eps, wpack, pre, acts, saved, stats, norm_ws, norm_ws_bytes,
+                                               need_backward, stream_);
+}
+
+int hexgnn_sage_norm_stack_forward_live(int n, const int* n_live, int c_in, int hidden, int num_layers, const int* rowptr,
+                                        const int* col, const float* invdeg, const float* x, int x_stride,
+                                        const float* const* wl, const float* const* bl, const float* const* wr,
+                                        const float* const* nw, const float* const* nb, float eps, void* wpack, float* pre,
+                                        float* acts, void* saved, float* stats, void* norm_ws, size_t norm_ws_bytes,
+                                        int need_backward, hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0) return HEXGNN_EINVAL;
+    if (n_live && need_backward) return HEXGNN_EINVAL;       // a live row count is an acting-time (forward-only) notion
     int rc = make_plan(n, c_in, hidden, num_layers, &p);
     if (rc != HEXGNN_OK) return rc;
     if (!wl || !bl || !wr || !nw || !nb || !wpack || !stats || !norm_ws) return HEXGNN_EINVAL;
@@ -2100,8 +2112,8 @@ int hexgnn_sage_norm_stack_forward(int n, int c_in, int hidden, int num_layers, 
             const float* xin = l == 0 ? x : acts + slab * (l - 1);
             HEXGNN_NT_SWITCH(p.nt, (launch_fwd<NT_>(n, rowptr, col, invdeg, xin, wp + p.fwd_off[l], bias, y, agg, 0, st)));
         }
-        rc = hexgnn_graph_layernorm_forward(n, hidden, y, nw[l], nb[l], eps, 1, acts + slab * l, stats + 2 * l, norm_ws,
-                                            norm_ws_bytes, stream_);
+        rc = hexgnn_graph_layernorm_forward_live(n, n_live, hidden, y, nw[l], nb[l], eps, 1, acts + slab * l, stats + 2 * l,
+                                                 norm_ws, norm_ws_bytes, stream_);
         if (rc != HEXGNN_OK) return rc;
     }
     return check_launch();

@@ -149,13 +149,14 @@ class DeviceRollout:
     def __init__(self, mgr: "Env_manager", model, steps: int = 16, eps: float = 0.05, graph: bool = True):
         if steps < 2 or steps % 2:
             raise ValueError("steps must be a positive even number")
-        if getattr(getattr(model, "gnn", None), "norms", None) is not None:
-            # --norm=True normalises over the LIVE batch (all nodes of the current observation).  The rollout hands the model
-            # capacity-sized buffers (num_envs * nv rows) whose tail rows are stale once nodes have been removed; the
-            # whole-batch statistics of the norm kernels would include them and the Q-values would silently differ from
-            # the reference.  Use the step-by-step API (Env_manager.observe / step), whose batches are exact-size.
-            raise NotImplementedError("DeviceRollout does not support models built with --norm=True (whole-batch LayerNorm "
-                                      "needs exact-size batches); use Env_manager.observe()/step()")
+        norms = getattr(getattr(model, "gnn", None), "norms", None)
+        # --norm=True normalises over the LIVE batch (all nodes of the current observation).  The rollout hands the model
+        # capacity-sized buffers (num_envs * nv rows) whose tail rows are stale once nodes have been removed: the norm kernels
+        # take the live node total from the device-side prefix sums instead (ops.live_rows).
+        self._live_norm = norms is not None
+        if norms is not None and any(type(m).__name__ != "LayerNorm" for m in norms):
+            raise NotImplementedError("DeviceRollout supports the whole-batch LayerNorm of --norm=True; per-channel "
+                                      "CachedGraphNorm statistics need exact-size batches: use Env_manager.observe()/step()")
         self.mgr, self.model, self.T, self.eps = mgr, model, steps, float(eps)
         self.start_side = mgr.global_onturn
         dev = mgr.device
@@ -183,7 +184,7 @@ class DeviceRollout:
         self.alive = torch.zeros((T + 1, k, nv), dtype=torch.uint8, device=dev)
         self._mt = torch.zeros(k, dtype=torch.int32, device=dev)
         self._tm = torch.zeros(k, dtype=torch.int32, device=dev)
-        self._iota = torch.arange(N + 1, dtype=torch.int32, device=dev) if nv > 128 else None
+        self._iota = torch.arange(N + 1, dtype=torch.int32, device=dev) if nv > 128 or self._live_norm else None
         self._run_no = 0           # bumped by every run(): results of earlier runs view overwritten snapshots
         self._graph = None
         if graph:
@@ -222,7 +223,7 @@ class DeviceRollout:
                                             self.gs.invdeg.data_ptr(), self.batch_vec.data_ptr(), ops._stream()),
                        "hexgnn_env_observe")
             if self._iota is not None:
-                # Boards above 128 nodes run on the layer-major kernels, which walk ALL rows of the capacity-sized buffers:
+                # Boards above 128 nodes (and --norm=True models) run on the layer-major kernels, which walk ALL rows of the capacity-sized buffers:
                 # rows past the current total must be empty, not whatever an earlier, larger observation left there (the
                 # row right behind the end marker otherwise shows a bogus degree of thousands: 146 us per layer launch).
                 torch.where(self._iota > self.node_off[k], self.edge_off[k], self.gs.rowptr, out=self.gs.rowptr)
@@ -232,7 +233,7 @@ class DeviceRollout:
             x._hex_hint_version = x._version
             ei = self.edge_global.view(self.edge_global.shape)
             ei._hex_csr = self.gs
-            with torch.no_grad():
+            with torch.no_grad(), ops.live_rows(self.node_off[k:k + 1] if self._live_norm else None):
                 adv = self.model(x, ei, self.batch_vec, self.node_off, advantages_only=True)
             u = None
             if self.eps > 0:

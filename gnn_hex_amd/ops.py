@@ -369,13 +369,43 @@ def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, conv
     return out
 
 
+class live_rows:
+    """``with ops.live_rows(count):`` -- inside, the whole-batch LayerNorm calls (``sage_norm_stack``, ``graph_layernorm``) take
+    their row count from ``count`` (a 1-element int32 device tensor, at most the buffers' row count) instead of the tensors'
+    shapes: the closed acting loop (``multi_env_manager.DeviceRollout``) hands the model capacity-sized buffers whose live
+    node total exists on the device only.  Forward-only: a call that would need a backward raises."""
+    _tls = threading.local()
+
+    def __init__(self, count: Optional[torch.Tensor]):
+        if count is not None and (count.dtype != torch.int32 or count.numel() != 1 or not count.is_cuda):
+            raise ValueError("live_rows: a 1-element int32 device tensor")
+        self.count = count
+
+    def __enter__(self):
+        self.prev = getattr(live_rows._tls, "count", None)
+        live_rows._tls.count = self.count
+        return self
+
+    def __exit__(self, *exc):
+        live_rows._tls.count = self.prev
+        return False
+
+    @staticmethod
+    def current(*tensors) -> Optional[torch.Tensor]:
+        """The count in force (called by the wrappers OUTSIDE the autograd function: there the grad mode is the caller's)."""
+        c = getattr(live_rows._tls, "count", None)
+        if c is not None and torch.is_grad_enabled() and any(t.requires_grad for t in tensors):
+            raise RuntimeError("ops.live_rows is forward-only (acting loop): run the model under torch.no_grad()")
+        return c
+
+
 class SageNormStackFn(torch.autograd.Function):
     """x = relu(norm_l(SAGE_l(x))) for every layer: CachifiedGNN.forward with the LayerNorm of --norm=True (GN0/models.py:
     261-294, 935, 945) as one call per direction (``hexgnn_sage_norm_stack_*``).  params: per layer lin_l.weight, lin_l.bias,
     lin_r.weight, norm.weight, norm.bias."""
 
     @staticmethod
-    def forward(ctx, x, gs: GraphStructure, c_in: int, hidden: int, num_layers: int, eps: float, *params):
+    def forward(ctx, x, gs: GraphStructure, c_in: int, hidden: int, num_layers: int, eps: float, live, *params):
         L = _lib.lib()
         dev = x.device
         n = int(x.shape[0])
@@ -390,7 +420,8 @@ class SageNormStackFn(torch.autograd.Function):
             x_stride = hp
         params = [p if (p.is_contiguous() and p.dtype == torch.float32) else p.float().contiguous() for p in params]
         wl, bl, wr, nw, nb = params[0::5], params[1::5], params[2::5], params[3::5], params[4::5]
-        need_bwd = any(ctx.needs_input_grad)
+        # live: ops.live_rows' device-side row count (forward-only)
+        need_bwd = any(ctx.needs_input_grad) and live is None
         # [pre | acts]: contraction outputs and norm + ReLU outputs of every layer
         both = torch.empty((2, num_layers, n, hp), dtype=torch.float32, device=dev)
         pre, acts = both[0], both[1]
@@ -399,11 +430,11 @@ class SageNormStackFn(torch.autograd.Function):
         stats = torch.empty((num_layers, 2), dtype=torch.float32, device=dev)
         nws_bytes = L.hexgnn_graph_layernorm_workspace_bytes(hidden)
         nws = _bytes(nws_bytes, dev)
-        _lib.check(L.hexgnn_sage_norm_stack_forward(
-            n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(),
+        _lib.check(L.hexgnn_sage_norm_stack_forward_live(
+            n, live.data_ptr() if live is not None else None, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(),
             x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), _ptr_array(nw), _ptr_array(nb), float(eps),
             wpack.data_ptr(), pre.data_ptr(), acts.data_ptr(), saved.data_ptr() if saved is not None else None,
-            stats.data_ptr(), nws.data_ptr(), nws_bytes, int(need_bwd), _stream()), "hexgnn_sage_norm_stack_forward")
+            stats.data_ptr(), nws.data_ptr(), nws_bytes, int(need_bwd), _stream()), "hexgnn_sage_norm_stack_forward_live")
         if need_bwd:
             ctx.gs = gs
             ctx.dims = (n, c_in, hidden, num_layers, hp, x_stride, float(eps))
@@ -433,7 +464,7 @@ class SageNormStackFn(torch.autograd.Function):
             _ptr_array(grads[2::5]), _ptr_array(grads[3::5]), _ptr_array(grads[4::5]), ws.data_ptr(), ws_bytes,
             nws.data_ptr(), nws_bytes, _stream()), "hexgnn_sage_norm_stack_backward")
         gx = _logical(dx, hidden) if dx is not None else None
-        return (gx, None, None, None, None, None) + tuple(grads)
+        return (gx, None, None, None, None, None, None) + tuple(grads)
 
 
 def sage_norm_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, convs, norms) -> torch.Tensor:
@@ -445,7 +476,7 @@ def sage_norm_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int,
         if float(norm.eps) != eps:
             raise ValueError("the norms of one stack must share eps")
         params += [conv.lin_l.weight, conv.lin_l.bias, conv.lin_r.weight, norm.weight, norm.bias]
-    out = SageNormStackFn.apply(x, gs, c_in, hidden, len(convs), eps, *params)
+    out = SageNormStackFn.apply(x, gs, c_in, hidden, len(convs), eps, live_rows.current(x, *params), *params)
     out._hexgnn_hp = padded_width(hidden)
     return out
 
@@ -455,7 +486,7 @@ class GraphLayerNormFn(torch.autograd.Function):
     affine, optional fused ReLU (GN0/models.py:286-289 norm -> act).  C ABI ``hexgnn_graph_layernorm_*``."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps: float, relu: bool):
+    def forward(ctx, x, weight, bias, eps: float, relu: bool, live=None):
         L = _lib.lib()
         hidden = int(x.shape[1])
         hp = padded_width(hidden)
@@ -467,9 +498,10 @@ class GraphLayerNormFn(torch.autograd.Function):
         stats = torch.empty(2, dtype=torch.float32, device=x.device)
         ws_bytes = L.hexgnn_graph_layernorm_workspace_bytes(hidden)
         ws = _bytes(ws_bytes, x.device)
-        _lib.check(L.hexgnn_graph_layernorm_forward(n, hidden, xp.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps),
-                                                    int(relu), y.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws_bytes,
-                                                    _stream()), "hexgnn_graph_layernorm_forward")
+        _lib.check(L.hexgnn_graph_layernorm_forward_live(n, live.data_ptr() if live is not None else None, hidden,
+                                                         xp.data_ptr(), w.data_ptr(), b.data_ptr(), float(eps), int(relu),
+                                                         y.data_ptr(), stats.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
+                   "hexgnn_graph_layernorm_forward_live")
         ctx.dims = (n, hidden, hp, float(eps), bool(relu))
         ctx.bufs = (xp, y, w, stats)
         return _logical(y, hidden)
@@ -489,12 +521,12 @@ class GraphLayerNormFn(torch.autograd.Function):
                                                      dyp.data_ptr(), eps, int(relu), dx.data_ptr(), dw.data_ptr(),
                                                      db.data_ptr(), ws.data_ptr(), ws_bytes, _stream()),
                    "hexgnn_graph_layernorm_backward")
-        return _logical(dx, hidden), dw, db, None, None
+        return _logical(dx, hidden), dw, db, None, None, None
 
 
 def graph_layernorm(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5, relu: bool = False):
     _require_cuda(x, "x")
-    out = GraphLayerNormFn.apply(x, weight, bias, eps, relu)
+    out = GraphLayerNormFn.apply(x, weight, bias, eps, relu, live_rows.current(x, weight, bias))
     out._hexgnn_hp = padded_width(int(x.shape[1]))
     return out
 

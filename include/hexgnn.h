@@ -230,6 +230,13 @@ size_t hexgnn_graph_layernorm_workspace_bytes(int hidden);
 int hexgnn_graph_layernorm_forward(int n, int hidden, const float* x, const float* weight /*[hidden]*/,
                                    const float* bias /*[hidden]*/, float eps, int relu, float* y, float* stats /*[2]*/,
                                    void* workspace, size_t workspace_bytes, hexgnn_stream_t stream);
+/* The same over a CAPACITY-sized buffer whose batch is its first *n_live rows (n_live: device int, clamped to [0, n]; NULL =
+ * all n rows): the closed acting loop (hexgnn_env_observe -> forward -> hexgnn_select_actions -> hexgnn_env_step, SURVEY 8(a)
+ * envs; the reference rebuilds an exact-size batch per move, graph_game/multi_env_manager.py:76-103) keeps its node count on
+ * the device.  Identical, bit for bit, to the call above with n = *n_live; rows at and after *n_live are left untouched. */
+int hexgnn_graph_layernorm_forward_live(int n, const int* n_live, int hidden, const float* x, const float* weight,
+                                        const float* bias, float eps, int relu, float* y, float* stats, void* workspace,
+                                        size_t workspace_bytes, hexgnn_stream_t stream);
 /* y: the forward output (only read when relu != 0, for the mask); d_weight / d_bias [hidden] are written. */
 int hexgnn_graph_layernorm_backward(int n, int hidden, const float* x, const float* y, const float* weight,
                                     const float* stats, const float* dy, float eps, int relu, float* dx,
@@ -264,6 +271,14 @@ int hexgnn_sage_norm_stack_forward(int n, int c_in, int hidden, int num_layers, 
                                    const float* const* nb, float eps, void* wpack, float* pre, float* acts, void* saved,
                                    float* stats, void* norm_ws, size_t norm_ws_bytes, int need_backward,
                                    hexgnn_stream_t stream);
+/* Forward-only (need_backward must be 0 when n_live is given) over capacity-sized buffers: the SAGE layers run over all n rows
+ * (rowptr must describe empty rows behind the live ones), every norm's statistics cover the first *n_live rows only. */
+int hexgnn_sage_norm_stack_forward_live(int n, const int* n_live, int c_in, int hidden, int num_layers, const int* rowptr,
+                                        const int* col, const float* invdeg, const float* x, int x_stride,
+                                        const float* const* wl, const float* const* bl, const float* const* wr,
+                                        const float* const* nw, const float* const* nb, float eps, void* wpack, float* pre,
+                                        float* acts, void* saved, float* stats, void* norm_ws, size_t norm_ws_bytes,
+                                        int need_backward, hexgnn_stream_t stream);
 size_t hexgnn_sage_norm_stack_backward_workspace_bytes(int n, int c_in, int hidden, int num_layers);
 int hexgnn_sage_norm_stack_backward(int n, int c_in, int hidden, int num_layers, const int* rowptr_t, const int* col_t,
                                     const float* invdeg, const float* x, int x_stride, const float* pre,

@@ -130,12 +130,68 @@ def test_norm_model_at_the_benchmark_batch():
     print("norm L256-D1 gradients vs the float64 oracle: HIP %.3g, fp32 oracle %.3g" % (worst_hip, worst_ref))
 
 
-def test_device_rollout_refuses_norm_models():
-    """the rollout hands the model capacity-sized buffers whose tail rows are stale after node removals; the
-    whole-batch LayerNorm statistics would include them.  It must refuse instead of returning silently different Q-values."""
+def test_live_row_count_equals_exact_size_call():
+    """hexgnn_graph_layernorm_forward_live / ops.live_rows: over a capacity-sized buffer with a device-side row count the norm
+    is, bit for bit, the exact-size call on the live rows, and rows behind the count are not written."""
+    from gnn_hex_amd import ops
+    gen = torch.Generator().manual_seed(5)
+    cap, hidden = 3000, 35
+    x = (torch.randn(cap, hidden, generator=gen) * 2.0 + 0.7).cuda()
+    x[2000:] = float("nan")                                     # stale rows: must not reach the statistics
+    w, b = (torch.rand(hidden, generator=gen) + 0.5).cuda(), torch.randn(hidden, generator=gen).cuda()
+    for live in (2000, 1, 777, 0):
+        cnt = torch.tensor([live], dtype=torch.int32, device="cuda")
+        with torch.no_grad(), ops.live_rows(cnt):
+            got = ops.graph_layernorm(x, w, b, 1e-5, True)
+        with torch.no_grad():
+            want = ops.graph_layernorm(x[:live].contiguous(), w, b, 1e-5, True)
+        assert torch.equal(got[:live], want), live
+    with pytest.raises(RuntimeError, match="forward-only"):
+        with ops.live_rows(cnt):
+            ops.graph_layernorm(x.clone().requires_grad_(True), w, b, 1e-5, True)
+    with pytest.raises(ValueError):
+        ops.live_rows(torch.tensor([3], device="cuda"))         # int64
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("size", [5, 12])
+def test_device_rollout_with_norm_model_equals_step_by_step_loop(graph, size):
+    """A --norm=True model in the closed acting loop: the rollout's buffers are capacity-sized and their tail rows go stale as
+    nodes are removed, so the whole-batch LayerNorm takes the live node total from the device (ops.live_rows).  It must play
+    exactly the games the step-by-step API plays with exact-size batches (round 3 refused such models)."""
+    from gnn_hex_amd.data import Batch
     from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
     hip, _ = _norm_pair(3, 35, seed=9, noisy=False)
+    k, T = 6, 8
+    a, b = Env_manager(k, size, gamma=0.9), Env_manager(k, size, gamma=0.9)
+    a.reset(); b.reset()
+    ro = DeviceRollout(a, hip, steps=T, eps=0.0, graph=graph)
+    for _round in range(2):
+        res = ro.run()
+        obs = b.observe()
+        for t in range(T):
+            bt = Batch.from_data_list(obs)
+            with torch.no_grad():
+                adv = hip(bt.x, bt.edge_index, bt.batch, bt.ptr, advantages_only=True)
+            vert, rank, _ = b.select_actions(adv, obs, eps=0.0)
+            assert vert.cpu().tolist() == res.vertices[t].tolist(), "step %d" % t
+            assert rank.cpu().tolist() == res.actions[t].tolist()
+            assert obs.node_off == res.states[t].node_off
+            obs, rew, dones, _ = b.step(vert)
+            assert rew.tolist() == res.rewards[t].tolist() and dones.tolist() == res.dones[t].tolist()
+        sa, sb = a._state(), b._state()
+        for key in ("adj", "alive", "maker_turn", "total_moves"):
+            assert (sa[key] == sb[key]).all(), key
+
+
+def test_device_rollout_refuses_per_channel_cached_norm():
+    """CachedGraphNorm (get_pre_defined("two_headed")) takes per-channel statistics over the batch's rows: still exact-size
+    batches only."""
+    from gnn_hex_amd.models import get_pre_defined
+    from gnn_hex_amd.multi_env_manager import DeviceRollout, Env_manager
+    args = Namespace(num_layers=3, hidden_channels=32, norm=True, noisy_dqn=False, noisy_sigma0=0.5, num_head_layers=2)
+    model = get_pre_defined("two_headed", args).cuda()
     mgr = Env_manager(4, 5, device="cuda")
     mgr.reset()
-    with pytest.raises(NotImplementedError, match="norm"):
-        DeviceRollout(mgr, hip, steps=2, eps=0.0, graph=False)
+    with pytest.raises(NotImplementedError, match="CachedGraphNorm"):
+        DeviceRollout(mgr, model, steps=2, eps=0.0, graph=False)
