@@ -39,6 +39,8 @@ CONFIGS = {
     "MIX": (15, 110, lambda b: [5 + (g % 9) for g in range(b)], "GNN-L mixed Hex-5..13 ragged batch=256"),
 }
 
+PACK_BATCHES = True      # --no-pack: batches with graphs above 128 nodes keep the round-robin order (default 128-row blocks)
+
 KNAMES = {0: "sage_hidden_fwd_kernel", 1: "sage_hidden_bwd_kernel", 2: "sage_dw_kernel",
           8: "qnet_fwd_kernel", 9: "qnet_bwd_kernel"}
 # classes 0 / 1 time whichever kernel runs the hidden layers of the layer-major path: one launch per layer, or (batch fits one
@@ -51,21 +53,39 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
     B graphs (D1 graphs differ per rank).  Strong scaling (`subset` = this rank's graph indices of ONE global B-graph batch,
     gnn_hex_amd.dist.balance_by_edges): the rank holds only those graphs; D1 seeds are the global graph indices."""
     from helpers import batch_tensors, sel_and_targets
+    from gnn_hex_amd.data import attach_blocks, pack_order
     sizes_fn = CONFIGS[config][2]
     all_sizes = sizes_fn(B)
     graphs = list(range(B)) if subset is None else list(subset)
     sizes = [all_sizes[g] for g in graphs]
+    # Batches with graphs above 128 nodes (MIX: Hex-12 / Hex-13) run on the one-launch stack kernels, whose workgroups own
+    # blocks of at most 128 rows: the collation lists the graphs in gnn_hex_amd.data.pack_order order (blocks of whole graphs
+    # wherever possible; the same multiset of graphs -- what Batch.from_data_list(pack=True) does) unless --no-pack
+    want_pack = PACK_BATCHES and max(sizes) ** 2 + 2 > 128
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count if torch.device(dev).type == "cuda" else None
     batches = []
     for maker in (True, False):
+        starts = None
         if data == "D0":
-            x, ei, bv, ptr = batch_tensors("D0", sizes, maker=maker)
+            if want_pack:
+                order, starts = pack_order([s * s + 2 for s in sizes], max_blocks=cus)
+                sizes_m = [sizes[k] for k in order]
+            else:
+                sizes_m = sizes
+            x, ei, bv, ptr = batch_tensors("D0", sizes_m, maker=maker)
         else:
             from oracle import env_ref          # input generation only (before any timed region)
             import numpy as np
-            xs, eis, bvs, ptrs, off = [], [], [], [0], 0
+            items = []
             for g, size in zip(graphs, sizes):
                 game = env_ref.random_position(size, (100000 * rank + g) if subset is None else g, maker)
                 gx, gei, _ = game.observe()
+                items.append((gx, gei))
+            if want_pack:
+                order, starts = pack_order([it[0].shape[0] for it in items], max_blocks=cus)
+                items = [items[k] for k in order]
+            xs, eis, bvs, ptrs, off = [], [], [], [0], 0
+            for gx, gei in items:
                 bvs.append(np.full(gx.shape[0], len(xs), dtype=np.int64)); xs.append(gx); eis.append(gei + off)
                 off += gx.shape[0]; ptrs.append(off)
             x, ei, bv, ptr = (torch.from_numpy(np.concatenate(xs, 0)), torch.from_numpy(np.concatenate(eis, 1)),
@@ -83,8 +103,11 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
         # hand): edges are grouped by graph, so graph g's range is the running count of the edges whose source lies in it
         ecnt = torch.bincount(bv[ei[0]], minlength=int(ptr.numel()) - 1)
         eid._hex_edge_ptr = torch.cat([torch.zeros(1, dtype=torch.long), ecnt.cumsum(0)]).to(dev)
+        if starts is not None and eid.is_cuda:
+            attach_blocks(eid, starts)
         batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
                             w=None if wts is None else wts.to(dev), graphs=len(graphs),
+                            blocks=None if starts is None else len(starts) - 1,
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
     return batches
 
@@ -133,8 +156,10 @@ def secondary_config(config, data, B, dev, steps, warmup, preheat_ms):
         n = (batches[0]["n"] + batches[1]["n"]) / 2.0
         e = (batches[0]["e"] + batches[1]["e"]) / 2.0
         step_bytes = 2 * (bytes_fwd(n, e, 2) + (num_layers + 1) * bytes_fwd(n, e, hidden))
-        return {"workload": "%s, %s board graphs (N=%d, E=%d)" % (label, "start-position" if data == "D0" else
-                                                                  "random-playout", batches[0]["n"], batches[0]["e"]),
+        return {"workload": "%s, %s board graphs (N=%d, E=%d)%s" % (
+                    label, "start-position" if data == "D0" else "random-playout", batches[0]["n"], batches[0]["e"],
+                    "" if batches[0]["blocks"] is None else
+                    ", graphs collated in data.pack_order order (%d graph-aligned row blocks)" % batches[0]["blocks"]),
                 "value": B * steps / dt, "unit": "graphs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                 "warmup": warmup, "preheat_steps": k,
                 "step_hbm_roofline_frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS}
@@ -160,6 +185,8 @@ def main():
     ap.add_argument("--config", default="L256", choices=sorted(CONFIGS))
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--data", default="D0", choices=["D0", "D1"])
+    ap.add_argument("--no-pack", action="store_true",
+                    help="MIX: keep the round-robin graph order (default: gnn_hex_amd.data.pack_order, graph-aligned row blocks)")
     ap.add_argument("--math", default="fp32", choices=["fp32", "f16x3"],
                     help="contraction arithmetic of the fused kernels: exact fp32 MFMA (default) or split f16x3")
     ap.add_argument("--mode", default="train", choices=["train", "selfplay"],
@@ -211,6 +238,9 @@ def main():
     args = ap.parse_args()
     if args.graph is None:
         args.graph = args.mode == "train"
+    if args.no_pack:
+        global PACK_BATCHES
+        PACK_BATCHES = False
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # not under a launcher: bring up the N ranks ourselves, as fresh child processes.  This process calls NOTHING in
@@ -565,6 +595,8 @@ def main():
                                       batches[0]["graphs"], batches[0]["n"], batches[0]["e"]),
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * gfactor,
                        "graphs_per_gpu": batches[0]["graphs"],
+                       "collation": "caller's order" if batches[0]["blocks"] is None else
+                                    "gnn_hex_amd.data.pack_order (%d graph-aligned row blocks)" % batches[0]["blocks"],
                        "step_issue": "model(...), F.mse_loss(q[sel], target), loss.backward()" if args.plain_autograd else
                                      "ops.td_step (model forward, TD loss in its tail, backward)" if td_fused else
                                      "model(...), ops.td_loss, ops.backward"},

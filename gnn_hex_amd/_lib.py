@@ -40,6 +40,9 @@ _SIGS = {
                                         vp, vp, vp, vp, sz, ci, vp]),
     "hexgnn_sage_stack_backward_tap": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
                                             vp, vp, vp, vp, sz, ci, ci, vp, vp]),
+    "hexgnn_sage_stack_forward_blocks": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, vp, ci, vp]),
+    "hexgnn_sage_stack_backward_blocks": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp,
+                                               vp, vp, vp, vp, sz, ci, ci, vp, vp, ci, vp]),
     "hexgnn_sage_norm_stack_forward": (ci, [ci, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.c_float, vp, vp, vp, vp,
                                             vp, vp, sz, ci, vp]),
     "hexgnn_sage_norm_stack_forward_live": (ci, [ci, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, C.c_float, vp, vp,

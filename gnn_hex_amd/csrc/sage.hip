@@ -250,8 +250,9 @@ __device__ __forceinline__ void static_for_(F&& f) {
 // s_memtime at fixed points of the layer-major kernels (the last launch of each kind wins)
 __device__ unsigned long long g_lstamps[2][8][8];
 #define LSTAMP(k, p) do { if (blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) g_lstamps[k][p][threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
-__device__ unsigned long long g_pstamps[2][16][8];      // one-launch stack kernels: layer 8 of the mid-grid workgroup
-#define PSTAMP(k, p) do { if (it == 8 && blockIdx.x == gridDim.x / 2 && (threadIdx.x & 63) == 0) g_pstamps[k][p][threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
+__device__ unsigned long long g_pstamps[2][16][8];      // one-launch stack kernels: layer 8 of the mid-grid workgroup (or of
+__device__ int g_stamp_block = -1;                      // the one chosen with hexgnn_debug_stamp_block)
+#define PSTAMP(k, p) do { if (it == 8 && (int)blockIdx.x == (g_stamp_block < 0 ? (int)gridDim.x / 2 : g_stamp_block) && (threadIdx.x & 63) == 0) g_pstamps[k][p][threadIdx.x >> 6] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define LSTAMP(k, p) do {} while (0)
 #define PSTAMP(k, p) do {} while (0)
@@ -697,6 +698,8 @@ struct StackKArgs {
     size_t astride;
     float* tap_out;
     unsigned* flags;                   // [blocks] progress counters, zero at launch
+    const int* bstart;                 // null: block b = rows [128 b, 128 b + 128); else [nblocks + 1] row offsets (block b =
+    int nblocks;                       //   rows [bstart[b], bstart[b + 1]), at most 128 each, a partition of [0, n))
     int* status;
     unsigned skew;                     // test aid (HEXGNN_STACK_SKEW): != 0 delays every block by a pseudo-random time per layer;
 };                                     // 0xDE00bbbb: block bbbb never publishes its progress (its readers must time out)
@@ -750,10 +753,29 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         for (int p = wave; p < 2 * NT * NT; p += 8) dma_piece(w4 + p * 64, 16 * lane, lds_w + p * 1024);
     };
     stage_weights(a.w0);
-    const int row0 = (blockIdx.x * 8 + wave) * 16;
+    // the block's rows.  With a block table (graph-aligned blocks: hexgnn_sage_stack_forward_blocks) the range comes from the
+    // table and is checked HERE (the table is device data the host never saw): a range that is not a piece of a partition of
+    // [0, n) in pieces of at most 128 rows makes the block empty and sets HEXGNN_EINVAL in the status word
+    int brow0 = blockIdx.x * 128, bcnt = min(128, n - brow0);
+    if (a.bstart) {
+        const int nbk = (int)gridDim.x;
+        brow0 = __builtin_amdgcn_readfirstlane(a.bstart[blockIdx.x]);
+        const int bend = __builtin_amdgcn_readfirstlane(a.bstart[blockIdx.x + 1]);
+        bcnt = bend - brow0;
+        const bool ok = brow0 >= 0 && bcnt >= 0 && bcnt <= 128 && bend <= n && (blockIdx.x != 0 || brow0 == 0) &&
+                        ((int)blockIdx.x != nbk - 1 || bend == n);
+        if (!ok) {
+            if (a.status && tid == 0) *a.status = HEXGNN_EINVAL;
+            brow0 = 0; bcnt = 0;
+        }
+    }
+    const int row0 = brow0 + wave * 16;
     const int r = lane & 15, g = lane >> 4;
     const int row = row0 + r;
-    const bool valid = row < n;
+    const bool valid = wave * 16 + r < bcnt;
+    // a wave without rows (blocks shorter than 113 rows: packed batches, the last block) issues no MFMAs -- it would only take
+    // the matrix pipe from the wave it shares its SIMD with -- but keeps its part in the hand-over (counters, staging, barriers)
+    const bool wactive = wave * 16 < bcnt;
     f32x4 xs[NT], ag[NT];
 #pragma unroll
     for (int c = 0; c < NT; ++c) xs[c] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -802,15 +824,20 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
     // layer started, profiles/r03/stack_stamps_MIX_v3_remote_wait_at_gap3.txt); waiting for it a few groups into the self half
     // made the edge waves of every block the slow ones of every layer.  W_l and the bias are requested at the TOP of the next
     // layer (behind the second barrier), not between the barriers.
-    constexpr bool kV3 = RL::on && !BWD;      // (backward: the plain hand-over measured faster, 349 vs 357 us per MIX launch)
-    constexpr int kGo = kV3 ? 4 : 0;              // gap of the publish hook + 1
+    constexpr bool kV3 = RL::on && !BWD;      // forward: + the remote rows in the tail of the self half, the publish in the hook
+    // round 4: the hand-over itself (ctl[0] / ctl[2], W_r requested from inside the aggregate half, ONE barrier) is written for
+    // both directions -- the backward would keep its remote rows where they are (waited for at the top of a layer, fetched in
+    // line with the LDS slots: no registers for a tail ring) and publish at the END of a layer, behind its own stores'
+    // acknowledge -- but pays only in the forward:
+    constexpr bool kHO = RL::on && !BWD;      // (measured with the backward on it too: 298 us per MIX launch against 287 plain)
+    constexpr int kGo = kHO ? 4 : 0;              // gap of the publish hook + 1
     constexpr int kGt = kV3 ? (GatherLds<NT>::G > GatherLds<NT>::add_gap(kEll - 1) + 1 ? GatherLds<NT>::G
                                                                                      : GatherLds<NT>::add_gap(kEll - 1) + 1) : 0;   // first tail gap
     constexpr unsigned kCtlWaves = BWD ? 4u : 5u; // waves that stage something behind barrier 1 (W_l; forward: + the bias)
     unsigned* ctl = reinterpret_cast<unsigned*>(rowsl + 129 * RL::XS);
     float* bias_lds = reinterpret_cast<float*>(ctl + 16);         // forward: the layer's bias, 1 KiB (one LDS-DMA piece)
     const unsigned lds_b = lds_w + (unsigned)(2 * NT * NT * 1024 + 129 * RL::XS * 4 + 64);
-    if constexpr (kV3) {
+    if constexpr (kHO) {
         if (tid == 0) { ctl[0] = 0u; ctl[1] = 0u; ctl[2] = kCtlWaves; ctl[3] = 0u; }
         if constexpr (!BWD) {
             if (wave == 4) dma_piece(a.b0, 16 * lane, lds_b);     // (reads past the 4 * HP bias bytes, inside the pack buffer)
@@ -846,21 +873,50 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
             for (int k = 0; k < kEll; ++k)
                 ns[k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir_, k < deg ? (unsigned)nid[k] * 4u : kOob, 0, 0));
         }
+        // block that owns row j (only asked for rows OUTSIDE this block).  Table form: the two neighbouring blocks from
+        // registers -- a graph cut by a block boundary continues in the next block --, anything else by bisection (every index
+        // stays inside the table whatever it holds)
+        int pb0 = 0, nb1 = 0, nb2 = 0;
+        const int nbk = (int)gridDim.x;
+        if (a.bstart) {
+            pb0 = a.bstart[blk > 0 ? blk - 1 : 0];
+            nb1 = a.bstart[blk + 1];
+            nb2 = a.bstart[blk + 2 <= nbk ? blk + 2 : nbk];
+        }
+        auto block_of = [&](int j) -> int {
+            if (!a.bstart) return j >> 7;
+            if (j >= nb1 && j < nb2) return blk + 1 < nbk ? blk + 1 : blk;
+            if (j >= pb0 && j < brow0) return blk > 0 ? blk - 1 : blk;
+            int lo = 0, hi = nbk;
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (a.bstart[mid] <= j) lo = mid; else hi = mid;
+            }
+            return lo;
+        };
 #pragma unroll
         for (int k = 0; k < kEll; ++k) {
-            if (k < deg) { dlo = min(dlo, nid[k] >> 7); dhi = max(dhi, nid[k] >> 7); }
+            if (k < deg && (unsigned)(nid[k] - brow0) >= (unsigned)bcnt) {
+                const int j = block_of(nid[k]);
+                dlo = min(dlo, j); dhi = max(dhi, j);
+            }
         }
         if (valid) {
-            for (int e = e0 + kEll; e < e1; ++e) { const int j = a.col[e] >> 7; dlo = min(dlo, j); dhi = max(dhi, j); }
+            for (int e = e0 + kEll; e < e1; ++e) {
+                const int c = a.col[e];
+                if ((unsigned)(c - brow0) < (unsigned)bcnt) continue;
+                const int j = block_of(c);
+                dlo = min(dlo, j); dhi = max(dhi, j);
+            }
         }
         if constexpr (RL::on) {
-            const unsigned blk0 = blockIdx.x * 128u;
+            const unsigned blk0 = (unsigned)brow0;
 #pragma unroll
             for (int k = 0; k < kEll / 2; ++k) loff[k] = 0u;
 #pragma unroll
             for (int k = 0; k < kEll; ++k) {
                 const unsigned loc = (unsigned)nid[k] - blk0;
-                const bool have = k < deg, inb = have && loc < 128u;
+                const bool have = k < deg, inb = have && loc < (unsigned)bcnt;
                 loff[k >> 1] |= ((inb ? loc : 128u) * (unsigned)(RL::XS * 4) + 16u * g) << (16 * (k & 1));
                 noff[k] = (have && !inb) ? (unsigned)nid[k] * (unsigned)(HP * 4) + 16u * g : kOob;
                 gneed |= (__ballot(have && !inb) != 0ull ? 1u : 0u) << k;
@@ -930,8 +986,8 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         constexpr int KS = BWD ? 1 : 0;
         (void)KS;
         PSTAMP(KS, 0);
-        if constexpr (kV3) {
-            // W_l (and the bias) of THIS layer: requested by waves 0-3 (4) behind the second barrier, so that the other waves
+        if constexpr (kHO) {
+            // W_l (and the bias) of THIS layer: requested by waves 0-3 (4) behind the barrier, so that the other waves
             // are already in their self halves; needed from the aggregate half on (ctl[2])
             if (it > 0) {
                 const f32x4* wc = reinterpret_cast<const f32x4*>(
@@ -961,17 +1017,22 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         if constexpr (!kV3) {
             if (it > 0 && remote && !dead) dead |= wait_blocks(a.flags, dlo, dhi, blk, fbase + 8u * (unsigned)it, a.status);
         }
+        auto publish_hook = [&]() {
+            if (it > 0) {
+                if constexpr (kV3) {
+                    wait_vmem();              // previous layer's rows written through; waves 0-3: their W_l pieces landed
+                    if (wave < (int)kCtlWaves) lds_bump(2);
+                    publish_block();
+                } else {
+                    if (wave < (int)kCtlWaves) { wait_vmem(); lds_bump(2); }      // (backward: published at the layer's end)
+                }
+            }
+            PSTAMP(KS, 1);
+        };
         auto filler_lds = [&](auto qq) {
             constexpr int Q = decltype(qq)::value;
             const char* lbase = reinterpret_cast<const char*>(rowsl);
-            if constexpr (kV3 && Q == kGo - 1) {
-                if (it > 0) {
-                    wait_vmem();                  // previous layer's rows written through; waves 0-3: their W_l pieces landed
-                    if (wave < (int)kCtlWaves) lds_bump(2);
-                    publish_block();
-                }
-                PSTAMP(KS, 1);
-            }
+            if constexpr (kHO && Q == kGo - 1) publish_hook();
             if constexpr (kV3 && Q == kGt) {
                 if (it > 0 && remote && !dead) dead |= wait_blocks(a.flags, dlo, dhi, self_excl, fbase + 8u * (unsigned)it, a.status);
                 PSTAMP(KS, 12);
@@ -1079,9 +1140,13 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                 });
             });
         };
-        contract_rr(wlds + NT * NT * 64, xs, filler);
-        static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
-        if constexpr (kV3) lds_bump(0);           // this wave's last W_r fragment has been read
+        if (wactive) {
+            contract_rr(wlds + NT * NT * 64, xs, filler);
+            static_for_<MfmaSeq<NT>::kGaps, kFillGaps>([&](auto qq) { filler(qq); __builtin_amdgcn_sched_barrier(0); });
+        } else {
+            if constexpr (kHO) publish_hook();
+        }
+        if constexpr (kHO) lds_bump(0);           // this wave's last W_r fragment has been read
         PSTAMP(KS, 2);
         f32x4 ym[BWD ? NT : 1];
         if constexpr (BWD) {
@@ -1115,11 +1180,40 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
             }
         }
         PSTAMP(KS, 3);
-        if constexpr (kV3) {
+        if constexpr (kHO) {
             while (lds_count(2) < kCtlWaves * (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(1);   // (W_l / bias of this layer in place)
         }
         PSTAMP(KS, 4);
-        contract_rr(wlds, ag, [](auto) {});
+        // W_r of the NEXT layer: its LDS region is free once every wave is through its self half (ctl[0]), which is long before
+        // this wave is through its aggregate half -- each wave requests its share of the pieces from inside the aggregate half
+        // (a counter read at a few gaps; round 4: the pieces used to be claimed by the waves that were done with the layer and
+        // landed 2-3 k ticks after the last epilogue, profiles/r04/stack_stamps_blocks.txt)
+        bool wr_issued = !kHO || it + 1 == a.n_layers;
+        auto issue_wr = [&]() {
+            const f32x4* wn = reinterpret_cast<const f32x4*>(
+                a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)(it + 1)) : (ptrdiff_t)(a.wstride * (size_t)(it + 1))));
+            for (int pc = wave; pc < NT * NT; pc += 8) {
+                const unsigned pw = (unsigned)(NT * NT + pc);
+                dma_piece(wn + pw * 64, 16 * lane, lds_w + pw * 1024);
+            }
+            wr_issued = true;
+        };
+        auto filler_agg = [&](auto qq) {
+            constexpr int Q = decltype(qq)::value;
+            if constexpr (kHO && (Q == 1 || Q == MfmaSeq<NT>::kGaps / 3 || Q == 2 * MfmaSeq<NT>::kGaps / 3)) {
+                if (!wr_issued && lds_count(0) >= 8u * (unsigned)(it + 1)) issue_wr();
+            }
+        };
+        if (wactive) contract_rr(wlds, ag, filler_agg);
+        if constexpr (kHO) {
+            if (!wr_issued) {         // (a wave without rows, or one that was ahead of the others at every check)
+                while (lds_count(0) < 8u * (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(2);      // every self half is over
+                issue_wr();
+            }
+            // the pieces have landed (requested a few thousand ticks ago) BEFORE the epilogue's stores are issued: nothing
+            // waits for a write-through acknowledge on the way to the barrier
+            wait_vmem();
+        }
         PSTAMP(KS, 5);
         // epilogue: the stored rows ARE the next layer's self rows, in the same lane layout -> they stay in xs
         if (valid) {
@@ -1158,30 +1252,20 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         PSTAMP(KS, 6);
         if (it + 1 == a.n_layers) break;
         // ---- between two layers ----
-        if constexpr (kV3) {
-            const f32x4* wn = reinterpret_cast<const f32x4*>(
-                a.w0 + (BWD ? -(ptrdiff_t)(a.wstride * (size_t)(it + 1)) : (ptrdiff_t)(a.wstride * (size_t)(it + 1))));
-            while (lds_count(0) < 8u * (unsigned)(it + 1)) __builtin_amdgcn_s_sleep(2);      // every self half is over
-            PSTAMP(KS, 7);
-            bool issued = false;
-            while (true) {
-                unsigned pc = 0;
-                if (lane == 0) pc = __hip_atomic_fetch_add(ctl + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pc = __builtin_amdgcn_readfirstlane(pc);
-                if (pc >= (unsigned)(NT * NT)) break;
-                const unsigned pw = (unsigned)(NT * NT) + pc;
-                dma_piece(wn + pw * 64, 16 * lane, lds_w + pw * 1024);
-                issued = true;
-            }
-            if (issued) wait_vmem();
-            PSTAMP(KS, 8);
-            lds_barrier();            // every wave is past its MFMAs and its reads of the LDS rows; W_r of the next layer complete
-            PSTAMP(KS, 9);
+        if constexpr (kHO) {
+            // every self half is over (this wave's W_r pieces could be requested): nobody reads the LDS row copy any more, this
+            // wave's output rows go there now; ONE barrier: rows written, W_r landed, every aggregate half over (W_l may be
+            // replaced: requested at the top of the next layer)
             rows_to_lds();
-            if (tid == 0) ctl[1] = 0u;
-            PSTAMP(KS, 10);
+            if constexpr (BWD) {
+                // the block's signal, behind this wave's acknowledged stores (the eighth arrival raises the global counter); and
+                // every wave is past this point before anybody leaves the barrier: a long row may read its own block's rows
+                wait_vmem();
+                publish_block();
+            }
+            PSTAMP(KS, 8);
             lds_barrier();
-            PSTAMP(KS, 11);
+            PSTAMP(KS, 9);
             xin = out;
             continue;
         }
@@ -1650,11 +1734,11 @@ static int stack_occupancy(int nt, bool bwd) {
         default: return 0;
     }
 }
-static bool persist_fits(int n, int nt, int layers, hipStream_t st, bool bwd) {
+static bool persist_fits(int n, int nblocks, int nt, int layers, hipStream_t st, bool bwd) {
     const int ov = g_persist_override.load();
     if (ov == 0) return false;
     if (!(nt >= 3 && layers >= 2 && n > 0 && persist_ready(st))) return false;
-    const int blocks = (n + 127) / 128;
+    const int blocks = nblocks > 0 ? nblocks : (n + 127) / 128;
     if (blocks > kStackFlagWords || cu_mask_in_force()) return false;
     const bool capturing = stream_capturing(st);
     const int occ = capturing ? 1 : stack_occupancy(nt, bwd);     // (no occupancy query inside a capture: queried by the warm-up)
@@ -1674,7 +1758,7 @@ static void launch_stack_fwd(StackKArgs a, hipStream_t st) {
     {
         KernelTimer kt(HEXGNN_K_SAGE_FWD, st);
         if constexpr (NT >= 3)
-            sage_stack_fwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
+            sage_stack_fwd_kernel<NT><<<a.bstart ? a.nblocks : (a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
     }
     note_stack_launch(st);
 }
@@ -1690,7 +1774,7 @@ static void launch_stack_bwd(StackKArgs a, hipStream_t st) {
     {
         KernelTimer kt(HEXGNN_K_SAGE_BWD, st);
         if constexpr (NT >= 3)
-            sage_stack_bwd_kernel<NT><<<(a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
+            sage_stack_bwd_kernel<NT><<<a.bstart ? a.nblocks : (a.n + 127) / 128, 512, 2 * NT * NT * 1024 + RowsLds<NT>::bytes + 64 + 1024, st>>>(a);
     }
     note_stack_launch(st);
 }
@@ -1884,9 +1968,26 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
                               const float* invdeg, const float* x, int x_stride, const float* const* wl,
                               const float* const* bl, const float* const* wr, void* wpack, float* acts,
                               void* saved, int need_backward, int flags, hexgnn_stream_t stream_) {
+    return hexgnn_sage_stack_forward_blocks(n, c_in, hidden, num_layers, rowptr, col, invdeg, x, x_stride, wl, bl, wr, wpack, acts,
+                                            saved, need_backward, flags, nullptr, 0, stream_);
+}
+
+// a block table is usable when it can be a partition of [0, n) into at most kStackFlagWords pieces of at most 128 rows (its
+// CONTENT is device data: checked by the kernel, block by block)
+static bool block_table_ok(int n, const int* block_starts, int num_blocks) {
+    if (!block_starts) return num_blocks == 0;
+    return num_blocks >= (n + 127) / 128 && num_blocks >= 1 && num_blocks <= kStackFlagWords && num_blocks <= n;
+}
+
+int hexgnn_sage_stack_forward_blocks(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                     const float* invdeg, const float* x, int x_stride, const float* const* wl,
+                                     const float* const* bl, const float* const* wr, void* wpack, float* acts,
+                                     void* saved, int need_backward, int flags, const int* block_starts, int num_blocks,
+                                     hexgnn_stream_t stream_) {
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
+    if (n > 0 && !block_table_ok(n, block_starts, num_blocks)) return HEXGNN_EINVAL;
     if (hidden > 16 * kMaxNT) {        // 129..256: the plain kernels of wide.hip (always materialise the aggregates in `saved`)
         if (!wl || !bl || !wr || !wpack) return HEXGNN_EINVAL;
         if (n > 0 && (!rowptr || !col || !invdeg || !x || !acts)) return HEXGNN_EINVAL;
@@ -1910,7 +2011,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
     rc = take_stack_status();
     if (rc != HEXGNN_OK) return rc;
     const int fh = p.small_first ? 1 : 0;
-    const bool one_launch = persist_fits(n, p.nt, p.L - fh, st, false);
+    const bool one_launch = persist_fits(n, block_starts ? num_blocks : 0, p.nt, p.L - fh, st, false);
     for (int l = 0; l < p.L; ++l) {
         float* y = acts + slab * l;
         const float* bias = (const float*)(wp + p.bias_off[l]);
@@ -1932,6 +2033,7 @@ int hexgnn_sage_stack_forward(int n, int c_in, int hidden, int num_layers, const
             a.agg0 = need_backward ? sv + p.agg_off[l] : nullptr;
             a.astride = p.L - l > 1 ? p.agg_off[l + 1] - p.agg_off[l] : 0;
             a.flags = reinterpret_cast<unsigned*>(wp + p.flag_off);
+            a.bstart = block_starts; a.nblocks = num_blocks;
             a.status = g_stack_status;
             HEXGNN_NT_SWITCH(p.nt, (launch_stack_fwd<NT_>(a, st)));
             break;
@@ -1969,10 +2071,23 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
                                    const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
                                    float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
                                    int tap_layer, float* tap_out, hexgnn_stream_t stream_) {
+    return hexgnn_sage_stack_backward_blocks(n, c_in, hidden, num_layers, rowptr, col, rowptr_t, col_t, invdeg, x, x_stride, acts,
+                                             saved, wpack, dy, dx, d_wl, d_bl, d_wr, workspace, workspace_bytes, flags,
+                                             tap_layer, tap_out, nullptr, 0, stream_);
+}
+
+int hexgnn_sage_stack_backward_blocks(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                      const int* rowptr_t, const int* col_t, const float* invdeg, const float* x,
+                                      int x_stride, const float* acts, const void* saved, const void* wpack,
+                                      const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
+                                      float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
+                                      int tap_layer, float* tap_out, const int* block_starts, int num_blocks,
+                                      hexgnn_stream_t stream_) {
     (void)rowptr; (void)col;
     hipStream_t st = (hipStream_t)stream_;
     StackPlan p;
     if (n < 0 || (flags & ~(HEXGNN_SAGE_LINEAR_LAST | HEXGNN_SAGE_DY_IN_PLACE))) return HEXGNN_EINVAL;
+    if (n > 0 && !block_table_ok(n, block_starts, num_blocks)) return HEXGNN_EINVAL;
     if ((flags & HEXGNN_SAGE_DY_IN_PLACE) && (flags & HEXGNN_SAGE_LINEAR_LAST)) return HEXGNN_EINVAL;
     if (hidden > 16 * kMaxNT) {
         if (!d_wl || !d_bl || !d_wr || !wpack || !saved) return HEXGNN_EINVAL;
@@ -2026,7 +2141,7 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
     rc = take_stack_status();
     if (rc != HEXGNN_OK) return rc;
     const int lo = (first_hidden == 0 && !dx) ? 1 : first_hidden;        // last layer whose data gradient is wanted
-    const bool one_launch = persist_fits(n, p.nt, p.L - lo, st, true);
+    const bool one_launch = persist_fits(n, block_starts ? num_blocks : 0, p.nt, p.L - lo, st, true);
     if (one_launch) {
         StackKArgs a{};
         a.n = n; a.l_first = p.L - 1; a.n_layers = p.L - lo;
@@ -2036,6 +2151,7 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers, 
         a.slabs = G; a.slab = slab; a.masks = acts; a.dx = dx;
         a.w0 = wp + p.bwd_off[p.L - 1]; a.wstride = p.bwd_off[p.L - 1] - p.bwd_off[p.L - 2];
         a.flags = reinterpret_cast<unsigned*>(const_cast<char*>(wp) + p.flag_off) + kStackFlagWords;
+        a.bstart = block_starts; a.nblocks = num_blocks;
         a.status = g_stack_status;
         HEXGNN_NT_SWITCH(p.nt, (launch_stack_bwd<NT_>(a, st)));
     }
@@ -2219,6 +2335,10 @@ int hexgnn_debug_occupy(int blocks, int usec, const void* buffer, size_t buffer_
 }
 
 #ifdef HEXGNN_STAMPS
+int hexgnn_debug_stamp_block(int block) {
+    if (hipDeviceSynchronize() != hipSuccess) return HEXGNN_EHIP;
+    return hipMemcpyToSymbol(HIP_SYMBOL(hexgnn::g_stamp_block), &block, sizeof(int)) == hipSuccess ? HEXGNN_OK : HEXGNN_EHIP;
+}
 // profiling builds only: s_memtime stamps of the layer-major kernels' last launches -> `out` (host pointer, 2 x 8 x 8)
 int hexgnn_debug_layer_stamps(unsigned long long* out, int capacity) {
     if (capacity < 128) return HEXGNN_EINVAL;

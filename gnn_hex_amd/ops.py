@@ -85,6 +85,24 @@ def sticky_status(device) -> torch.Tensor:
     return t
 
 
+def _blocks_of(edge_index, n: int):
+    """The collation's row-block table of a batch (``edge_index._hex_blocks`` = (int32 device tensor [nb + 1], nb), attached by
+    ``Batch.from_data_list(..., pack=True)`` / ``data.attach_blocks``): graph-aligned blocks for the one-launch stack kernels
+    (``hexgnn_sage_stack_*_blocks``).  Anything malformed is ignored (the default 128-row blocks then)."""
+    blk = getattr(edge_index, "_hex_blocks", None)
+    if blk is None:
+        return None
+    try:
+        t, nb = blk
+        nb = int(nb)
+    except (TypeError, ValueError):
+        return None
+    if not (torch.is_tensor(t) and t.dtype == torch.int32 and t.is_cuda and t.is_contiguous() and t.dim() == 1
+            and t.numel() == nb + 1 and (int(n) + 127) // 128 <= nb <= min(512, max(int(n), 1))):
+        return None
+    return (t, nb)
+
+
 class GraphStructure:
     """Target-major CSR of a batch + its transpose + 1/deg, built once per batch on the device.
 
@@ -92,7 +110,7 @@ class GraphStructure:
     Replaces the per-layer x[edge_index[0]] / scatter(edge_index[1]) indexing of the reference
     (GN0/models.py:276)."""
 
-    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status", "_ptrs")
+    __slots__ = ("n", "e", "rowptr", "col", "rowptr_t", "col_t", "invdeg", "status", "_ptrs", "blocks")
 
     def __init__(self, edge_index: torch.Tensor, num_nodes: int, gptr: Optional[torch.Tensor] = None, b: int = 0,
                  ptr64: Optional[torch.Tensor] = None):
@@ -103,6 +121,7 @@ class GraphStructure:
         _require_cuda(edge_index, "edge_index")
         if edge_index.dim() != 2 or edge_index.shape[0] != 2:
             raise ValueError("edge_index must be [2, E]")
+        blocks = _blocks_of(edge_index, num_nodes)
         if edge_index.dtype != torch.int64:
             edge_index = edge_index.long()
         edge_index = edge_index.contiguous()
@@ -111,6 +130,7 @@ class GraphStructure:
         L = _lib.lib()
         self.n, self.e = n, e
         self._ptrs = None
+        self.blocks = blocks
         if gptr is not None and b > 0:
             ibuf = torch.empty(2 * (n + 1), dtype=torch.int32, device=dev)
             self.rowptr, self.rowptr_t = ibuf[:n + 1], ibuf[n + 1:2 * (n + 1)]
@@ -153,6 +173,7 @@ class GraphStructure:
         dev = edge_index.device
         n, e = int(num_nodes), int(edge_index.shape[1])
         self.n, self.e = n, e
+        self.blocks = _blocks_of(edge_index, n)
         e1 = e if e > 0 else 1
         o1, o2 = n + 1, 2 * (n + 1)
         o3, o4 = o2 + e1, o2 + 2 * e1
@@ -193,6 +214,7 @@ class GraphStructure:
         self.col_t = col if col_t is None else col_t
         self.status = sticky_status(rowptr.device)
         self._ptrs = None
+        self.blocks = None
         return self
 
     def check(self) -> None:
@@ -318,11 +340,12 @@ class SageStackFn(torch.autograd.Function):
         wpack = _bytes(L.hexgnn_sage_stack_pack_bytes(c_in, hidden, num_layers), dev)
         # (hidden > 128: the plain kernels materialise every layer's aggregate, with or without a backward)
         saved = _bytes(L.hexgnn_sage_stack_saved_bytes(n, c_in, hidden, num_layers), dev) if (need_bwd or hidden > 128) else None
-        _lib.check(L.hexgnn_sage_stack_forward(
+        blk = gs.blocks
+        _lib.check(L.hexgnn_sage_stack_forward_blocks(
             n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.invdeg.data_ptr(),
             xin.data_ptr(), x_stride, _ptr_array(wl), _ptr_array(bl), _ptr_array(wr), wpack.data_ptr(),
-            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), int(flags), _stream()),
-            "hexgnn_sage_stack_forward")
+            acts.data_ptr(), saved.data_ptr() if saved is not None else None, int(need_bwd), int(flags),
+            blk[0].data_ptr() if blk else None, blk[1] if blk else 0, _stream()), "hexgnn_sage_stack_forward_blocks")
         if need_bwd:
             ctx.gs = gs
             ctx.flags = int(flags)
@@ -344,12 +367,14 @@ class SageStackFn(torch.autograd.Function):
         grads = [torch.empty(s, dtype=torch.float32, device=dev) for s in ctx.param_shapes]
         ws_bytes = L.hexgnn_sage_stack_backward_workspace_bytes(n, c_in, hidden, num_layers)
         ws = _bytes(ws_bytes, dev)
-        _lib.check(L.hexgnn_sage_stack_backward(
+        blk = gs.blocks
+        _lib.check(L.hexgnn_sage_stack_backward_blocks(
             n, c_in, hidden, num_layers, gs.rowptr.data_ptr(), gs.col.data_ptr(), gs.rowptr_t.data_ptr(),
             gs.col_t.data_ptr(), gs.invdeg.data_ptr(), xin.data_ptr(), x_stride, acts.data_ptr(),
             saved.data_ptr(), wpack.data_ptr(), dy.data_ptr(), dx.data_ptr() if dx is not None else None,
             _ptr_array(grads[0::3]), _ptr_array(grads[1::3]), _ptr_array(grads[2::3]), ws.data_ptr(), ws_bytes,
-            ctx.flags, _stream()), "hexgnn_sage_stack_backward")
+            ctx.flags, -1, None, blk[0].data_ptr() if blk else None, blk[1] if blk else 0, _stream()),
+            "hexgnn_sage_stack_backward_blocks")
         gx = _logical(dx, hidden) if dx is not None else None
         return (gx, None, None, None, None, None) + tuple(grads)
 
@@ -1159,9 +1184,11 @@ def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: 
               gptr.data_ptr(), gs.status.data_ptr())
     t = cache.tail
     stream = _stream()
-    _lib.check(L.hexgnn_sage_stack_forward(n, c_in, hidden, tot, gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl,
-                                           wr, base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), 0, stream),
-               "hexgnn_sage_stack_forward")
+    blk = gs.blocks
+    _lib.check(L.hexgnn_sage_stack_forward_blocks(n, c_in, hidden, tot, gp[0], gp[1], gp[4], x.data_ptr(), x_stride, wl, bl,
+                                                  wr, base + a_bytes, base, base + a_bytes + w_bytes, int(need_bwd), 0,
+                                                  blk[0].data_ptr() if blk else None, blk[1] if blk else 0, stream),
+               "hexgnn_sage_stack_forward_blocks")
     h_top = base + 4 * (tot - 1) * n * hp
     _lib.check(L.hexgnn_head_forward(n, b, hidden, mode, gp[5], h_top, t[0], t[1], t[2], t[3], t[4], t[5], q.data_ptr(),
                                      out_v.data_ptr() if out_v is not None else None, base + a_bytes + w_bytes + s_bytes,
@@ -1224,11 +1251,12 @@ def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
     d_wl = vp(*[fb + 4 * offs[3 * l] for l in range(tot)])
     d_bl = vp(*[fb + 4 * offs[3 * l + 1] for l in range(tot)])
     d_wr = vp(*[fb + 4 * offs[3 * l + 2] for l in range(tot)])
-    _lib.check(L.hexgnn_sage_stack_backward_tap(
+    blk = call.gs.blocks
+    _lib.check(L.hexgnn_sage_stack_backward_blocks(
         n, c_in, hidden, tot, gp[0], gp[1], gp[2], gp[3], gp[4], call.x.data_ptr(), x_stride, base, base + a_bytes + w_bytes,
         base + a_bytes, dh_ptr, None, d_wl, d_bl, d_wr, ws.data_ptr(), ws_bytes, 2,
-        body_layers - 1 if d_emb is not None else -1, d_emb.data_ptr() if d_emb is not None else None, stream),
-        "hexgnn_sage_stack_backward_tap")
+        body_layers - 1 if d_emb is not None else -1, d_emb.data_ptr() if d_emb is not None else None,
+        blk[0].data_ptr() if blk else None, blk[1] if blk else 0, stream), "hexgnn_sage_stack_backward_blocks")
     _assign_flat_grads(cache, flat, mode)
     if call.sink is not None and d_emb is not None:
         call.sink(d_emb[:, :hidden])

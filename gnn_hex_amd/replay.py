@@ -32,8 +32,14 @@ class GraphReplayBuffer:
     buffer for maker and one for breaker transitions, multi_env_manager.py:139)."""
 
     def __init__(self, capacity: int, hex_size: int, prioritized: bool = True, alpha: float = 0.5, eps: float = 1e-6,
-                 burnin: int = 0, device="cuda"):
+                 burnin: int = 0, device="cuda", pack_blocks: bool = True):
+        """``pack_blocks`` (boards above 128 nodes, Hex-12 and larger, which run on the one-launch SAGE stack kernels): a draw is
+        listed in ``data.pack_order`` order -- indices, weights, both batches, actions, rewards and done flags alike, the order of
+        a random draw carries no meaning -- with the row-block tables attached, so that workgroups hold whole graphs or their own
+        pieces of a large one instead of whatever a multiple of 128 rows cuts."""
         self.capacity, self.hex_size = int(capacity), int(hex_size)
+        self.pack_blocks = bool(pack_blocks) and hex_size * hex_size + 2 > 128
+        self._max_blocks = None
         self.prioritized, self.alpha, self.eps, self.burnin = prioritized, float(alpha), float(eps), int(burnin)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -182,7 +188,7 @@ class GraphReplayBuffer:
             self._tree_update_td(st, None)         # new transitions enter at the running maximum priority
 
     # ---- sampling ----------------------------------------------------------------------------------------
-    def _build_batch(self, slots_dev: torch.Tensor, slots_host: np.ndarray) -> Batch:
+    def _build_batch(self, slots_dev: torch.Tensor, slots_host: np.ndarray, starts=None) -> Batch:
         L = _lib.lib()
         dev = self.device
         k = len(slots_host)
@@ -213,7 +219,10 @@ class GraphReplayBuffer:
         b._num_graphs = k
         b.x._hex_max_nodes = int(self.n_nodes[slots_host].max()) if k else 0
         b.x._hex_hint_version = b.x._version
-        b.edge_index._hex_csr = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
+        gs = ops.GraphStructure.from_csr(N, E, rowptr, col, invdeg)
+        if starts is not None and len(starts) - 1 <= self._max_blocks:
+            gs.blocks = (torch.tensor(starts, dtype=torch.int32).to(dev, non_blocking=True), len(starts) - 1)
+        b.edge_index._hex_csr = gs
         return b
 
     def sample(self, batch_size: int, beta: Optional[float] = None, generator: Optional[torch.Generator] = None):
@@ -255,8 +264,20 @@ class GraphReplayBuffer:
         ev.synchronize()
         host = host_t.numpy().copy()
         batch_size = len(host)
-        state = self._build_batch(idx, host)
-        nxt = self._build_batch(idx + self.capacity, host + self.capacity)
+        st_blocks = nx_blocks = None
+        if self.pack_blocks and batch_size:
+            from .data import blocks_for_order, pack_order
+            if self._max_blocks is None:
+                self._max_blocks = torch.cuda.get_device_properties(self.device).multi_processor_count
+            order, st_blocks = pack_order(self.n_nodes[host], max_blocks=self._max_blocks)
+            if st_blocks is not None:
+                perm = np.asarray(order, dtype=np.int64)
+                host = host[perm]
+                pd = torch.from_numpy(perm).to(self.device, non_blocking=True)
+                idx, w = idx[pd], w[pd]
+                nx_blocks = blocks_for_order(self.n_nodes[host + self.capacity])      # (same order: fewer nodes per graph)
+        state = self._build_batch(idx, host, st_blocks)
+        nxt = self._build_batch(idx + self.capacity, host + self.capacity, nx_blocks)
         # all stored states of one buffer share the mover's side (maker / breaker buffers are separate)
         state.x._hex_is_maker = bool(self.side_host[int(host[0])]) if batch_size else True
         state.x._hex_hint_version = state.x._version

@@ -148,6 +148,31 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers,
                                    void* workspace, size_t workspace_bytes, int flags,
                                    int tap_layer, float* tap_out, hexgnn_stream_t stream);
 
+/* Both directions with GRAPH-ALIGNED row blocks (round 4).  The one-launch stack kernels give every workgroup a block of at
+ * most 128 consecutive rows; by default block b = rows [128 b, 128 b + 128), which cuts graphs wherever a multiple of 128 falls,
+ * and a block that holds part of a graph waits, layer by layer, for the blocks that hold the rest.  block_starts (DEVICE array,
+ * num_blocks + 1 ascending row offsets, block_starts[0] = 0, block_starts[num_blocks] = n, pieces of at most 128 rows) lets the
+ * collation decide instead: with the graphs ordered so that blocks hold whole graphs (gnn_hex_amd.data.pack_order; the
+ * reference's Batch.from_data_list, GN0/RainbowDQN/Rainbow/common/utils.py via torch_geometric, keeps the caller's order, and
+ * the order of a replay batch carries no meaning) only graphs above 128 rows couple blocks -- the two or three they span.
+ * The table's content is checked by the kernel (a block whose range is not such a piece computes nothing and the launch
+ * reports HEXGNN_EINVAL through hexgnn_stack_status); num_blocks must lie in [ceil(n / 128), 512].  Results equal the default
+ * blocks' to fp32 rounding (the order in which a row's neighbour sum takes in-block and out-of-block neighbours differs).
+ * block_starts == NULL (num_blocks 0): exactly the calls above.  Per-layer launches (batch too large for one resident
+ * workgroup per CU, HEXGNN_NO_PERSIST) and hidden > 128 ignore the table. */
+int hexgnn_sage_stack_forward_blocks(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                     const float* invdeg, const float* x, int x_stride, const float* const* wl,
+                                     const float* const* bl, const float* const* wr, void* wpack, float* acts,
+                                     void* saved, int need_backward, int flags, const int* block_starts, int num_blocks,
+                                     hexgnn_stream_t stream);
+int hexgnn_sage_stack_backward_blocks(int n, int c_in, int hidden, int num_layers, const int* rowptr, const int* col,
+                                      const int* rowptr_t, const int* col_t, const float* invdeg, const float* x,
+                                      int x_stride, const float* acts, const void* saved, const void* wpack,
+                                      const float* dy, float* dx, float* const* d_wl, float* const* d_bl,
+                                      float* const* d_wr, void* workspace, size_t workspace_bytes, int flags,
+                                      int tap_layer, float* tap_out, const int* block_starts, int num_blocks,
+                                      hexgnn_stream_t stream);
+
 /* ---- head tail: HeadNetwork.forward after its gnn (GN0/models.py:374-384), MLP value head
  *      (GN0/models.py:36-82: Linear(4H,H/2) -> relu -> Linear(H/2,1)) and the dueling combine of
  *      DuellingTwoHeaded.forward (GN0/models.py:567-584).
