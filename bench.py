@@ -62,7 +62,8 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
     # blocks of at most 128 rows: the collation lists the graphs in gnn_hex_amd.data.pack_order order (blocks of whole graphs
     # wherever possible; the same multiset of graphs -- what Batch.from_data_list(pack=True) does) unless --no-pack
     want_pack = PACK_BATCHES and max(sizes) ** 2 + 2 > 128
-    cus = torch.cuda.get_device_properties(dev).multi_processor_count if torch.device(dev).type == "cuda" else None
+    from gnn_hex_amd import ops as _ops
+    cus = _ops.stack_block_budget(dev) if torch.device(dev).type == "cuda" else None      # CUs minus those reserved (overlap)
     batches = []
     for maker in (True, False):
         starts = None

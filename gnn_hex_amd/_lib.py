@@ -84,6 +84,7 @@ _SIGS = {
                                        vp, vp, vp, vp, vp, sz, vp, ci, ci, ci, vp]),
     "hexgnn_stack_status": (ci, [ci]),
     "hexgnn_stack_reserve_cus": (ci, [ci]),
+    "hexgnn_stack_block_budget": (ci, []),
     "hexgnn_debug_stack_mode": (ci, [ci, C.c_uint]),
     "hexgnn_debug_occupy": (ci, [ci, ci, vp, sz, vp, vp]),
     "hexgnn_qnet_forward_td": (ci, [ci, ci, ci, ci, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci,

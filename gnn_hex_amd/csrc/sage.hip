@@ -2011,7 +2011,11 @@ int hexgnn_sage_stack_forward_blocks(int n, int c_in, int hidden, int num_layers
     rc = take_stack_status();
     if (rc != HEXGNN_OK) return rc;
     const int fh = p.small_first ? 1 : 0;
-    const bool one_launch = persist_fits(n, block_starts ? num_blocks : 0, p.nt, p.L - fh, st, false);
+    bool one_launch = persist_fits(n, block_starts ? num_blocks : 0, p.nt, p.L - fh, st, false);
+    if (!one_launch && block_starts && persist_fits(n, 0, p.nt, p.L - fh, st, false)) {
+        one_launch = true;           // the table's blocks do not fit the resident-workgroup budget, the default 128-row blocks do
+        block_starts = nullptr; num_blocks = 0;
+    }
     for (int l = 0; l < p.L; ++l) {
         float* y = acts + slab * l;
         const float* bias = (const float*)(wp + p.bias_off[l]);
@@ -2141,7 +2145,11 @@ int hexgnn_sage_stack_backward_blocks(int n, int c_in, int hidden, int num_layer
     rc = take_stack_status();
     if (rc != HEXGNN_OK) return rc;
     const int lo = (first_hidden == 0 && !dx) ? 1 : first_hidden;        // last layer whose data gradient is wanted
-    const bool one_launch = persist_fits(n, block_starts ? num_blocks : 0, p.nt, p.L - lo, st, true);
+    bool one_launch = persist_fits(n, block_starts ? num_blocks : 0, p.nt, p.L - lo, st, true);
+    if (!one_launch && block_starts && persist_fits(n, 0, p.nt, p.L - lo, st, true)) {
+        one_launch = true;           // (as in the forward call)
+        block_starts = nullptr; num_blocks = 0;
+    }
     if (one_launch) {
         StackKArgs a{};
         a.n = n; a.l_first = p.L - 1; a.n_layers = p.L - lo;
@@ -2303,6 +2311,17 @@ int hexgnn_stack_status(int clear) {
 int hexgnn_stack_reserve_cus(int cus) {
     if (cus < 0) return HEXGNN_EINVAL;
     return g_reserved_cus.exchange(cus);
+}
+
+int hexgnn_stack_block_budget(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    if (cu_mask_in_force()) return 0;
+    const int b = cus - g_reserved_cus.load();
+    return b < 0 ? 0 : (b > kStackFlagWords ? kStackFlagWords : b);
 }
 
 int hexgnn_debug_stack_mode(int persist, unsigned skew_seed) {

@@ -177,7 +177,7 @@ class Batch(Data):
         """``pack=True`` (graphs above 128 nodes in the batch -- Hex-12 and larger, mixed sizes): the graphs are collated in
         ``pack_order`` order with its row-block table attached, and ``batch.order`` (LongTensor [num_graphs]) says which entry
         of ``data_list`` sits at each position -- per-graph quantities of the caller (actions, targets, weights) go through
-        ``t[batch.order]``.  ``max_blocks``: see ``pack_order`` (default: the device's CU count)."""
+        ``t[batch.order]``.  ``max_blocks``: see ``pack_order`` (default: ``ops.stack_block_budget``, the CUs the one-launch kernels may fill)."""
         if hasattr(data_list, "to_batch"):      # an Env_manager observation is already batched on the device
             return data_list.to_batch()
         out = cls()
@@ -187,7 +187,8 @@ class Batch(Data):
         if pack:
             dev0 = data_list[0].x.device
             if max_blocks is None and dev0.type == "cuda":
-                max_blocks = torch.cuda.get_device_properties(dev0).multi_processor_count
+                from . import ops
+                max_blocks = ops.stack_block_budget(dev0)
             order, starts = pack_order([int(d.x.shape[0]) for d in data_list], BLOCK_ROWS, max_blocks)
             data_list = [data_list[g] for g in order]
             out.order = torch.tensor(order, dtype=torch.long)

@@ -394,6 +394,15 @@ def sage_stack(x: torch.Tensor, gs: GraphStructure, c_in: int, hidden: int, conv
     return out
 
 
+def stack_block_budget(device=None) -> int:
+    """Row blocks the one-launch stack kernels may use on ``device`` right now (CUs minus those reserved for kernels that run
+    beside them, ``GradSync.enable_overlap``): what ``data.pack_order`` packs against."""
+    if device is not None and torch.device(device).type == "cuda":
+        with torch.cuda.device(device):
+            return int(_lib.lib().hexgnn_stack_block_budget())
+    return int(_lib.lib().hexgnn_stack_block_budget())
+
+
 class live_rows:
     """``with ops.live_rows(count):`` -- inside, the whole-batch LayerNorm calls (``sage_norm_stack``, ``graph_layernorm``) take
     their row count from ``count`` (a 1-element int32 device tensor, at most the buffers' row count) instead of the tensors'

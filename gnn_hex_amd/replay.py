@@ -267,8 +267,7 @@ class GraphReplayBuffer:
         st_blocks = nx_blocks = None
         if self.pack_blocks and batch_size:
             from .data import blocks_for_order, pack_order
-            if self._max_blocks is None:
-                self._max_blocks = torch.cuda.get_device_properties(self.device).multi_processor_count
+            self._max_blocks = ops.stack_block_budget(self.device)      # (a host-side query; changes with GradSync.enable_overlap)
             order, st_blocks = pack_order(self.n_nodes[host], max_blocks=self._max_blocks)
             if st_blocks is not None:
                 perm = np.asarray(order, dtype=np.int64)

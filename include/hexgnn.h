@@ -395,6 +395,9 @@ int hexgnn_qnet_backward_flat(int n, int b, int c_in, int hidden, int total_laye
  * value.  The guard also keeps to per-layer launches while a one-launch kernel of this process is in flight on another stream. */
 int hexgnn_stack_status(int clear);
 int hexgnn_stack_reserve_cus(int cus);
+/* Row blocks a one-launch stack kernel may have right now on the current device (one resident workgroup per CU, minus the
+ * reserved CUs; 0 under a CU mask): the budget a collation packs against (gnn_hex_amd.data.pack_order's max_blocks). */
+int hexgnn_stack_block_budget(void);
 /* Test aids (tests/test_gpu_stack_stress.py): persist -1 = default (HEXGNN_NO_PERSIST decides), 0 = per-layer launches, 1 = one
  * launch where the guard allows; skew_seed != 0 delays every workgroup by a pseudo-random time per layer.  hexgnn_debug_occupy:
  * `blocks` 1024-thread workgroups streaming `buffer` for ~usec microseconds on `stream` (uneven load beside a stack kernel). */

@@ -173,3 +173,34 @@ def test_replay_draws_of_large_boards_are_packed():
         q0 = hip(ref.x, ref.edge_index, ref.batch, ref.ptr)
     torch.cuda.synchronize()
     assert _close(torch.as_tensor(q1), torch.as_tensor(q0)) and _lib.lib().hexgnn_stack_status(1) == 0
+
+
+def test_table_over_the_block_budget_falls_back_to_default_blocks():
+    """CUs reserved for kernels running beside the stack kernels (GradSync.enable_overlap) shrink the resident-workgroup budget:
+    a table with more blocks than that is ignored (default 128-row blocks, still one launch when those fit), never launched."""
+    from gnn_hex_amd import _lib, ops
+    from gnn_hex_amd.data import Batch
+    hip, _ = make_pair(3, 110, seed=8)
+    dl = _data_list([5 + (g % 9) for g in range(63)])
+    bt = Batch.from_data_list(dl, pack=True)
+    nb = bt.edge_index._hex_blocks[1]
+    dflt = (int(bt.x.shape[0]) + 127) // 128
+    assert nb > dflt + 2
+    L = _lib.lib()
+    budget0 = ops.stack_block_budget(bt.x.device)
+    assert budget0 >= nb
+    with torch.no_grad():
+        q0 = torch.as_tensor(hip(bt.x, bt.edge_index, bt.batch, bt.ptr)).clone()
+    try:
+        L.hexgnn_stack_reserve_cus(budget0 - (dflt + 1))
+        assert ops.stack_block_budget(bt.x.device) == dflt + 1
+        with torch.no_grad():
+            q1 = torch.as_tensor(hip(bt.x, bt.edge_index, bt.batch, bt.ptr)).clone()
+        # a batch collated now packs against the smaller budget: no table that cannot run
+        again = Batch.from_data_list(dl, pack=True)
+        blk = getattr(again.edge_index, "_hex_blocks", None)
+        assert blk is None or blk[1] <= dflt + 1
+    finally:
+        L.hexgnn_stack_reserve_cus(0)
+    torch.cuda.synchronize()
+    assert _close(q1, q0) and L.hexgnn_stack_status(1) == 0
