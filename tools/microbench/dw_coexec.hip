@@ -22,7 +22,16 @@ using namespace hexgnn;
 #ifndef DW_S
 #define DW_S 32
 #endif
-constexpr int NT = 7, HP = 16 * NT, LAYERS = 16, N = 31488, S = DW_S, RPS = ((N + S - 1) / S + 31) / 32 * 32;
+#ifndef DW_NT
+#define DW_NT 7
+#endif
+#ifndef DW_N
+#define DW_N 31488
+#endif
+#ifndef DW_LAYERS
+#define DW_LAYERS 16
+#endif
+constexpr int NT = DW_NT, HP = 16 * NT, LAYERS = DW_LAYERS, N = DW_N, S = DW_S, RPS = ((N + S - 1) / S + 31) / 32 * 32;
 
 template <int VT, int E, int MV = 0>
 static float run(const DwArgs& a, float* part, int reps, hipStream_t st) {
@@ -79,6 +88,13 @@ int main(int argc, char** argv) {
     };
     const double flop = 2.0 * LAYERS * (double)N * HP * (2 * HP + 1);
     // warm the clocks, then alternate the variants a few times (boxes drift)
+#if DW_NT < 4
+    for (int round = 0; round < 3; ++round) {
+        const float t = run<0, 2>(a, part_ref, reps, st);
+        printf("round %d  NT %d N %d layers %d S %d RH %d: %7.1f us  %6.1f TFLOP/s\n", round, NT, N, LAYERS, S, HEXGNN_DW_RH, t, flop / t * 1e-6);
+    }
+    return 0;
+#endif
     for (int round = 0; round < 3; ++round) {
         float t;
         t = run<0, 2>(a, part_ref, reps, st); printf("round %d  <VT 0, E 2> %7.1f us  %6.1f TFLOP/s\n", round, t, flop / t * 1e-6);
