@@ -13,19 +13,24 @@ Every forward / backward runs in libhexgnn.so (CUDA(HIP) tensors only, no CPU fa
   linear fed with zeros);
 * terminal-node removal, swap-logit insertion and ``scatter_log_softmax``: ``hexgnn_policy_log_softmax_*``.
 
-Out of scope (NotImplementedError): ``norm`` other than None (``get_current_model``'s default), the PNA / CNN / Unet / Gao
-variants of the same file.  TorchScript tracing (``rl_loop/trace_model.py``) does not apply: the model already is native code.
+``norm=LayerNorm`` (``gnn_hex_amd.models.LayerNorm`` for pyg's, the option rl_loop/train_config.py:10,131 offers; round 4): conv ->
+whole-batch LayerNorm -> relu for all layers of a net but the last (``ops.sage_norm_stack``), the last conv on its own, and
+``before_head_norm`` on the embeddings (GN0/torch_script_models.py:151-160, 179-187, 306, 316-317).
+
+Out of scope (NotImplementedError): other norms, the PNA / CNN / Unet / Gao variants of the same file.  TorchScript tracing (``rl_loop/trace_model.py``) does not apply: the model already is native code.
 """
 from __future__ import annotations
 
 from typing import Optional
+
+import copy
 
 import torch
 from torch import Tensor
 from torch.nn import ModuleList
 
 from . import ops
-from .models import MLP, SAGEConv
+from .models import MLP, LayerNorm, SAGEConv
 
 
 class ModifiedSAGEConv(SAGEConv):
@@ -39,8 +44,9 @@ class ModifiedBaseNet(torch.nn.Module):
     def __init__(self, in_channels: int, hidden_channels: int, num_layers: int, out_channels: Optional[int] = None,
                  conv_class=ModifiedSAGEConv, norm=None, norm_kwargs=None, **kwargs):
         super().__init__()
-        if norm is not None:
-            raise NotImplementedError("ModifiedBaseNet: only norm=None (get_current_model's default) is on the HIP path")
+        if norm is not None and not isinstance(norm, LayerNorm):
+            raise NotImplementedError("ModifiedBaseNet: norm is None or a gnn_hex_amd.models.LayerNorm instance (pyg's LayerNorm "
+                                      "in the batch-less call form, rl_loop/train_config.py:10,131)")
         if conv_class is not ModifiedSAGEConv or kwargs:
             raise NotImplementedError("ModifiedBaseNet: only ModifiedSAGEConv without extra arguments")
         if out_channels not in (None, 1):
@@ -67,6 +73,10 @@ class ModifiedBaseNet(torch.nn.Module):
         else:
             self.convs.append(self.init_conv(c, hidden_channels))
         self.norms = None
+        if norm is not None:             # GN0/torch_script_models.py:151-160: one copy per layer but the last
+            if hidden_channels > 128:
+                raise NotImplementedError("norms need hidden_channels <= 128")
+            self.norms = ModuleList([copy.deepcopy(norm) for _ in range(num_layers - 1)])
 
     def init_conv(self, in_channels: int, out_channels: int, **kwargs):
         return self.conv_class(in_channels, out_channels, **kwargs)
@@ -81,6 +91,14 @@ class ModifiedBaseNet(torch.nn.Module):
         ops._require_cuda(x, "x")
         gs = _graph if _graph is not None else ops.GraphStructure(edge_index, x.shape[0])
         h = self.hidden_channels
+        if self.norms is not None and len(self.norms) > 0:
+            # GN0/torch_script_models.py:179-187: conv -> norm -> relu for all layers but the last (one stack call with the
+            # whole-batch LayerNorm between a layer's contraction and its ReLU), then the last conv on its own
+            convs = list(self.convs)
+            x = ops.sage_norm_stack(x, gs, self.in_channels, h, convs[:-1], list(self.norms))
+            if self.out_channels == 1 and h != 1:
+                return ops.sage_scalar(x, gs, h, convs[-1]).view(-1, 1)
+            return ops.sage_stack(x, gs, h, h, convs[-1:], linear_last=True)
         if self.out_channels == 1 and h != 1:
             if len(self.convs) > 1:
                 x = ops.sage_stack(x, gs, self.in_channels, h, list(self.convs)[:-1])
@@ -96,22 +114,26 @@ class SAGE_torch_script(torch.nn.Module):
     def __init__(self, hidden_channels, hidden_layers, policy_layers, value_layers, in_channels=3, swap_allowed=False,
                  norm=None, **gnn_kwargs):
         super().__init__()
-        if norm is not None or gnn_kwargs:
-            raise NotImplementedError("SAGE_torch_script: norm=None and no extra conv arguments on the HIP path")
+        if gnn_kwargs:
+            raise NotImplementedError("SAGE_torch_script: no extra conv arguments on the HIP path")
+        if norm is not None and norm is not LayerNorm:
+            raise NotImplementedError("SAGE_torch_script: norm is None or the LayerNorm class (gnn_hex_amd.models.LayerNorm for "
+                                      "torch_geometric.nn.norm.LayerNorm, rl_loop/train_config.py:10,131)")
+        mk = (lambda: None) if norm is None else (lambda: norm(hidden_channels))
         self.final_conv_acts = None
         self.final_conv_grad = None
         self.swap_allowed = swap_allowed
-        self.gnn = ModifiedBaseNet(in_channels=in_channels, norm=None, hidden_channels=hidden_channels,
+        self.gnn = ModifiedBaseNet(in_channels=in_channels, norm=mk(), hidden_channels=hidden_channels,
                                    num_layers=hidden_layers, conv_class=ModifiedSAGEConv)
         self.my_modules = torch.nn.ModuleDict()
-        self.my_modules["value_head"] = ModifiedBaseNet(in_channels=hidden_channels, norm=None, hidden_channels=hidden_channels,
+        self.my_modules["value_head"] = ModifiedBaseNet(in_channels=hidden_channels, norm=mk(), hidden_channels=hidden_channels,
                                                         conv_class=ModifiedSAGEConv, num_layers=value_layers)
-        self.my_modules["policy_head"] = ModifiedBaseNet(in_channels=hidden_channels, norm=None,
+        self.my_modules["policy_head"] = ModifiedBaseNet(in_channels=hidden_channels, norm=mk(),
                                                          hidden_channels=hidden_channels, num_layers=policy_layers,
                                                          conv_class=ModifiedSAGEConv, out_channels=1)
         self.my_modules["value_linear"] = MLP(hidden_channels // 2, 1, hidden_channels * 4, 1)
         self.my_modules["swap_linear"] = MLP(hidden_channels // 2, 1, hidden_channels * 4, 1)
-        self.before_head_norm = None
+        self.before_head_norm = mk()          # GN0/torch_script_models.py:306
         self.value_activation = torch.nn.Tanh()
 
     def activations_hook(self, grad):
@@ -137,6 +159,8 @@ class SAGE_torch_script(torch.nn.Module):
         gs = ops.GraphStructure(edge_index, n)
         gptr = batch_ptr.to(torch.int32)
         embeds = self.gnn(x, edge_index, _graph=gs)
+        if self.before_head_norm is not None:                   # GN0/torch_script_models.py:316-317
+            embeds = self.before_head_norm(embeds)
         self.final_conv_acts = embeds.detach()
         if embeds.requires_grad:
             embeds.register_hook(self.activations_hook)

@@ -7,14 +7,18 @@ reference's own ``rl_loop/unittest_model.py:16-92`` holds exact expected sizes, 
 hand-made batches and the invariants of a randomized test; ``tests/test_oracle_hexara.py`` checks this file against them.
 
 * ``ModifiedBaseNetRef``   <- GN0/torch_script_models.py:75-189 (layer layout 123-144; forward 167-189: activation after
-                              every layer but the last, norms unsupported here = ``norm=None``, the default of
-                              ``get_current_model``, line 495)
+                              every layer but the last; with ``norm`` -- an INSTANCE, deep-copied per layer like
+                              normalization_resolver does (151-160) -- conv -> norm -> relu for all layers but the last, then
+                              the last conv alone (177-187).  rl_loop/train_config.py:10,131 offers pyg's LayerNorm, called
+                              without a batch vector: ``model_ref.LayerNormRef``)
 * ``SageTorchScriptRef``   <- GN0/torch_script_models.py:286-379; the output surgery (326-376) restated graph by graph
 * ``scatter_log_softmax_ref`` <- torch_scatter 2.1.0 ``composite.scatter_log_softmax``: per group, x - max, then
                               minus log(sum(exp(.)))
 * ``get_current_model_ref`` <- GN0/torch_script_models.py:495-507, ``net_type="SAGE"``
 """
 from __future__ import annotations
+
+import copy
 
 import torch
 from torch import Tensor
@@ -33,8 +37,6 @@ def scatter_log_softmax_ref(src: Tensor, index: Tensor) -> Tensor:
 class ModifiedBaseNetRef(torch.nn.Module):
     def __init__(self, in_channels: int, hidden_channels: int, num_layers: int, out_channels=None, norm=None, **_):
         super().__init__()
-        if norm is not None:
-            raise NotImplementedError("oracle: norm=None only (get_current_model's default)")
         self.in_channels, self.hidden_channels, self.num_layers = in_channels, hidden_channels, num_layers
         self.out_channels = out_channels if out_channels is not None else hidden_channels
         self.convs = torch.nn.ModuleList()
@@ -47,13 +49,22 @@ class ModifiedBaseNetRef(torch.nn.Module):
             c = hidden_channels
         self.convs.append(SAGEConvRef(c, self.out_channels))
         self.norms = None
+        if norm is not None:                 # GN0/torch_script_models.py:151-160
+            self.norms = torch.nn.ModuleList([copy.deepcopy(norm) for _ in range(num_layers - 1)])
 
     def forward(self, x: Tensor, edge_index: Tensor) -> Tensor:
-        for i, conv in enumerate(self.convs):
+        if self.norms is None:               # GN0/torch_script_models.py:173-178
+            for i, conv in enumerate(self.convs):
+                x = conv(x, edge_index)
+                if i != self.num_layers - 1:
+                    x = torch.relu(x)
+            return x
+        assert len(self.norms) == len(self.convs) - 1          # 179-187
+        for i, (norm, conv) in enumerate(zip(self.norms, self.convs)):
             x = conv(x, edge_index)
             if i != self.num_layers - 1:
-                x = torch.relu(x)
-        return x
+                x = torch.relu(norm(x))
+        return self.convs[-1](x, edge_index)
 
 
 class SageTorchScriptRef(torch.nn.Module):
@@ -63,14 +74,15 @@ class SageTorchScriptRef(torch.nn.Module):
         self.final_conv_acts = None
         self.final_conv_grads = None
         self.swap_allowed = swap_allowed
-        self.gnn = ModifiedBaseNetRef(in_channels, hidden_channels, hidden_layers, norm=norm)
+        mk = (lambda: None) if norm is None else (lambda: norm(hidden_channels))      # (292-298: a fresh instance per net)
+        self.gnn = ModifiedBaseNetRef(in_channels, hidden_channels, hidden_layers, norm=mk())
         self.my_modules = torch.nn.ModuleDict()
-        self.my_modules["value_head"] = ModifiedBaseNetRef(hidden_channels, hidden_channels, value_layers, norm=norm)
+        self.my_modules["value_head"] = ModifiedBaseNetRef(hidden_channels, hidden_channels, value_layers, norm=mk())
         self.my_modules["policy_head"] = ModifiedBaseNetRef(hidden_channels, hidden_channels, policy_layers, out_channels=1,
-                                                            norm=norm)
+                                                            norm=mk())
         self.my_modules["value_linear"] = MLPRef(hidden_channels // 2, 1, hidden_channels * 4, 1)
         self.my_modules["swap_linear"] = MLPRef(hidden_channels // 2, 1, hidden_channels * 4, 1)
-        self.before_head_norm = None
+        self.before_head_norm = mk()          # 306
         self.value_activation = torch.nn.Tanh()
 
     def activations_hook(self, grad):
@@ -79,6 +91,8 @@ class SageTorchScriptRef(torch.nn.Module):
     def forward(self, x: Tensor, edge_index: Tensor, graph_indices: Tensor, batch_ptr: Tensor):
         assert ((batch_ptr[1:] - batch_ptr[:-1]) > 2).all()
         embeds = self.gnn(x, edge_index)
+        if self.before_head_norm is not None:                  # 316-317
+            embeds = self.before_head_norm(embeds)
         self.final_conv_acts = embeds
         if embeds.requires_grad:
             embeds.register_hook(self.activations_hook)

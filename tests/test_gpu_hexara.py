@@ -12,14 +12,21 @@ pytestmark = pytest.mark.gpu
 TOL = 1e-4
 
 
-def _pair(hidden, layers, policy_layers, value_layers, swap_allowed, seed=0):
+def _pair(hidden, layers, policy_layers, value_layers, swap_allowed, seed=0, norm=False):
+    from gnn_hex_amd.models import LayerNorm
     from gnn_hex_amd.torch_script_models import get_current_model
     from oracle.hexara_ref import get_current_model_ref
+    from oracle.model_ref import LayerNormRef
     torch.manual_seed(seed)
     ref = get_current_model_ref(hidden_channels=hidden, hidden_layers=layers, policy_layers=policy_layers,
-                                value_layers=value_layers, swap_allowed=swap_allowed)
+                                value_layers=value_layers, swap_allowed=swap_allowed, norm=LayerNormRef if norm else None)
+    if norm:
+        with torch.no_grad():                      # non-trivial affine parameters (the default is weight 1, bias 0)
+            for k, p in ref.named_parameters():
+                if "norm" in k:
+                    p.add_(torch.randn(p.shape) * 0.2)
     hip = get_current_model(hidden_channels=hidden, hidden_layers=layers, policy_layers=policy_layers,
-                            value_layers=value_layers, swap_allowed=swap_allowed)
+                            value_layers=value_layers, swap_allowed=swap_allowed, norm=LayerNorm if norm else None)
     assert list(hip.state_dict().keys()) == list(ref.state_dict().keys())
     hip.load_state_dict(ref.state_dict())
     return hip.cuda(), ref
@@ -60,7 +67,20 @@ def _loss(pi, value, gen_pi, tv):
                                                        (16, 1, 2, 2, [5, 6, 5])])
 @pytest.mark.parametrize("swap_allowed", [False, True])
 def test_sage_torch_script_matches_oracle(hidden, layers, pl, vl, sizes, swap_allowed):
-    hip, ref = _pair(hidden, layers, pl, vl, swap_allowed, seed=hidden)
+    _check_against_oracle(hidden, layers, pl, vl, sizes, swap_allowed, norm=False)
+
+
+@pytest.mark.parametrize("hidden,layers,pl,vl,sizes", [(60, 4, 2, 2, [5, 7, 6, 9]), (35, 3, 1, 3, [7, 5]), (110, 3, 3, 2, [11, 9]),
+                                                       (16, 1, 2, 2, [5, 6, 5])])
+@pytest.mark.parametrize("swap_allowed", [False, True])
+def test_sage_torch_script_with_layernorm_matches_oracle(hidden, layers, pl, vl, sizes, swap_allowed):
+    """``norm=LayerNorm`` (rl_loop/train_config.py:10,131; GN0/torch_script_models.py:151-160,179-187,306,316-317): whole-batch
+    LayerNorm between every contraction and its ReLU but the last layer's, and on the embeddings in front of the heads."""
+    _check_against_oracle(hidden, layers, pl, vl, sizes, swap_allowed, norm=True)
+
+
+def _check_against_oracle(hidden, layers, pl, vl, sizes, swap_allowed, norm):
+    hip, ref = _pair(hidden, layers, pl, vl, swap_allowed, seed=hidden, norm=norm)
     x, ei, batch, ptr = batch_tensors("D1", sizes, maker=True)
     x = x.clone()
     b = len(sizes)
@@ -114,6 +134,6 @@ def test_unsupported_variants_fail_loudly():
     with pytest.raises(NotImplementedError):
         get_current_model("PNA")
     with pytest.raises(NotImplementedError):
-        get_current_model("SAGE", norm=torch.nn.LayerNorm)
+        get_current_model("SAGE", norm=torch.nn.LayerNorm)        # (only the whole-batch LayerNorm of gnn_hex_amd.models)
     with pytest.raises(ValueError):
         get_current_model("nope")
