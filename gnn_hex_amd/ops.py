@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 import threading
 from typing import List, Optional, Sequence
 
@@ -1026,14 +1027,42 @@ def set_direct_grads(enabled: bool) -> None:
 class QNetParamCache:
     """Per (model, head): the parameter list of the fused call, its cached pointer arrays and the flat gradient layout."""
     __slots__ = ("params", "ptrs", "wl", "bl", "wr", "tail", "flat_params", "offsets", "total", "direct_ok", "tot",
-                 "sizes", "cut")
+                 "sizes", "cut", "grad_ring")
 
     def __init__(self, params, tot):
         self.params = params
         self.tot = tot
         self.ptrs = None
         self.sizes = {}          # (n, b) -> buffer sizes of the fused calls (three C queries per new batch shape)
+        self.grad_ring = []      # [(flat gradient buffer, its per-parameter views, stream)]: see grad_buffer()
         self.refresh()
+
+    def grad_buffer(self, dev):
+        """The flat buffer the backward writes and its per-parameter views.  A training loop drops its gradients every step
+        (``zero_grad(set_to_none=True)`` / ``p.grad = None``) and the next backward allocates them again: 60 views through
+        ``unflatten_dense_tensors`` cost 25 us per step -- a sixth of the host time of an eager GNN-S step.  A buffer of an
+        earlier backward is handed out again when NOBODY references any of its views any more (Python reference counts: the
+        ring's own tuple only), which is exactly when autograd's freshly allocated gradients would be indistinguishable
+        from it; a view still held anywhere (``p.grad`` not cleared, a list of gradients kept for logging) leaves that buffer
+        alone (``Tensor._use_count()`` sees the holders Python reference counts do not: ``.grad`` itself).  Not inside a HIP-graph capture (those gradients must come from the graph's pool)."""
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty(self.total, dtype=torch.float32, device=dev), None
+        rc = sys.getrefcount
+        st = _stream()
+        for flat, views, owner in self.grad_ring:
+            if owner == st and flat.device == dev:      # (same stream only: the caching allocator's rule for a freed block)
+                for v in views:
+                    # Python side: the tuple, the loop variable, the argument; C++ side (a .grad, a saved tensor): the wrapper only
+                    if rc(v) != 3 or v._use_count() != 1:
+                        break
+                else:
+                    return flat, views
+        flat = torch.empty(self.total, dtype=torch.float32, device=dev)
+        views = tuple(torch._C._nn.unflatten_dense_tensors(flat, self.flat_params))
+        if len(self.grad_ring) >= 3:
+            self.grad_ring.pop(0)
+        self.grad_ring.append((flat, views, st))
+        return flat, views
 
     def refresh(self):
         params, tot = self.params, self.tot
@@ -1051,6 +1080,7 @@ class QNetParamCache:
         self.flat_params = [params[i] for i in order]
         self.offsets = (C.c_int64 * len(params))(*offs)
         self.total = o
+        self.grad_ring = []
         self.cut = offs[3 * (1 + tot // 2)] if tot >= 3 else 0      # flat position where the staged backward splits
         # (post-accumulate-grad hooks -- optimizer-in-backward, FSDP-style reducers -- hang off AccumulateGrad, which the direct
         # path never runs: such parameters take the autograd form, like tensor hooks do)
@@ -1214,10 +1244,11 @@ def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: 
     return q, out_v, call
 
 
-def _assign_flat_grads(cache: QNetParamCache, flat: torch.Tensor, mode: int) -> None:
+def _assign_flat_grads(cache: QNetParamCache, flat: torch.Tensor, mode: int, views=None) -> None:
     """Views of the flat gradient buffer -> ``p.grad`` (accumulating into a gradient that is already there)."""
     fp = cache.flat_params
-    views = torch._C._nn.unflatten_dense_tensors(flat, fp)
+    if views is None:
+        views = torch._C._nn.unflatten_dense_tensors(flat, fp)
     skip = mode == 2          # advantages only: the value head (flat positions -6 .. -3) has no gradient
     k_lo, k_hi = len(fp) - 6, len(fp) - 2
     for k, (p, v) in enumerate(zip(fp, views)):
@@ -1238,7 +1269,7 @@ def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
         d_v = None
     dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
         (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
-    flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
+    flat, gviews = cache.grad_buffer(dev)
     ws = torch.empty(ws_bytes + hws_bytes, dtype=torch.uint8, device=dev)
     # the head tail writes dh * [h > 0] = G of the top layer straight into its slab of the stack's workspace
     # (HEXGNN_HEAD_MASK_DH / HEXGNN_SAGE_DY_IN_PLACE: no masked copy in between)
@@ -1266,7 +1297,8 @@ def qnet_layered_backward(call: "_QNetCall", dq, d_v=None) -> None:
         base + a_bytes, dh_ptr, None, d_wl, d_bl, d_wr, ws.data_ptr(), ws_bytes, 2,
         body_layers - 1 if d_emb is not None else -1, d_emb.data_ptr() if d_emb is not None else None,
         blk[0].data_ptr() if blk else None, blk[1] if blk else 0, stream), "hexgnn_sage_stack_backward_blocks")
-    _assign_flat_grads(cache, flat, mode)
+    _assign_flat_grads(cache, flat, mode, gviews)
+    del gviews
     if call.sink is not None and d_emb is not None:
         call.sink(d_emb[:, :hidden])
 
@@ -1326,7 +1358,7 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None, defer_lower: bool = Fa
         d_v = None
     dq = torch.zeros(n, dtype=torch.float32, device=dev) if dq is None else \
         (dq if (dq.dtype == torch.float32 and dq.is_contiguous()) else dq.float().contiguous())
-    flat = torch.empty(cache.total, dtype=torch.float32, device=dev)
+    flat, gviews = cache.grad_buffer(dev)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     d_emb = torch.empty((n, hp), dtype=torch.float32, device=dev) if call.sink is not None else None
     base = call.bufs.data_ptr()
@@ -1369,7 +1401,8 @@ def qnet_direct_backward(call: "_QNetCall", dq, d_v=None, defer_lower: bool = Fa
         hook(flat, cut, cache.total)
         _lib.check(L.hexgnn_qnet_backward_flat(*common, 4, 1, mid, _stream()), "hexgnn_qnet_backward_flat")
         hook(flat, 0, cut)
-    _assign_flat_grads(cache, flat, mode)
+    _assign_flat_grads(cache, flat, mode, gviews)
+    del gviews
     if call.sink is not None:
         call.sink(d_emb[:, :hidden])
 

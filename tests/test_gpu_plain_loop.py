@@ -140,3 +140,46 @@ def test_direct_gradient_guards():
         assert len(fired) == 1 and p0.grad is not None
     finally:
         h.remove()
+
+
+def test_gradient_buffers_are_reused_only_when_nobody_holds_them():
+    """The backward hands out the flat gradient buffer of an earlier step again once every view of it has been dropped
+    (``zero_grad(set_to_none=True)``), and leaves it alone while ``p.grad`` or any other reference still points into it:
+    gradients a caller keeps must keep their values, accumulation into uncleared gradients must add."""
+    import torch.nn.functional as F
+    from helpers import batch_tensors, make_pair, sel_and_targets
+    from gnn_hex_amd import ops
+    hip, _ = make_pair(3, 35, seed=2)
+    x, ei, bv, ptr = batch_tensors("D0", [7] * 16)
+    sel, tgt = sel_and_targets(ptr)
+    xd = ops.attach_hints(x.cuda(), True, int((ptr[1:] - ptr[:-1]).max()))
+    eid = ei.cuda()
+    eid._hex_grouped = True
+    bvd, ptrd, seld = bv.cuda(), ptr.cuda(), sel.cuda()
+    plist = [p for p in hip.parameters()]
+
+    def step(t, clear=True):
+        if clear:
+            hip.zero_grad(set_to_none=True)
+        q = hip(xd, eid, bvd, ptrd)
+        F.mse_loss(q[seld], t).backward()
+
+    t1, t2 = tgt.cuda(), (tgt * -0.5 + 0.1).cuda()
+    step(t1)
+    g1 = [p.grad for p in plist if p.grad is not None]
+    ptr1 = g1[0].data_ptr()
+    want1 = [g.clone() for g in g1]
+    step(t2)                                               # g1 is still referenced here: its buffer must not be written
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(g1, want1))
+    g2 = [p.grad.clone() for p in plist if p.grad is not None]
+    assert plist[0].grad.data_ptr() != ptr1
+    del g1
+    step(t1)                                               # nobody holds the first buffer any more: handed out again
+    torch.cuda.synchronize()
+    assert plist[0].grad.data_ptr() == ptr1
+    assert all(torch.equal(p.grad, w) for p, w in zip([p for p in plist if p.grad is not None], want1))
+    step(t2, clear=False)                                  # accumulation into gradients that are still there
+    torch.cuda.synchronize()
+    got = [p.grad for p in plist if p.grad is not None]
+    assert all(torch.allclose(g, a + b, rtol=0, atol=1e-6) for g, a, b in zip(got, want1, g2))

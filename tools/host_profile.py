@@ -1,6 +1,6 @@
 """Host-side profile of the eager training step (cProfile over N steps of `bench.py`'s step on one config): where the
 Python time of a launch-bound configuration (GNN-S B=256: kernels 0.13 ms, step 0.6 ms) goes.
-    python tools/host_profile.py [S256|L256] [steps]"""
+    python tools/host_profile.py [S256|L256] [steps] [plain]"""
 import cProfile
 import os
 import pstats
@@ -30,10 +30,15 @@ def main():
     bvd, ptrd, seld, tgtd = bv.cuda(), ptr.cuda(), sel.cuda(), tgt.cuda()
     plist = list(hip.parameters())
 
+    plain = len(sys.argv) > 3 and sys.argv[3] == "plain"      # the step as an unmodified train.py writes it
+
     def step():
         for p in plist:
             p.grad = None
         q = hip(xd, eid, bvd, ptrd)
+        if plain:
+            torch.nn.functional.mse_loss(q[seld], tgtd).backward()
+            return
         loss, _ = ops.td_loss(q, seld, tgtd)
         ops.backward(loss)
 
