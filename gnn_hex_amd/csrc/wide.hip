@@ -1,10 +1,11 @@
 // hidden_channels 129..256: the SAGE stack and the head tail beyond the widths the LDS-resident kernels are compiled for.
 //
 // Reference: CachifiedGNN.grow_width / DuellingTwoHeaded.grow_width widen a model to ANY width (GN0/models.py:187-238,
-// 497-508); no configuration of the reference goes past 110, so this path is built for coverage, not for speed: plain,
-// deterministic kernels -- a mean gather (HBM-bound), one exact-fp32 MFMA GEMM streaming its operands from L2 (no LDS
-// staging, no fusion with the gather), transposed weight copies for the backward, one wave per 16 x 16 weight-gradient tile
-// running over all rows in a fixed order, simple per-graph head-tail kernels.  Same arithmetic as the narrow kernels
+// 497-508); no configuration of the reference goes past 110, so this path is built for coverage first:
+// deterministic kernels -- a mean gather (HBM-bound), an exact-fp32 MFMA GEMM (round 4: weights streamed through LDS in K
+// chunks of 16 shared by the eight waves of a 128-row block, row operands prefetched in registers; no fusion with the
+// gather), transposed weight copies for the backward, a weight-gradient GEMM over 128 x 128 output tiles per row slice (round 4:
+// both operands staged through LDS; it was one wave per 16 x 16 tile reading straight from L2), simple per-graph head-tail kernels.  Same arithmetic as the narrow kernels
 // (v_mfma_f32_16x16x4_f32, fmaf chains in k order), same saved-tensor layout (acts [L][n][HP], agg per layer), same C entry
 // points (sage.hip / head.hip dispatch here when hidden > 128).  Not covered at these widths: the fused per-graph kernels, the
 // norms, the two_headed tail and the HexAra pieces (their entry points refuse loudly).
@@ -45,7 +46,7 @@ int wide_make_plan(int n, int c_in, int hidden, int L, WidePlan* p) {
     p->g_off = 0;
     p->tmp_off = slab * L;
     p->part_off = slab * (L + 2);               // row-slice partials of ONE weight-gradient launch (reused launch after launch)
-    p->bwd_bytes = p->part_off + align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256);
+    p->bwd_bytes = p->part_off + 2 * align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256);      // (W_l | W_r partials)
     return HEXGNN_OK;
 }
 
@@ -306,10 +307,174 @@ __global__ void wide_combine_kernel(int n, int hp, const int* __restrict__ rowpt
     reinterpret_cast<f32x4*>(out + (size_t)row * hp)[p] = v;
 }
 
+// ---- the same product, LDS-tiled (round 4) ---------------------------------------------------------------------------------
+// Block = 8 waves x 16 rows = 128 rows x ALL HP = 16 NTW columns.  K runs in chunks of 16 over [A1 | A2]: the chunk of the weight
+// operand (HP columns x 16 k, 16 KB at HP = 256) is staged in LDS once for the eight waves (double buffered, one barrier per
+// chunk; row stride 20 floats: the b128 fragment reads of 8 consecutive lanes cover the 32 banks), a wave's own row fragment
+// (16 B per lane and chunk) is prefetched in registers one chunk ahead.  Per chunk and wave: NTW b128 LDS reads, 4 NTW MFMAs
+// (tile-interleaved: consecutive MFMAs never share an accumulator).  Same operand swap and k order as wide_gemm_kernel.
+template <int NTW>
+__global__ __launch_bounds__(512) void wide_gemm_tiled_kernel(int M, const float* __restrict__ A1, const float* __restrict__ W1,
+                                                             const float* __restrict__ A2, const float* __restrict__ W2,
+                                                             const float* __restrict__ bias, const float* __restrict__ rowscale,
+                                                             int relu, float* __restrict__ C) {
+    constexpr int HP = 16 * NTW, WS = 20;
+    constexpr int kPieces = HP * 4;                       // b128 pieces of one weight chunk
+    constexpr int kPer = (kPieces + 511) / 512;
+    __shared__ __attribute__((aligned(16))) float Ws[2][HP * WS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, kk = lane >> 4;
+    const int row = blockIdx.x * 128 + wave * 16 + i;
+    const bool rv = row < M;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[NTW];
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) acc[t] = z4;
+    const int nchunks = (A2 ? 2 : 1) * NTW;
+    f32x4 wreg[kPer];
+    auto load_w = [&](int c) {
+        const float* W = c < NTW ? W1 : W2;
+        const int k0 = (c < NTW ? c : c - NTW) * 16;
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+            const int p = tid + 512 * r;
+            if (p < kPieces) wreg[r] = *reinterpret_cast<const f32x4*>(W + (size_t)(p >> 2) * HP + k0 + 4 * (p & 3));
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int r = 0; r < kPer; ++r) {
+            const int p = tid + 512 * r;
+            if (p < kPieces) *reinterpret_cast<f32x4*>(&Ws[buf][(p >> 2) * WS + 4 * (p & 3)]) = wreg[r];
+        }
+    };
+    auto load_a = [&](int c) -> f32x4 {
+        const float* A = c < NTW ? A1 : A2;
+        const int k0 = (c < NTW ? c : c - NTW) * 16;
+        return rv ? *reinterpret_cast<const f32x4*>(A + (size_t)row * HP + k0 + 4 * kk) : z4;
+    };
+    load_w(0);
+    f32x4 a_cur = load_a(0);
+    store_w(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        f32x4 a_nxt = z4;
+        if (c + 1 < nchunks) { load_w(c + 1); a_nxt = load_a(c + 1); }
+        f32x4 w4[NTW];
+#pragma unroll
+        for (int t = 0; t < NTW; ++t) w4[t] = *reinterpret_cast<const f32x4*>(&Ws[buf][(16 * t + i) * WS + 4 * kk]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+#pragma unroll
+            for (int t = 0; t < NTW; ++t) acc[t] = mfma16x16x4(w4[t][j], a_cur[j], acc[t]);
+        }
+        if (c + 1 < nchunks) store_w(buf ^ 1);            // (its readers passed the previous barrier)
+        a_cur = a_nxt;
+        __syncthreads();
+    }
+    if (!rv) return;
+    const float rs = rowscale ? rowscale[row] : 1.f;
+#pragma unroll
+    for (int t = 0; t < NTW; ++t) {
+        const int nn = 16 * t + 4 * kk;
+        f32x4 v = acc[t];
+        if (bias) v += *reinterpret_cast<const f32x4*>(bias + nn);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((v[q] > 0.f || !relu) ? v[q] : 0.f) * rs;
+        *reinterpret_cast<f32x4*>(C + (size_t)row * HP + nn) = v;
+    }
+}
+
 static void gemm(int n, int hp, const float* A1, const float* W1, const float* A2, const float* W2, const float* bias,
                  const float* rowscale, int relu, float* C, hipStream_t st) {
+    const unsigned grid = (unsigned)((n + 127) / 128);
+    switch (hp / 16) {
+#define HEXGNN_WIDE_GEMM(NTW_) case NTW_: wide_gemm_tiled_kernel<NTW_><<<grid, 512, 0, st>>>(n, A1, W1, A2, W2, bias, rowscale, relu, C); return;
+        HEXGNN_WIDE_GEMM(9) HEXGNN_WIDE_GEMM(10) HEXGNN_WIDE_GEMM(11) HEXGNN_WIDE_GEMM(12)
+        HEXGNN_WIDE_GEMM(13) HEXGNN_WIDE_GEMM(14) HEXGNN_WIDE_GEMM(15) HEXGNN_WIDE_GEMM(16)
+#undef HEXGNN_WIDE_GEMM
+        default: break;
+    }
     wide_gemm_kernel<<<dim3((n + 63) / 64, (hp + 63) / 64), 256, 0, st>>>(n, hp, A1, W1, A2, W2, bias, rowscale, relu, C);
 }
+
+// ---- weight gradient, LDS-tiled (round 4): part[which][s][o][i] = sum_{m in slice s} G[m][o] X_which[m][i] ---------------------
+// grid (o blocks of 128, 2 x i blocks of 128, S): blockIdx.y picks the operand (agg -> W_l partials, layer input -> W_r partials)
+// and the i block.  Block = 8 waves: wave w owns output channels o0 + 16 w .. + 15 against the block's eight i tiles.  Rows in
+// chunks of 16, both operands staged through LDS (double buffered, one barrier per chunk), ascending rows: deterministic.
+// NTI = i tiles per block (8: full 128-column blocks iblk0 .. iblk0 + nib - 1; 1..7: the partial last block, launched apart).
+template <int NTI>
+__global__ __launch_bounds__(512) void wide_dw_tiled_kernel(int n, int hp, int rows_per_slice, const float* __restrict__ G,
+                                                           const float* __restrict__ Xagg, const float* __restrict__ Xin,
+                                                           float* __restrict__ part, size_t part_stride /* floats per operand */,
+                                                           int iblk0, int nib) {
+    constexpr int TS = 128 + 16;                          // LDS row stride (floats): == 16 (mod 32)
+    __shared__ __attribute__((aligned(16))) float Gs[2][16 * TS];
+    __shared__ __attribute__((aligned(16))) float Xs[2][16 * TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m = lane & 15, kq = lane >> 4;
+    const int which = blockIdx.y / nib;
+    const int o0 = blockIdx.x * 128, i0 = (iblk0 + blockIdx.y % nib) * 128, sl = blockIdx.z;
+    const float* __restrict__ X = which == 0 ? Xagg : Xin;
+    const int m_lo = sl * rows_per_slice, m_hi = min(n, m_lo + rows_per_slice);
+    const bool wact = o0 + 16 * wave < hp;                // wave-uniform
+    f32x4 acc[NTI];
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // staging: thread (r = tid >> 5, q = tid & 31): 16 B of row r of each operand
+    const int sr = tid >> 5, sq = tid & 31;
+    const bool sgo = o0 + 4 * sq < hp, sxo = i0 + 4 * sq < hp;
+    const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 rg = z4, rx = z4;
+    auto issue = [&](int mc) {
+        const int r = mc + sr;
+        const bool ok = r < m_hi;
+        rg = (ok && sgo) ? *reinterpret_cast<const f32x4*>(G + (size_t)r * hp + o0 + 4 * sq) : z4;
+        rx = (ok && sxo) ? *reinterpret_cast<const f32x4*>(X + (size_t)r * hp + i0 + 4 * sq) : z4;
+    };
+    auto stage = [&](int buf) {
+        *reinterpret_cast<f32x4*>(&Gs[buf][sr * TS + 4 * sq]) = rg;
+        *reinterpret_cast<f32x4*>(&Xs[buf][sr * TS + 4 * sq]) = rx;
+    };
+    if (m_lo < m_hi) { issue(m_lo); stage(0); }
+    __syncthreads();
+    int buf = 0;
+    for (int mc = m_lo; mc < m_hi; mc += 16, buf ^= 1) {
+        if (mc + 16 < m_hi) issue(mc + 16);
+        if (wact) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const float a = Gs[buf][(4 * ks + kq) * TS + 16 * wave + m];
+#pragma unroll
+                for (int t = 0; t < NTI; ++t) acc[t] = mfma16x16x4(a, Xs[buf][(4 * ks + kq) * TS + 16 * t + m], acc[t]);
+            }
+        }
+        if (mc + 16 < m_hi) stage(buf ^ 1);
+        __syncthreads();
+    }
+    if (!wact) return;
+    // acc[t][r] = tile[o0 + 16 wave + 4 kq + r][i0 + 16 t + m]
+    float* base = part + (size_t)which * part_stride + ((size_t)sl * hp + o0 + 16 * wave + 4 * kq) * hp + i0 + m;
+#pragma unroll
+    for (int t = 0; t < NTI; ++t) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) base[(size_t)r * hp + 16 * t] = acc[t][r];
+    }
+}
+static void launch_wide_dw(int n, int hp, int rps, int S, const float* G, const float* Xagg, const float* Xin, float* part,
+                           size_t pstride, hipStream_t st) {
+    const int ob = (hp + 127) / 128, full = hp / 128, tail = (hp % 128) / 16;
+    if (full > 0)
+        wide_dw_tiled_kernel<8><<<dim3(ob, 2 * full, S), 512, 0, st>>>(n, hp, rps, G, Xagg, Xin, part, pstride, 0, full);
+    switch (tail) {
+#define HEXGNN_WIDE_DW(T_) case T_: wide_dw_tiled_kernel<T_><<<dim3(ob, 2, S), 512, 0, st>>>(n, hp, rps, G, Xagg, Xin, part, pstride, full, 1); break;
+        HEXGNN_WIDE_DW(1) HEXGNN_WIDE_DW(2) HEXGNN_WIDE_DW(3) HEXGNN_WIDE_DW(4) HEXGNN_WIDE_DW(5) HEXGNN_WIDE_DW(6) HEXGNN_WIDE_DW(7)
+#undef HEXGNN_WIDE_DW
+        default: break;
+    }
+}
+
 
 // ---- SAGE stack, forward ------------------------------------------------------------------------------------------------
 int wide_stack_forward(int n, int c_in, int hidden, int L, const int* rowptr, const int* col, const float* invdeg,
@@ -405,14 +570,13 @@ int wide_stack_backward(int n, int c_in, int hidden, int L, const int* rowptr_t,
     // parameter gradients: row-slice partials (one scratch region, launches are stream-ordered), added in slice order
     const int S = kWideSlices, rps = ((n + S - 1) / S + 15) / 16 * 16;
     float* part = (float*)(ws + p.part_off);
-    const dim3 tiles(hp / 16, hp / 16, S);
     const unsigned rg = (unsigned)((hidden * hidden + 255) / 256);
+    const size_t pstride = align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256) / sizeof(float);
     for (int l = first_hidden; l < L; ++l) {
         const float* xin = l == 0 ? x : acts + slab * (l - 1);
-        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hp, rps, Gl(l), (const float*)(sv + p.agg_off[l]), part);
+        launch_wide_dw(n, hp, rps, S, Gl(l), (const float*)(sv + p.agg_off[l]), xin, part, pstride, st);
         wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part, d_wl[l]);
-        wide_dw_kernel<<<tiles, 64, 0, st>>>(n, hp, rps, Gl(l), xin, part);
-        wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part, d_wr[l]);
+        wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part + pstride, d_wr[l]);
         wide_colsum_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, hp, rps, Gl(l), part);
         wide_colsum_reduce_kernel<<<(hidden + 255) / 256, 256, 0, st>>>(S, hidden, hp, part, d_bl[l]);
     }
