@@ -54,7 +54,7 @@ int launch_weight_grads(int n, int c_in, int hidden, const StackPlan& p, const B
 
 // ---- hidden 129..256 (wide.hip): plain kernels behind the same entry points ------------------------------------------------
 constexpr int kWideMaxHidden = 256;
-constexpr int kWideSlicesMax = 32;           // row slices of a wide weight-gradient launch (workspace sized for this many)
+constexpr int kWideSlicesMax = 64;           // row slices of a wide weight-gradient launch (workspace sized for this many)
 int padded_width_wide(int hidden);           // 16-multiple up to 256, -1 beyond
 struct WidePlan {
     int hp, L;

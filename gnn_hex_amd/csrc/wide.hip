@@ -46,7 +46,8 @@ int wide_make_plan(int n, int c_in, int hidden, int L, WidePlan* p) {
     p->g_off = 0;
     p->tmp_off = slab * L;
     p->part_off = slab * (L + 2);               // row-slice partials of ONE weight-gradient launch (reused launch after launch)
-    p->bwd_bytes = p->part_off + 2 * align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256);      // (W_l | W_r partials)
+    p->bwd_bytes = p->part_off + 2 * align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256)       // (W_l | W_r partials
+                   + align_up(sizeof(float) * (size_t)kWideSlicesMax * hp, 256);                            //  | bias partials)
     return HEXGNN_OK;
 }
 
@@ -212,40 +213,34 @@ __global__ __launch_bounds__(256) void wide_gemm_kernel(int M, int hp, const flo
     }
 }
 
-// ---- weight gradient: one wave per (16 x 16 tile of dW, row slice): part[s][o][i] = sum_{m in slice s} G[m][o] X[m][i] -------
-// lane (i, kk): a = G[m + 4 kk + j][o0 + i], b = X[m + 4 kk + j][i0 + i]; acc[r] = tile[4 kk + r][i].  The slices are added in
-// slice order by wide_slices_reduce_kernel: deterministic.  (The first version walked all rows in ONE wave per tile: 65 ms per
-// GNN-L step at hidden 160.)
-constexpr int kWideSlices = 32;
-__global__ __launch_bounds__(64) void wide_dw_kernel(int n, int hp, int rows_per_slice, const float* __restrict__ G,
-                                                    const float* __restrict__ X, float* __restrict__ part /*[S][HP][HP]*/) {
-    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int o0 = blockIdx.x * 16, i0 = blockIdx.y * 16, sl = blockIdx.z;
-    const int m_lo = sl * rows_per_slice, m_hi = min(n, m_lo + rows_per_slice);
-    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    for (int m = m_lo; m < m_hi; m += 16) {
-        float a[4], b[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = m + 4 * kk + j;
-            a[j] = r < m_hi ? G[(size_t)r * hp + o0 + i] : 0.f;
-            b[j] = r < m_hi ? X[(size_t)r * hp + i0 + i] : 0.f;
-        }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc = mfma16x16x4(a[j], b[j], acc);
-    }
-    float* t = part + ((size_t)sl * hp + o0 + 4 * kk) * hp + i0 + i;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) t[(size_t)r * hp] = acc[r];
-}
-__global__ void wide_slices_reduce_kernel(int S, int H, int hp, const float* __restrict__ part, float* __restrict__ dW /*[H][H]*/) {
+// ---- weight gradient: row-slice partials part[s][o][i] (wide_dw_tiled_kernel below), added in slice order by
+// wide_slices_reduce_kernel: deterministic.
+constexpr int kWideSlices = 64;
+// roles (blockIdx.y): 0 = W_l partials, 1 = W_r partials (part + part_stride), 2 = bias partials [S][HP] (part + 2 part_stride).
+// Eight independent loads per step of the slice loop (the one-load-per-iteration form took 16 us for 64 slices: a latency chain).
+__global__ void wide_slices_reduce_kernel(int S, int H, int hp, const float* __restrict__ part, size_t part_stride,
+                                          float* __restrict__ dWl, float* __restrict__ dWr, float* __restrict__ db) {
+    const int role = blockIdx.y;
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= H * H) return;
-    const int o = idx / H, c = idx % H;
+    const float* base;
+    size_t stride;
+    float* out;
+    if (role == 2) {
+        if (idx >= H || !db) return;
+        base = part + 2 * part_stride + idx; stride = (size_t)hp; out = db + idx;
+    } else {
+        if (idx >= H * H) return;
+        const int o = idx / H, c = idx % H;
+        base = part + (size_t)role * part_stride + (size_t)o * hp + c; stride = (size_t)hp * hp; out = (role ? dWr : dWl) + idx;
+    }
     float s = 0.f;
-    for (int k = 0; k < S; ++k) s += part[((size_t)k * hp + o) * hp + c];
-    dW[idx] = s;
+    for (int k = 0; k < S; k += 8) {
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = k + j < S ? base[(size_t)(k + j) * stride] : 0.f;
+        s += ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+    }
+    *out = s;
 }
 
 // column sums of G (the bias gradient): block = 16 columns x 16 row phases over one row slice, fixed-order combine
@@ -400,78 +395,87 @@ static void gemm(int n, int hp, const float* A1, const float* W1, const float* A
 }
 
 // ---- weight gradient, LDS-tiled (round 4): part[which][s][o][i] = sum_{m in slice s} G[m][o] X_which[m][i] ---------------------
-// grid (o blocks of 128, 2 x i blocks of 128, S): blockIdx.y picks the operand (agg -> W_l partials, layer input -> W_r partials)
-// and the i block.  Block = 8 waves: wave w owns output channels o0 + 16 w .. + 15 against the block's eight i tiles.  Rows in
-// chunks of 16, both operands staged through LDS (double buffered, one barrier per chunk), ascending rows: deterministic.
-// NTI = i tiles per block (8: full 128-column blocks iblk0 .. iblk0 + nib - 1; 1..7: the partial last block, launched apart).
-template <int NTI>
-__global__ __launch_bounds__(512) void wide_dw_tiled_kernel(int n, int hp, int rows_per_slice, const float* __restrict__ G,
-                                                           const float* __restrict__ Xagg, const float* __restrict__ Xin,
-                                                           float* __restrict__ part, size_t part_stride /* floats per operand */,
-                                                           int iblk0, int nib) {
-    constexpr int TS = 128 + 16;                          // LDS row stride (floats): == 16 (mod 32)
-    __shared__ __attribute__((aligned(16))) float Gs[2][16 * TS];
-    __shared__ __attribute__((aligned(16))) float Xs[2][16 * TS];
+// grid (2 operands x 2 halves of the i tiles, S row slices): blockIdx.x picks the operand (agg -> W_l partials, layer input ->
+// W_r partials) and the half.  Block = NT = HP / 16 waves: wave w owns output channels 16 w .. 16 w + 15 (ALL of them: G is staged
+// once per block) against the half's NTI = ceil(NT / 2) i tiles.  Rows in chunks of 16, both operands through LDS (double
+// buffered, one barrier per chunk), ascending rows: deterministic.  (First tiled version, 128 x 128 output blocks: 85 + 48 us per
+// layer at hidden 160 -- the partial blocks idled six of eight waves; one wave per 16 x 16 tile before that.)
+template <int NT>
+__global__ __launch_bounds__((64 * NT)) void wide_dw_tiled_kernel(int n, int rows_per_slice, const float* __restrict__ G,
+                                                                 const float* __restrict__ Xagg, const float* __restrict__ Xin,
+                                                                 float* __restrict__ part, size_t part_stride /* floats per operand */) {
+    // (+ the bias gradient's partials, the column sums of G over the slice, by the blocks of operand 0 / half 0: [S][HP] behind the
+    // two operands' regions)
+    constexpr int HP = 16 * NT, NTI = (NT + 1) / 2;
+    constexpr int GSW = HP % 32 == 0 ? HP + 16 : HP + 32;               // LDS row strides (floats): == 16 (mod 32)
+    constexpr int XW = 16 * NTI, XSW = XW % 32 == 0 ? XW + 16 : XW + 32;
+    __shared__ __attribute__((aligned(16))) float Gs[2][16 * GSW];
+    __shared__ __attribute__((aligned(16))) float Xs[2][16 * XSW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m = lane & 15, kq = lane >> 4;
-    const int which = blockIdx.y / nib;
-    const int o0 = blockIdx.x * 128, i0 = (iblk0 + blockIdx.y % nib) * 128, sl = blockIdx.z;
+    const int which = blockIdx.x >> 1, half = blockIdx.x & 1, sl = blockIdx.y;
+    const int i0 = half * XW;
     const float* __restrict__ X = which == 0 ? Xagg : Xin;
     const int m_lo = sl * rows_per_slice, m_hi = min(n, m_lo + rows_per_slice);
-    const bool wact = o0 + 16 * wave < hp;                // wave-uniform
     f32x4 acc[NTI];
 #pragma unroll
     for (int t = 0; t < NTI; ++t) acc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    // staging: thread (r = tid >> 5, q = tid & 31): 16 B of row r of each operand
-    const int sr = tid >> 5, sq = tid & 31;
-    const bool sgo = o0 + 4 * sq < hp, sxo = i0 + 4 * sq < hp;
+    const bool do_b = blockIdx.x == 0;
+    float bsum = 0.f;
+    // staging: G -- every thread 16 B (16 rows x HP / 4 pieces = 64 NT); X -- the first 64 NTI threads
+    constexpr int GQ = HP / 4, XQ = XW / 4;
+    const int gr = tid / GQ, gq = tid % GQ;
+    const bool xth = tid < 16 * XQ;
+    const int xr = tid / XQ, xq = tid % XQ;
+    const bool xin_range = xth && i0 + 4 * xq < HP;
     const f32x4 z4 = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 rg = z4, rx = z4;
     auto issue = [&](int mc) {
-        const int r = mc + sr;
-        const bool ok = r < m_hi;
-        rg = (ok && sgo) ? *reinterpret_cast<const f32x4*>(G + (size_t)r * hp + o0 + 4 * sq) : z4;
-        rx = (ok && sxo) ? *reinterpret_cast<const f32x4*>(X + (size_t)r * hp + i0 + 4 * sq) : z4;
+        rg = mc + gr < m_hi ? *reinterpret_cast<const f32x4*>(G + (size_t)(mc + gr) * HP + 4 * gq) : z4;
+        rx = (xin_range && mc + xr < m_hi) ? *reinterpret_cast<const f32x4*>(X + (size_t)(mc + xr) * HP + i0 + 4 * xq) : z4;
     };
     auto stage = [&](int buf) {
-        *reinterpret_cast<f32x4*>(&Gs[buf][sr * TS + 4 * sq]) = rg;
-        *reinterpret_cast<f32x4*>(&Xs[buf][sr * TS + 4 * sq]) = rx;
+        *reinterpret_cast<f32x4*>(&Gs[buf][gr * GSW + 4 * gq]) = rg;
+        if (xth) *reinterpret_cast<f32x4*>(&Xs[buf][xr * XSW + 4 * xq]) = rx;
     };
     if (m_lo < m_hi) { issue(m_lo); stage(0); }
     __syncthreads();
     int buf = 0;
     for (int mc = m_lo; mc < m_hi; mc += 16, buf ^= 1) {
         if (mc + 16 < m_hi) issue(mc + 16);
-        if (wact) {
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                const float a = Gs[buf][(4 * ks + kq) * TS + 16 * wave + m];
+        for (int ks = 0; ks < 4; ++ks) {
+            const float a = Gs[buf][(4 * ks + kq) * GSW + 16 * wave + m];
+            if (do_b) bsum += a;
 #pragma unroll
-                for (int t = 0; t < NTI; ++t) acc[t] = mfma16x16x4(a, Xs[buf][(4 * ks + kq) * TS + 16 * t + m], acc[t]);
-            }
+            for (int t = 0; t < NTI; ++t) acc[t] = mfma16x16x4(a, Xs[buf][(4 * ks + kq) * XSW + 16 * t + m], acc[t]);
         }
         if (mc + 16 < m_hi) stage(buf ^ 1);
         __syncthreads();
     }
-    if (!wact) return;
-    // acc[t][r] = tile[o0 + 16 wave + 4 kq + r][i0 + 16 t + m]
-    float* base = part + (size_t)which * part_stride + ((size_t)sl * hp + o0 + 16 * wave + 4 * kq) * hp + i0 + m;
+    if (do_b) {
+        bsum += __shfl_xor(bsum, 16);
+        bsum += __shfl_xor(bsum, 32);
+        if (kq == 0) part[2 * part_stride + (size_t)sl * HP + 16 * wave + m] = bsum;
+    }
+    // acc[t][r] = tile[16 wave + 4 kq + r][i0 + 16 t + m]
+    float* base = part + (size_t)which * part_stride + ((size_t)sl * HP + 16 * wave + 4 * kq) * HP + i0 + m;
 #pragma unroll
     for (int t = 0; t < NTI; ++t) {
+        if (i0 + 16 * t < HP) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) base[(size_t)r * hp + 16 * t] = acc[t][r];
+            for (int r = 0; r < 4; ++r) base[(size_t)r * HP + 16 * t] = acc[t][r];
+        }
     }
 }
-static void launch_wide_dw(int n, int hp, int rps, int S, const float* G, const float* Xagg, const float* Xin, float* part,
+static bool launch_wide_dw(int n, int hp, int rps, int S, const float* G, const float* Xagg, const float* Xin, float* part,
                            size_t pstride, hipStream_t st) {
-    const int ob = (hp + 127) / 128, full = hp / 128, tail = (hp % 128) / 16;
-    if (full > 0)
-        wide_dw_tiled_kernel<8><<<dim3(ob, 2 * full, S), 512, 0, st>>>(n, hp, rps, G, Xagg, Xin, part, pstride, 0, full);
-    switch (tail) {
-#define HEXGNN_WIDE_DW(T_) case T_: wide_dw_tiled_kernel<T_><<<dim3(ob, 2, S), 512, 0, st>>>(n, hp, rps, G, Xagg, Xin, part, pstride, full, 1); break;
-        HEXGNN_WIDE_DW(1) HEXGNN_WIDE_DW(2) HEXGNN_WIDE_DW(3) HEXGNN_WIDE_DW(4) HEXGNN_WIDE_DW(5) HEXGNN_WIDE_DW(6) HEXGNN_WIDE_DW(7)
+    switch (hp / 16) {
+#define HEXGNN_WIDE_DW(NT_) case NT_: wide_dw_tiled_kernel<NT_><<<dim3(4, S), 64 * NT_, 0, st>>>(n, rps, G, Xagg, Xin, part, pstride); return true;
+        HEXGNN_WIDE_DW(9) HEXGNN_WIDE_DW(10) HEXGNN_WIDE_DW(11) HEXGNN_WIDE_DW(12)
+        HEXGNN_WIDE_DW(13) HEXGNN_WIDE_DW(14) HEXGNN_WIDE_DW(15) HEXGNN_WIDE_DW(16)
 #undef HEXGNN_WIDE_DW
-        default: break;
+        default: return false;
     }
 }
 
@@ -574,16 +578,15 @@ int wide_stack_backward(int n, int c_in, int hidden, int L, const int* rowptr_t,
     const size_t pstride = align_up(sizeof(float) * (size_t)kWideSlicesMax * hp * hp, 256) / sizeof(float);
     for (int l = first_hidden; l < L; ++l) {
         const float* xin = l == 0 ? x : acts + slab * (l - 1);
-        launch_wide_dw(n, hp, rps, S, Gl(l), (const float*)(sv + p.agg_off[l]), xin, part, pstride, st);
-        wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part, d_wl[l]);
-        wide_slices_reduce_kernel<<<rg, 256, 0, st>>>(S, hidden, hp, part + pstride, d_wr[l]);
-        wide_colsum_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, hp, rps, Gl(l), part);
-        wide_colsum_reduce_kernel<<<(hidden + 255) / 256, 256, 0, st>>>(S, hidden, hp, part, d_bl[l]);
+        if (!launch_wide_dw(n, hp, rps, S, Gl(l), (const float*)(sv + p.agg_off[l]), xin, part, pstride, st)) return HEXGNN_EUNSUPPORTED;
+        wide_slices_reduce_kernel<<<dim3(rg, 3), 256, 0, st>>>(S, hidden, hp, part, pstride, d_wl[l], d_wr[l], d_bl[l]);
     }
     if (p.small_first) {
-        wide_first_dw_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, c_in, hidden, hp, rps, Gl(0),
-                                                                     (const float*)(sv + p.agg_off[0]), x, x_stride, part);
-        wide_first_dw_reduce_kernel<<<(hidden * 16 + 255) / 256, 256, 0, st>>>(S, c_in, hidden, hp, part, d_wl[0], d_wr[0]);
+        // (its threads walk a slice's rows one by one: many short slices -- 400 us with 32 slices of 984 rows)
+        const int S1 = 256, rps1 = (n + S1 - 1) / S1;
+        wide_first_dw_kernel<<<dim3((hp + 15) / 16, S1), 256, 0, st>>>(n, c_in, hidden, hp, rps1, Gl(0),
+                                                                      (const float*)(sv + p.agg_off[0]), x, x_stride, part);
+        wide_first_dw_reduce_kernel<<<(hidden * 16 + 255) / 256, 256, 0, st>>>(S1, c_in, hidden, hp, part, d_wl[0], d_wr[0]);
         wide_colsum_kernel<<<dim3((hp + 15) / 16, S), 256, 0, st>>>(n, hp, rps, Gl(0), part);
         wide_colsum_reduce_kernel<<<(hidden + 255) / 256, 256, 0, st>>>(S, hidden, hp, part, d_bl[0]);
     }
