@@ -113,9 +113,10 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
     return batches
 
 
-def secondary_config(config, data, B, dev, steps, warmup, preheat_ms):
+def secondary_config(config, data, B, dev, steps, warmup, preheat_ms, _order_too=True):
     """One more BASELINE configuration measured the same way as the headline (HIP-graph replay, preheat, W warm-up steps,
-    K timed steps), so that the driver's record carries it too.  Returns a small dict; never raises."""
+    K timed steps), so that the driver's record carries it too.  Returns a small dict; never raises.  A configuration whose
+    batch is collated packed (MIX) is measured in the caller's round-robin order as well (`callers_order`)."""
     try:
         from helpers import make_pair
         from gnn_hex_amd import ops as hexops
@@ -157,13 +158,23 @@ def secondary_config(config, data, B, dev, steps, warmup, preheat_ms):
         n = (batches[0]["n"] + batches[1]["n"]) / 2.0
         e = (batches[0]["e"] + batches[1]["e"]) / 2.0
         step_bytes = 2 * (bytes_fwd(n, e, 2) + (num_layers + 1) * bytes_fwd(n, e, hidden))
-        return {"workload": "%s, %s board graphs (N=%d, E=%d)%s" % (
-                    label, "start-position" if data == "D0" else "random-playout", batches[0]["n"], batches[0]["e"],
-                    "" if batches[0]["blocks"] is None else
-                    ", graphs collated in data.pack_order order (%d graph-aligned row blocks)" % batches[0]["blocks"]),
-                "value": B * steps / dt, "unit": "graphs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
-                "warmup": warmup, "preheat_steps": k,
-                "step_hbm_roofline_frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+        out = {"workload": "%s, %s board graphs (N=%d, E=%d)%s" % (
+                   label, "start-position" if data == "D0" else "random-playout", batches[0]["n"], batches[0]["e"],
+                   "" if batches[0]["blocks"] is None else
+                   ", graphs collated in data.pack_order order (%d graph-aligned row blocks)" % batches[0]["blocks"]),
+               "value": B * steps / dt, "unit": "graphs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+               "warmup": warmup, "preheat_steps": k,
+               "step_hbm_roofline_frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS}
+        if batches[0]["blocks"] is not None and _order_too:
+            global PACK_BATCHES
+            del graphs, g0, g1, batches
+            keep, PACK_BATCHES = PACK_BATCHES, False
+            try:
+                alt = secondary_config(config, data, B, dev, steps, warmup, min(preheat_ms, 300.0), _order_too=False)
+            finally:
+                PACK_BATCHES = keep
+            out["callers_order"] = {k2: alt[k2] for k2 in ("value", "ms_per_step", "error") if k2 in alt}
+        return out
     except Exception as exc:  # noqa: BLE001  (a secondary line must never take the headline down)
         return {"workload": "%s %s" % (config, data), "error": "%s: %s" % (type(exc).__name__, exc)}
 
