@@ -258,6 +258,58 @@ __device__ int g_stamp_block = -1;                      // the one chosen with h
 #define PSTAMP(k, p) do {} while (0)
 #endif
 
+// The rest of a row with more than kEll neighbours (the terminals of a board; after dead / captured removal late in a game many
+// rows), summed from global memory in CSR order.  Four neighbour ids (and, backward, their 1 / deg) are requested at once and
+// DEPTH neighbour rows are in flight (the one-launch kernels sit at the register ceiling: one): per four neighbours 1 + 4 / DEPTH
+// round trips instead of eight (the one-at-a-time loop made random-playout MIX batches 60 % slower than start positions: 413
+// against 255 us per launch).  Same order of additions
+// as the plain loop: bit-identical sums.  COH: agent-scope (sc1) row loads -- rows written by other workgroups of this launch.
+#ifndef HEXGNN_LR_IDS
+#define HEXGNN_LR_IDS 2
+#endif
+template <int NT, bool BWD, bool COH, int DEPTH, int IDS>
+__device__ __forceinline__ void long_row_tail(const int* __restrict__ col, __amdgpu_buffer_rsrc_t ir /* 1 / deg (backward) */,
+                                              __amdgpu_buffer_rsrc_t xr, int e_lo, int e_hi, int g, f32x4 (&ag)[NT]) {
+    constexpr unsigned kRowB = 16u * NT * 4u;
+    constexpr int kAux = COH ? 16 : 0;
+    const __amdgpu_buffer_rsrc_t cr = slab_rsrc(col);
+    for (int e = e_lo; e < e_hi; e += IDS) {
+        int j[IDS];
+        float sj[IDS];
+#pragma unroll
+        for (int q = 0; q < IDS; ++q)
+            j[q] = __builtin_amdgcn_raw_buffer_load_b32(cr, e + q < e_hi ? (unsigned)(e + q) * 4u : kOob, 0, 0);
+#pragma unroll
+        for (int q = 0; q < IDS; ++q) {
+            sj[q] = 1.f;
+            if constexpr (BWD)
+                sj[q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ir, e + q < e_hi ? (unsigned)j[q] * 4u : kOob, 0, 0));
+        }
+#pragma unroll
+        for (int h = 0; h < IDS; h += DEPTH) {
+            if (e + h >= e_hi) break;             // (no lane of the wave left with a neighbour in this group: nothing is issued)
+            f32x4 rr[DEPTH][NT];
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                const unsigned o = e + h + d < e_hi ? (unsigned)j[h + d] * kRowB + 16u * g : kOob;
+#pragma unroll
+                for (int c = 0; c < NT; ++c)
+                    rr[d][c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xr, o + 64 * c, 0, kAux));
+            }
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (e + h + d < e_hi) {
+#pragma unroll
+                    for (int c = 0; c < NT; ++c) {
+                        if constexpr (BWD) ag[c] += rr[d][c] * sj[h + d];
+                        else ag[c] += rr[d][c];
+                    }
+                }
+            }
+        }
+    }
+}
+
 // ---- hidden layer, forward and backward (data) -------------------------------------------------------------------
 //   forward :  y_i   = act( mean_{j in N(i)} x_j W_l^T + x_i W_r^T + b )                       (GN0/torch_script_models.py:52-73)
 //   backward:  dY_i  = ( sum_{j in T(i)} G_j / deg_j ) W_l + G_i W_r,   G' = dY * [y' > 0]       (its autograd transpose, with
@@ -564,19 +616,8 @@ __device__ __forceinline__ void sage_layer_body(
         for (int c = 0; c < NT; ++c) ym[c] = buf_load(yr_, off + 64 * c);
     }
     if (valid) {
-        if (deg > kEll) {              // the rest of a long row (the two terminals of a board late in a game), from the CSR
-            for (int e = e0 + kEll; e < e1; ++e) {
-                const int j = col[e];
-                const f32x4* xj = reinterpret_cast<const f32x4*>(x + (size_t)j * HP) + g;
-                float sj = 1.f;
-                if constexpr (BWD) sj = invdeg[j];
-#pragma unroll
-                for (int c = 0; c < NT; ++c) {
-                    if constexpr (BWD) ag[c] += xj[4 * c] * sj;
-                    else ag[c] += xj[4 * c];
-                }
-            }
-        }
+        if (deg > kEll)                // the rest of a long row (the two terminals of a board; late in a game many rows), from the CSR
+            long_row_tail<NT, BWD, false, 2, 4>(col, slab_rsrc(invdeg), slab_rsrc(x), e0 + kEll, e1, g, ag);
         if constexpr (!BWD) {
 #pragma unroll
             for (int c = 0; c < NT; ++c) ag[c] *= sc;
@@ -1156,19 +1197,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
             for (int c = 0; c < NT; ++c) ym[c] = buf_load(yr_, off + 64 * c);
         }
         if (valid) {
-            if (deg > kEll) {
-                for (int e = e0 + kEll; e < e1; ++e) {
-                    const int j = a.col[e];
-                    const unsigned oj = (unsigned)j * (unsigned)(HP * 4) + 16u * g;
-                    float sj = 1.f;
-                    if constexpr (BWD) sj = a.invdeg[j];
-#pragma unroll
-                    for (int c = 0; c < NT; ++c) {
-                        if constexpr (BWD) ag[c] += buf_load_coh(xr_, oj + 64 * c) * sj;
-                        else ag[c] += buf_load_coh(xr_, oj + 64 * c);
-                    }
-                }
-            }
+            if (deg > kEll) long_row_tail<NT, BWD, true, 1, HEXGNN_LR_IDS>(a.col, ir_, xr_, e0 + kEll, e1, g, ag);
             if constexpr (!BWD) {
 #pragma unroll
                 for (int c = 0; c < NT; ++c) ag[c] *= sc;
