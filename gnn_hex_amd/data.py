@@ -81,6 +81,8 @@ def pack_order(sizes: List[int], block: int = BLOCK_ROWS, max_blocks: Optional[i
     if n_graphs == 0:
         return [], None
     sizes = [int(v) for v in sizes]
+    if max_blocks is not None and -(-sum(sizes) // block) > max_blocks:
+        return list(range(n_graphs)), None           # (not even full blocks fit the budget: nothing to pack for)
     big = sorted((g for g in range(n_graphs) if sizes[g] > block), key=lambda g: (-sizes[g], g))
     small = sorted((g for g in range(n_graphs) if sizes[g] <= block), key=lambda g: (-sizes[g], g))
 
