@@ -53,7 +53,7 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
     B graphs (D1 graphs differ per rank).  Strong scaling (`subset` = this rank's graph indices of ONE global B-graph batch,
     gnn_hex_amd.dist.balance_by_edges): the rank holds only those graphs; D1 seeds are the global graph indices."""
     from helpers import batch_tensors, sel_and_targets
-    from gnn_hex_amd.data import attach_blocks, pack_order
+    from gnn_hex_amd.data import attach_blocks, blocks_for_order, pack_order
     sizes_fn = CONFIGS[config][2]
     all_sizes = sizes_fn(B)
     graphs = list(range(B)) if subset is None else list(subset)
@@ -73,6 +73,10 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
                 sizes_m = [sizes[k] for k in order]
             else:
                 sizes_m = sizes
+                if max(sizes) ** 2 + 2 > 128 and cus:
+                    # the caller's order: blocks along ITS graph boundaries when they fit (Batch.from_data_list does the same)
+                    st2 = blocks_for_order([s_ * s_ + 2 for s_ in sizes])
+                    starts = st2 if len(st2) - 1 <= cus else None
             x, ei, bv, ptr = batch_tensors("D0", sizes_m, maker=maker)
         else:
             from oracle import env_ref          # input generation only (before any timed region)
@@ -85,6 +89,9 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
             if want_pack:
                 order, starts = pack_order([it[0].shape[0] for it in items], max_blocks=cus)
                 items = [items[k] for k in order]
+            elif max(it[0].shape[0] for it in items) > 128 and cus:
+                st2 = blocks_for_order([it[0].shape[0] for it in items])
+                starts = st2 if len(st2) - 1 <= cus else None
             xs, eis, bvs, ptrs, off = [], [], [], [0], 0
             for gx, gei in items:
                 bvs.append(np.full(gx.shape[0], len(xs), dtype=np.int64)); xs.append(gx); eis.append(gei + off)
@@ -108,7 +115,7 @@ def make_batches(config, data, B, dev, rank=0, subset=None, world=1):
             attach_blocks(eid, starts)
         batches.append(dict(x=xd, ei=eid, bv=bv.to(dev), ptr=ptr.to(dev), sel=sel.to(dev), tgt=tgt.to(dev),
                             w=None if wts is None else wts.to(dev), graphs=len(graphs),
-                            blocks=None if starts is None else len(starts) - 1,
+                            blocks=None if starts is None else len(starts) - 1, packed=bool(want_pack and starts is not None),
                             cpu=(x, ei, bv, ptr, sel, tgt), n=int(x.shape[0]), e=int(ei.shape[1])))
     return batches
 
@@ -161,11 +168,12 @@ def secondary_config(config, data, B, dev, steps, warmup, preheat_ms, _order_too
         out = {"workload": "%s, %s board graphs (N=%d, E=%d)%s" % (
                    label, "start-position" if data == "D0" else "random-playout", batches[0]["n"], batches[0]["e"],
                    "" if batches[0]["blocks"] is None else
-                   ", graphs collated in data.pack_order order (%d graph-aligned row blocks)" % batches[0]["blocks"]),
+                   ", %s (%d graph-aligned row blocks)" % ("graphs collated in data.pack_order order" if batches[0]["packed"]
+                                                           else "caller's graph order", batches[0]["blocks"])),
                "value": B * steps / dt, "unit": "graphs/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
                "warmup": warmup, "preheat_steps": k,
                "step_hbm_roofline_frac": step_bytes / (dt / steps) / 1e9 / HBM_PEAK_GBS}
-        if batches[0]["blocks"] is not None and _order_too:
+        if batches[0]["packed"] and _order_too:
             global PACK_BATCHES
             del graphs, g0, g1, batches
             keep, PACK_BATCHES = PACK_BATCHES, False
@@ -608,7 +616,8 @@ def main():
                        "parallelism": "dp%d" % world, "hip_graph": bool(args.graph), "global_batch": B * gfactor,
                        "graphs_per_gpu": batches[0]["graphs"],
                        "collation": "caller's order" if batches[0]["blocks"] is None else
-                                    "gnn_hex_amd.data.pack_order (%d graph-aligned row blocks)" % batches[0]["blocks"],
+                                    "%s (%d graph-aligned row blocks)" % ("gnn_hex_amd.data.pack_order" if batches[0]["packed"] else
+                                                                          "caller's order, data.blocks_for_order", batches[0]["blocks"]),
                        "step_issue": "model(...), F.mse_loss(q[sel], target), loss.backward()" if args.plain_autograd else
                                      "ops.td_step (model forward, TD loss in its tail, backward)" if td_fused else
                                      "model(...), ops.td_loss, ops.backward"},

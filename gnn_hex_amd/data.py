@@ -179,21 +179,33 @@ class Batch(Data):
         """``pack=True`` (graphs above 128 nodes in the batch -- Hex-12 and larger, mixed sizes): the graphs are collated in
         ``pack_order`` order with its row-block table attached, and ``batch.order`` (LongTensor [num_graphs]) says which entry
         of ``data_list`` sits at each position -- per-graph quantities of the caller (actions, targets, weights) go through
-        ``t[batch.order]``.  ``max_blocks``: see ``pack_order`` (default: ``ops.stack_block_budget``, the CUs the one-launch kernels may fill)."""
+        ``t[batch.order]``.  Without ``pack`` the order is the caller's and the table follows its graph boundaries when that fits
+        (``blocks_for_order``).  ``max_blocks``: see ``pack_order`` (default: ``ops.stack_block_budget``, the CUs the one-launch
+        kernels may fill)."""
         if hasattr(data_list, "to_batch"):      # an Env_manager observation is already batched on the device
             return data_list.to_batch()
         out = cls()
         if len(data_list) == 0:
             raise ValueError("empty data_list")
         starts = None
-        if pack:
-            dev0 = data_list[0].x.device
-            if max_blocks is None and dev0.type == "cuda":
+        dev0 = data_list[0].x.device
+        sizes = [int(d.x.shape[0]) for d in data_list]
+        if dev0.type == "cuda" and max(sizes) > BLOCK_ROWS:
+            if max_blocks is None:
                 from . import ops
                 max_blocks = ops.stack_block_budget(dev0)
-            order, starts = pack_order([int(d.x.shape[0]) for d in data_list], BLOCK_ROWS, max_blocks)
-            data_list = [data_list[g] for g in order]
-            out.order = torch.tensor(order, dtype=torch.long)
+            if pack:
+                order, starts = pack_order(sizes, BLOCK_ROWS, max_blocks)
+                data_list = [data_list[g] for g in order]
+                out.order = torch.tensor(order, dtype=torch.long)
+            elif -(-sum(sizes) // BLOCK_ROWS) <= max_blocks:
+                # the caller's order is kept; blocks follow the graph boundaries of THAT order where the budget allows (more,
+                # shorter blocks than a packing needs: the Hex-5..13 round robin takes 254 of 256)
+                starts = blocks_for_order(sizes)
+                if len(starts) - 1 > max_blocks:
+                    starts = None
+        elif pack:
+            out.order = torch.arange(len(sizes))
         sizes = [int(d.x.shape[0]) for d in data_list]
         device = data_list[0].x.device
         ptr = torch.zeros(len(sizes) + 1, dtype=torch.long)

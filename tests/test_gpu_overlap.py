@@ -212,4 +212,6 @@ def test_rccl_call_sequence_on_a_one_rank_group():
                 assert torch.equal(p.grad, g_n[k]), k
     finally:
         ops.set_grad_stage_hook(None)
+        from gnn_hex_amd import _lib as _hl
+        _hl.lib().hexgnn_stack_reserve_cus(0)            # (enable_overlap reserved CUs for the RCCL channels)
         dist.destroy_process_group()

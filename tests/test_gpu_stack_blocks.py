@@ -58,6 +58,12 @@ def test_packed_batch_equals_default_blocks_and_caller_order():
     sel_p = (packed.ptr.cpu()[:-1] + local[order]).cuda()
     tgt_p = tgt[order].cuda()
     q0, g0 = _step(hip, plain, sel0.cuda(), tgt.cuda())
+    # (the caller's order gets a table too -- blocks along ITS graph boundaries, no reordering; same results as without it)
+    tbl0 = plain.edge_index._hex_blocks
+    assert tbl0[1] > nb and not hasattr(plain, "order")
+    del plain.edge_index._hex_blocks
+    q0b, g0b = _step(hip, plain, sel0.cuda(), tgt.cuda())
+    assert _close(q0, q0b) and all(_close(a, b, 1e-4) for a, b in zip(g0, g0b))
     q1, g1 = _step(hip, packed, sel_p, tgt_p)
     # graph by graph: position k of the packed batch is graph order[k] of the caller's list
     pp, p0 = packed.ptr.tolist(), plain.ptr.tolist()
@@ -187,6 +193,7 @@ def test_table_over_the_block_budget_falls_back_to_default_blocks():
     dflt = (int(bt.x.shape[0]) + 127) // 128
     assert nb > dflt + 2
     L = _lib.lib()
+    prev = L.hexgnn_stack_reserve_cus(0)          # (an earlier test may have left CUs reserved: start from none, restore below)
     budget0 = ops.stack_block_budget(bt.x.device)
     assert budget0 >= nb
     with torch.no_grad():
@@ -201,6 +208,6 @@ def test_table_over_the_block_budget_falls_back_to_default_blocks():
         blk = getattr(again.edge_index, "_hex_blocks", None)
         assert blk is None or blk[1] <= dflt + 1
     finally:
-        L.hexgnn_stack_reserve_cus(0)
+        L.hexgnn_stack_reserve_cus(prev)
     torch.cuda.synchronize()
     assert _close(q1, q0) and L.hexgnn_stack_status(1) == 0
