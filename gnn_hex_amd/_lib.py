@@ -31,6 +31,8 @@ _SIGS = {
     "hexgnn_csr_build_grouped": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "hexgnn_csr_build_grouped_pack": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]),
     "hexgnn_csr_build_grouped_pack_e": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, vp]),
+    "hexgnn_csr_build_grouped_pack_b": (ci, [ci, ci, ci, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, vp,
+                                             vp, ci, vp]),
     "hexgnn_graph_ptr": (ci, [ci, ci, vp, vp, vp]),
     "hexgnn_sage_stack_pack_bytes": (sz, [ci, ci, ci]),
     "hexgnn_sage_stack_saved_bytes": (sz, [ci, ci, ci, ci]),

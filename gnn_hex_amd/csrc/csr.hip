@@ -183,12 +183,12 @@ __device__ __forceinline__ void csr_grouped_body(int n, int e, int b, const int6
                                                  int* __restrict__ rowptr, int* __restrict__ col,
                                                  int* __restrict__ rowptr_t, int* __restrict__ col_t,
                                                  float* __restrict__ invdeg, int* __restrict__ status,
-                                                 const int64_t* __restrict__ eptr64 = nullptr) {
+                                                 const int64_t* __restrict__ eptr64 = nullptr, int g_first = 0) {
     __shared__ int s_start[2][kCsrMaxGraph + 1];   // row starts (local, exclusive prefix), CSR and transpose
     __shared__ int s_cnt[2][kCsrMaxGraph];         // degree histogram, then fill cursors
     __shared__ int s_part[2][256];
     __shared__ int s_col[2][kCsrLdsEdges];         // this graph's col / col_t while they are filled and sorted
-    const int g = blockIdx.x, tid = threadIdx.x;
+    const int g = (int)blockIdx.x - g_first, tid = threadIdx.x;      // (g_first: workgroups in front of the graphs' ones)
     const int r0 = ptr64 ? (int)ptr64[g] : gptr[g], r1 = ptr64 ? (int)ptr64[g + 1] : gptr[g + 1];
     if (gptr_out && tid == 0) { gptr_out[g] = r0; if (g == b - 1) gptr_out[b] = r1; }
     const int cnt = r1 - r0;
@@ -333,15 +333,81 @@ struct CsrArgs {
     const int64_t* src; const int64_t* dst; const int* gptr; const int64_t* ptr64;
     int* gptr_out; int* rowptr; int* col; int* rowptr_t; int* col_t; float* invdeg; int* status;
     const int64_t* eptr64;
+    int* blocks_out; int max_blocks;      // row-block table for the one-launch stack kernels ([max_blocks + 1]; null: none)
 };
+
+// Row-block table of the batch IN ITS OWN graph order, built on the device from the graph ranges (one extra workgroup of the CSR
+// launch: hidden under it) -- the same rule as gnn_hex_amd.data.blocks_for_order: consecutive whole graphs share a block of at most
+// 128 rows while they fit, a graph above 128 rows gets a 64-row head block and the rest in equal pieces of at most 128.  The host
+// never sees the graph sizes (raw tensors of another collation: torch_geometric's Batch), so the table always has max_blocks
+// entries: unused ones are empty blocks at the end (start == n), and a batch that needs more than max_blocks aligned blocks gets
+// the plain 128-row partition (the caller made sure that one fits).  Sizes pass through LDS in chunks of 1024 graphs; the packing
+// itself is sequential (one lane).
+__device__ void block_table_body(int n, int b, const int* __restrict__ gptr, const int64_t* __restrict__ ptr64,
+                                 int* __restrict__ out, int max_blocks) {
+    constexpr int kChunk = 1024;
+    __shared__ int s_sz[kChunk];
+    __shared__ int s_fail;
+    const int tid = threadIdx.x;
+    // (the packing runs on wave 0 with every value wave-uniform -- sizes through readfirstlane --, i.e. on the scalar unit; lane 0
+    // stores.  As vector code under `tid == 0` it took 35 us for 178 graphs and was the longest workgroup of the launch)
+    int row = 0, fill = 0, nb = 0;
+    bool fail = false;
+    if (tid == 0) { out[0] = 0; s_fail = 0; }
+    auto close = [&](int r) {
+        if (nb < max_blocks) { ++nb; if (tid == 0) out[nb] = r; }
+        else fail = true;
+    };
+    for (int g0 = 0; g0 < b; g0 += kChunk) {
+        const int cnt = min(kChunk, b - g0);
+        __syncthreads();
+        for (int i = tid; i < cnt; i += 256) {
+            const int g = g0 + i;
+            s_sz[i] = ptr64 ? (int)(ptr64[g + 1] - ptr64[g]) : gptr[g + 1] - gptr[g];
+        }
+        __syncthreads();
+        if (tid < 64) {
+            for (int i = 0; i < cnt && !fail; ++i) {
+                const int sz = __builtin_amdgcn_readfirstlane(s_sz[i]);
+                if (sz < 0) { fail = true; break; }
+                if (sz > 128) {
+                    if (fill) { close(row); fill = 0; }
+                    row += 64; close(row);
+                    const int rest = sz - 64, k = (rest + 127) / 128, base = rest / k, extra = rest % k;
+                    for (int q = 0; q < k; ++q) { row += base + (q < extra ? 1 : 0); close(row); }
+                } else {
+                    if (fill + sz > 128) { close(row); fill = 0; }
+                    fill += sz; row += sz;
+                }
+            }
+        }
+    }
+    if (tid < 64) {
+        if (!fail && fill) close(row);
+        if (fail || row != n) {              // over the budget (or inconsistent ranges): the plain partition
+            nb = 0;
+            for (int r = 128; r < n && nb < max_blocks; r += 128) { ++nb; if (tid == 0) out[nb] = r; }
+            if (nb < max_blocks) { ++nb; if (tid == 0) out[nb] = n; }
+        }
+        if (tid == 0) s_fail = nb;
+    }
+    __syncthreads();
+    const int used = s_fail;
+    for (int i = used + 1 + tid; i <= max_blocks; i += 256) out[i] = n;      // empty blocks behind the last one
+    if (tid == 0 && used >= 1) out[used] = n;
+}
 __global__ __launch_bounds__(256) void csr_grouped_pack_kernel(CsrArgs c, PackArgs pa, char* __restrict__ wpack, int nbx) {
-    if ((int)blockIdx.x < c.b) {
+    // (the table's workgroup FIRST: its packing loop is sequential, it should not be the last one to start)
+    const int off = c.blocks_out ? 1 : 0;
+    if (off && blockIdx.x == 0) {
+        block_table_body(c.n, c.b, c.gptr, c.ptr64, c.blocks_out, c.max_blocks);
+    } else if ((int)blockIdx.x - off < c.b) {
         csr_grouped_body(c.n, c.e, c.b, c.src, c.dst, c.gptr, c.ptr64, c.gptr_out, c.rowptr, c.col, c.rowptr_t, c.col_t, c.invdeg,
-                         c.status, c.eptr64);
+                         c.status, c.eptr64, off);
     } else {
         // (this kernel's static LDS allows few workgroups per CU: a pack workgroup takes kPackPer of the pack kernel's blocks, so
         // that CSR + pack workgroups are resident in one round)
-        const int i0 = ((int)blockIdx.x - c.b) * kPackPer, tot = nbx * pa.L;
+        const int i0 = ((int)blockIdx.x - off - c.b) * kPackPer, tot = nbx * pa.L;
         for (int i = i0; i < min(i0 + kPackPer, tot); ++i) sage_pack_body(pa, wpack, i % nbx, i / nbx, nbx);
     }
 
@@ -449,7 +515,19 @@ int hexgnn_csr_build_grouped_pack_e(int n, int e, int b, const int64_t* src, con
                                     int* rowptr_t, int* col_t, float* invdeg, int* status, int c_in, int hidden,
                                     int num_layers, const float* const* wl, const float* const* bl,
                                     const float* const* wr, void* wpack, hexgnn_stream_t stream_) {
+    return hexgnn_csr_build_grouped_pack_b(n, e, b, src, dst, gptr, ptr64, edge_ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg,
+                                           status, c_in, hidden, num_layers, wl, bl, wr, wpack, nullptr, 0, stream_);
+}
+
+int hexgnn_csr_build_grouped_pack_b(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                                    const int64_t* ptr64, const int64_t* edge_ptr64, int* gptr_out, int* rowptr, int* col,
+                                    int* rowptr_t, int* col_t, float* invdeg, int* status, int c_in, int hidden,
+                                    int num_layers, const float* const* wl, const float* const* bl,
+                                    const float* const* wr, void* wpack, int* block_starts_out, int max_blocks,
+                                    hexgnn_stream_t stream_) {
     hipStream_t stream = (hipStream_t)stream_;
+    // (a table is built only when the plain partition fits it: the fallback of the builder)
+    if (block_starts_out && (max_blocks < 1 || max_blocks > kStackFlagWords || (n + 127) / 128 > max_blocks)) return HEXGNN_EINVAL;
     if (n < 0 || e < 0 || b < 1 || !rowptr || !rowptr_t || !status || (!gptr && !ptr64) || (ptr64 && !gptr_out) ||
         (n > 0 && !invdeg) || !wl || !bl || !wr || !wpack)
         return HEXGNN_EINVAL;
@@ -461,10 +539,12 @@ int hexgnn_csr_build_grouped_pack_e(int n, int e, int b, const int64_t* src, con
     PackArgs pa;
     rc = fill_pack_args(p, c_in, hidden, wl, bl, wr, &pa);
     if (rc != HEXGNN_OK) return rc;
-    const CsrArgs c{n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg, status, edge_ptr64};
+    const CsrArgs c{n, e, b, src, dst, gptr, ptr64, gptr_out, rowptr, col, rowptr_t, col_t, invdeg, status, edge_ptr64,
+                    block_starts_out, max_blocks};
     const int nbx = 2 * p.nt * p.nt;
     KernelTimer kt(HEXGNN_K_CSR, stream);
-    csr_grouped_pack_kernel<<<b + (nbx * p.L + kPackPer - 1) / kPackPer, 256, 0, stream>>>(c, pa, (char*)wpack, nbx);
+    csr_grouped_pack_kernel<<<b + (nbx * p.L + kPackPer - 1) / kPackPer + (block_starts_out ? 1 : 0), 256, 0, stream>>>(
+        c, pa, (char*)wpack, nbx);
     return check_launch();
 }
 

@@ -793,7 +793,6 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
         const f32x4* w4 = reinterpret_cast<const f32x4*>(wp);
         for (int p = wave; p < 2 * NT * NT; p += 8) dma_piece(w4 + p * 64, 16 * lane, lds_w + p * 1024);
     };
-    stage_weights(a.w0);
     // the block's rows.  With a block table (graph-aligned blocks: hexgnn_sage_stack_forward_blocks) the range comes from the
     // table and is checked HERE (the table is device data the host never saw): a range that is not a piece of a partition of
     // [0, n) in pieces of at most 128 rows makes the block empty and sets HEXGNN_EINVAL in the status word
@@ -807,9 +806,14 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
                         ((int)blockIdx.x != nbk - 1 || bend == n);
         if (!ok) {
             if (a.status && tid == 0) *a.status = HEXGNN_EINVAL;
-            brow0 = 0; bcnt = 0;
+            brow0 = 0; bcnt = 0;          // (stays in the protocol: a reader of the rows it should have owned must not time out)
+        } else if (bcnt == 0) {
+            // a VALID empty block (a table built on the device has as many entries as the grid: the unused ones sit at the end with
+            // start == n) leaves before anything is in flight; nobody ever waits for it -- no row lies in its range
+            return;
         }
     }
+    stage_weights(a.w0);
     const int row0 = brow0 + wave * 16;
     const int r = lane & 15, g = lane >> 4;
     const int row = row0 + r;

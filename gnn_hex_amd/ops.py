@@ -19,6 +19,7 @@ from . import _lib
 
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 _USE_EDGE_PTR = os.environ.get("HEXGNN_NO_EDGE_PTR", "") in ("", "0")      # (A/B switch: ignore the collation's edge offsets)
+_DEVICE_BLOCKS = os.environ.get("HEXGNN_NO_DEVICE_BLOCKS", "") in ("", "0")  # (A/B switch: no device-built row-block tables)
 
 
 def _stream() -> int:
@@ -165,7 +166,7 @@ class GraphStructure:
                                       _stream()), "hexgnn_csr_build")
 
     @classmethod
-    def grouped(cls, edge_index: torch.Tensor, num_nodes: int, b: int, ptr64: torch.Tensor, pack=None):
+    def grouped(cls, edge_index: torch.Tensor, num_nodes: int, b: int, ptr64: torch.Tensor, pack=None, device_blocks: bool = False):
         """The one-launch build for a collated batch (edges grouped by graph, int64 ``ptr`` on the device) with ONE int32
         allocation [rowptr | rowptr_t | col | col_t | gptr] + one for 1/deg instead of six, and the raw pointers kept in
         ``_ptrs`` = (rowptr, col, rowptr_t, col_t, invdeg, gptr, status) so that the fused calls need no ``data_ptr()``: the
@@ -194,10 +195,21 @@ class GraphStructure:
             if ep is not None and not (torch.is_tensor(ep) and ep.dtype == torch.long and ep.device == dev and ep.is_contiguous()
                                        and ep.numel() == int(b) + 1):
                 ep = None
-            _lib.check(_lib.lib().hexgnn_csr_build_grouped_pack_e(
+            tbl, budget = None, 0
+            if device_blocks and self.blocks is None and _DEVICE_BLOCKS:
+                # the layer-major path of a batch that carries no block table (raw tensors: another collation): built on the device
+                # in this launch, in the batch's own graph order (the host never sees the sizes)
+                budget = stack_block_budget()
+                if 0 < budget and (n + 127) // 128 <= budget:
+                    tbl = torch.empty(budget + 1, dtype=torch.int32, device=dev)
+                    self.blocks = (tbl, budget)
+                else:
+                    budget = 0
+            _lib.check(_lib.lib().hexgnn_csr_build_grouped_pack_b(
                 n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), ep.data_ptr() if ep is not None else None,
                 base + 4 * o4, base, base + 4 * o2, base + 4 * o1, base + 4 * o3, self._ptrs[4], self._ptrs[6], pack[0], pack[1],
-                pack[2], pack[3], pack[4], pack[5], pack[6], _stream()), "hexgnn_csr_build_grouped_pack_e")
+                pack[2], pack[3], pack[4], pack[5], pack[6], tbl.data_ptr() if tbl is not None else None, budget, _stream()),
+                "hexgnn_csr_build_grouped_pack_b")
             return self
         _lib.check(_lib.lib().hexgnn_csr_build_grouped(
             n, e, int(b), src, src + 8 * e, None, ptr64.data_ptr(), base + 4 * o4, base, base + 4 * o2, base + 4 * o1,
@@ -1213,7 +1225,8 @@ def qnet_layered_forward(cache: QNetParamCache, x, gs: GraphStructure, gptr, b: 
     wl, bl, wr = cache.wl, cache.bl, cache.wr
     if type(gs) is tuple:       # deferred grouped build: CSR + weight pack in one launch (hidden <= 128: the packed layout)
         if hidden <= 128:
-            gs = GraphStructure.grouped(gs[0], gs[1], gs[2], gs[3], pack=(c_in, hidden, tot, wl, bl, wr, base + a_bytes))
+            gs = GraphStructure.grouped(gs[0], gs[1], gs[2], gs[3], pack=(c_in, hidden, tot, wl, bl, wr, base + a_bytes),
+                                        device_blocks=True)
             wl = bl = wr = None
         else:
             gs = GraphStructure.grouped(*gs)

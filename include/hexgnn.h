@@ -86,6 +86,18 @@ int hexgnn_csr_build_grouped_pack_e(int n, int e, int b, const int64_t* src, con
                                     int* rowptr_t, int* col_t, float* invdeg, int* status, int c_in, int hidden,
                                     int num_layers, const float* const* wl, const float* const* bl,
                                     const float* const* wr, void* wpack, hexgnn_stream_t stream);
+/* + a row-block table for the one-launch stack kernels built ON THE DEVICE in the same launch, for callers whose host never saw
+ * the graph sizes (raw tensors of another collation -- the reference's loop hands the model torch_geometric's Batch,
+ * GN0/models.py:537): block_starts_out [max_blocks + 1] receives the partition gnn_hex_amd.data.blocks_for_order would give for
+ * this graph order, unused entries = n (empty blocks: such a workgroup exits at once), or the plain 128-row partition when the
+ * aligned one needs more than max_blocks blocks.  Pass it on as (block_starts, num_blocks = max_blocks) of
+ * hexgnn_sage_stack_*_blocks.  Requires ceil(n / 128) <= max_blocks <= 512. */
+int hexgnn_csr_build_grouped_pack_b(int n, int e, int b, const int64_t* src, const int64_t* dst, const int* gptr,
+                                    const int64_t* ptr64, const int64_t* edge_ptr64, int* gptr_out, int* rowptr, int* col,
+                                    int* rowptr_t, int* col_t, float* invdeg, int* status, int c_in, int hidden,
+                                    int num_layers, const float* const* wl, const float* const* bl,
+                                    const float* const* wr, void* wpack, int* block_starts_out, int max_blocks,
+                                    hexgnn_stream_t stream);
 
 /* Replaces the segment lookup inside torch_scatter.scatter(x, graph_indices) (GN0/models.py:381,578)
  * and torch_geometric Batch.ptr: batch (int64, sorted ascending, values in [0,b)) -> gptr[b+1]. */

@@ -211,3 +211,53 @@ def test_table_over_the_block_budget_falls_back_to_default_blocks():
         L.hexgnn_stack_reserve_cus(prev)
     torch.cuda.synchronize()
     assert _close(q1, q0) and L.hexgnn_stack_status(1) == 0
+
+
+@pytest.mark.parametrize("sizes", [[5 + (g % 9) for g in range(63)], [13] * 20 + [5] * 7, [12] * 30, [15, 14, 6, 6, 6, 13]])
+def test_device_built_table_equals_blocks_for_order(sizes):
+    """Raw tensors of another collation (no table, the host never saw the sizes): the CSR launch builds the row-block table on
+    the device, in the batch's own order -- entry for entry what data.blocks_for_order gives, padded with empty blocks -- and the
+    forward / backward on it equal those on the attached table bit for bit."""
+    from gnn_hex_amd import ops
+    from gnn_hex_amd.data import Batch, blocks_for_order
+    hip, _ = make_pair(3, 110, seed=11)
+    dl = _data_list(sizes)
+    bt = Batch.from_data_list(dl)
+    want = blocks_for_order([int(d.x.shape[0]) for d in dl])
+    n = int(bt.x.shape[0])
+    sel, tgt = sel_and_targets(bt.ptr.cpu(), seed=3)
+    q0, g0 = _step(hip, bt, sel.cuda(), tgt.cuda())                   # the attached table
+    assert bt.edge_index._hex_blocks[0].cpu().tolist() == want
+    del bt.edge_index._hex_blocks
+    q1, g1 = _step(hip, bt, sel.cuda(), tgt.cuda())                   # no table: built on the device
+    tbl, nb = hip._fca.gs.blocks
+    got = tbl.cpu().tolist()
+    budget = ops.stack_block_budget(bt.x.device)
+    assert nb == budget and len(got) == budget + 1
+    assert got[:len(want)] == want and all(v == n for v in got[len(want):])
+    assert torch.equal(q1, q0) and all(torch.equal(a, b) for a, b in zip(g1, g0))
+
+
+def test_device_built_table_falls_back_to_plain_blocks_over_budget():
+    """More aligned blocks than the budget: the device writes the plain 128-row partition (which the caller made sure fits)."""
+    from gnn_hex_amd import _lib, ops
+    from gnn_hex_amd.data import Batch
+    hip, _ = make_pair(3, 110, seed=12)
+    dl = _data_list([5 + (g % 9) for g in range(63)])
+    bt = Batch.from_data_list(dl)
+    del bt.edge_index._hex_blocks
+    n = int(bt.x.shape[0])
+    dflt = (n + 127) // 128
+    L = _lib.lib()
+    with torch.no_grad():
+        q0 = torch.as_tensor(hip(bt.x, bt.edge_index, bt.batch, bt.ptr)).clone()
+    prev = L.hexgnn_stack_reserve_cus(0)
+    try:
+        L.hexgnn_stack_reserve_cus(ops.stack_block_budget(bt.x.device) - (dflt + 1))
+        with torch.no_grad():
+            q1 = torch.as_tensor(hip(bt.x, bt.edge_index, bt.batch, bt.ptr)).clone()
+        got = hip._fca.gs.blocks[0].cpu().tolist()
+    finally:
+        L.hexgnn_stack_reserve_cus(prev)
+    assert got == [min(128 * i, n) for i in range(dflt + 1)] + [n]
+    assert _close(q1, q0) and L.hexgnn_stack_status(1) == 0

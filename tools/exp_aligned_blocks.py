@@ -80,7 +80,7 @@ def main():
     # per-kernel HIP-event passes on eager steps (after ALL captures: graphs.py, AccumulateGrad caveat)
     for name, bt, fn, ms in runs:
         out = ["%-42s n=%d  step %.1f us" % (name, bt["n"], ms * 1e3)]
-        for cls, kn in ((0, "stack fwd"), (1, "stack bwd"), (2, "dW")):
+        for cls, kn in ((0, "stack fwd"), (1, "stack bwd"), (2, "dW"), (7, "csr+pack")):
             L.hexgnn_profile_enable(cls)
             for _ in range(20):
                 fn()
