@@ -1201,7 +1201,7 @@ __device__ __forceinline__ void sage_stack_body(const StackKArgs& a, f32x4* wlds
             for (int c = 0; c < NT; ++c) ym[c] = buf_load(yr_, off + 64 * c);
         }
         if (valid) {
-            if (deg > kEll) long_row_tail<NT, BWD, true, 1, HEXGNN_LR_IDS>(a.col, ir_, xr_, e0 + kEll, e1, g, ag);
+            if (deg > kEll) long_row_tail<NT, BWD, true, BWD ? 1 : 2, HEXGNN_LR_IDS>(a.col, ir_, xr_, e0 + kEll, e1, g, ag);
             if constexpr (!BWD) {
 #pragma unroll
                 for (int c = 0; c < NT; ++c) ag[c] *= sc;
