@@ -346,7 +346,7 @@ struct CsrArgs {
 __device__ void block_table_body(int n, int b, const int* __restrict__ gptr, const int64_t* __restrict__ ptr64,
                                  int* __restrict__ out, int max_blocks) {
     constexpr int kChunk = 1024;
-    __shared__ int s_sz[kChunk];
+    __shared__ __attribute__((aligned(16))) int s_sz[kChunk];
     __shared__ int s_fail;
     const int tid = threadIdx.x;
     // (the packing runs on wave 0 with every value wave-uniform -- sizes through readfirstlane --, i.e. on the scalar unit; lane 0
@@ -361,14 +361,20 @@ __device__ void block_table_body(int n, int b, const int* __restrict__ gptr, con
     for (int g0 = 0; g0 < b; g0 += kChunk) {
         const int cnt = min(kChunk, b - g0);
         __syncthreads();
-        for (int i = tid; i < cnt; i += 256) {
+        const int cnt4 = (cnt + 3) & ~3;              // (sizes are read four at a time; a padding entry of 0 rows changes nothing)
+        for (int i = tid; i < cnt4; i += 256) {
             const int g = g0 + i;
-            s_sz[i] = ptr64 ? (int)(ptr64[g + 1] - ptr64[g]) : gptr[g + 1] - gptr[g];
+            s_sz[i] = i < cnt ? (ptr64 ? (int)(ptr64[g + 1] - ptr64[g]) : gptr[g + 1] - gptr[g]) : 0;
         }
         __syncthreads();
         if (tid < 64) {
-            for (int i = 0; i < cnt && !fail; ++i) {
-                const int sz = __builtin_amdgcn_readfirstlane(s_sz[i]);
+            for (int i4 = 0; i4 < cnt4 && !fail; i4 += 4) {
+              const int4 v4 = *reinterpret_cast<const int4*>(&s_sz[i4]);
+              const int szs[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+              for (int k4 = 0; k4 < 4; ++k4) {
+                if (fail) break;
+                const int sz = __builtin_amdgcn_readfirstlane(szs[k4]);
                 if (sz < 0) { fail = true; break; }
                 if (sz > 128) {
                     if (fill) { close(row); fill = 0; }
@@ -379,6 +385,7 @@ __device__ void block_table_body(int n, int b, const int* __restrict__ gptr, con
                     if (fill + sz > 128) { close(row); fill = 0; }
                     fill += sz; row += sz;
                 }
+              }
             }
         }
     }
