@@ -1036,6 +1036,20 @@ def set_direct_grads(enabled: bool) -> None:
     _DIRECT_GRADS = bool(enabled)
 
 
+_FREE_RC = None
+
+
+def _free_refcount() -> int:
+    """What ``sys.getrefcount(v)`` returns inside ``for v in views`` for an object that only the tuple ``views`` holds (3 on
+    CPython 3.10: the tuple, the loop variable, the call's argument) -- measured, not assumed."""
+    global _FREE_RC
+    if _FREE_RC is None:
+        probe = (object(),)
+        for v in probe:
+            _FREE_RC = sys.getrefcount(v)
+    return _FREE_RC
+
+
 class QNetParamCache:
     """Per (model, head): the parameter list of the fused call, its cached pointer arrays and the flat gradient layout."""
     __slots__ = ("params", "ptrs", "wl", "bl", "wr", "tail", "flat_params", "offsets", "total", "direct_ok", "tot",
@@ -1060,12 +1074,14 @@ class QNetParamCache:
         if torch.cuda.is_current_stream_capturing():
             return torch.empty(self.total, dtype=torch.float32, device=dev), None
         rc = sys.getrefcount
+        free_rc = _free_refcount()
         st = _stream()
         for flat, views, owner in self.grad_ring:
             if owner == st and flat.device == dev:      # (same stream only: the caching allocator's rule for a freed block)
                 for v in views:
-                    # Python side: the tuple, the loop variable, the argument; C++ side (a .grad, a saved tensor): the wrapper only
-                    if rc(v) != 3 or v._use_count() != 1:
+                    # Python side: the tuple, the loop variable, the argument (measured once, _free_refcount); C++ side (a .grad, a
+                    # saved tensor): the wrapper only
+                    if rc(v) != free_rc or v._use_count() != 1:
                         break
                 else:
                     return flat, views
