@@ -168,7 +168,9 @@ int hexgnn_sage_stack_backward_tap(int n, int c_in, int hidden, int num_layers,
  * reference's Batch.from_data_list, GN0/RainbowDQN/Rainbow/common/utils.py via torch_geometric, keeps the caller's order, and
  * the order of a replay batch carries no meaning) only graphs above 128 rows couple blocks -- the two or three they span.
  * The table's content is checked by the kernel (a block whose range is not such a piece computes nothing and the launch
- * reports HEXGNN_EINVAL through hexgnn_stack_status); num_blocks must lie in [ceil(n / 128), 512].  Results equal the default
+ * reports HEXGNN_EINVAL through hexgnn_stack_status); num_blocks must lie in [ceil(n / 128), 512]; empty blocks are allowed (a
+ * table padded at its end with entries == n, as hexgnn_csr_build_grouped_pack_b writes it: such a workgroup exits at once).
+ * A table with more blocks than hexgnn_stack_block_budget() is ignored (default blocks).  Results equal the default
  * blocks' to fp32 rounding (the order in which a row's neighbour sum takes in-block and out-of-block neighbours differs).
  * block_starts == NULL (num_blocks 0): exactly the calls above.  Per-layer launches (batch too large for one resident
  * workgroup per CU, HEXGNN_NO_PERSIST) and hidden > 128 ignore the table. */
