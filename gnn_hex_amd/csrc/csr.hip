@@ -345,17 +345,20 @@ struct CsrArgs {
 // itself is sequential (one lane).
 __device__ void block_table_body(int n, int b, const int* __restrict__ gptr, const int64_t* __restrict__ ptr64,
                                  int* __restrict__ out, int max_blocks) {
-    constexpr int kChunk = 1024;
-    __shared__ __attribute__((aligned(16))) int s_sz[kChunk];
-    __shared__ int s_fail;
+    constexpr int kChunk = 512;
+    __shared__ __attribute__((aligned(16))) int s_buf[kChunk + kStackFlagWords + 4];     // sizes of a chunk | the table
+    __shared__ int s_used;
+    int* s_sz = s_buf;
+    int* s_out = s_buf + kChunk;
     const int tid = threadIdx.x;
-    // (the packing runs on wave 0 with every value wave-uniform -- sizes through readfirstlane --, i.e. on the scalar unit; lane 0
-    // stores.  As vector code under `tid == 0` it took 35 us for 178 graphs and was the longest workgroup of the launch)
+    // (the packing runs on wave 0 with every value wave-uniform -- sizes through readfirstlane -- and collects the table in LDS;
+    // with lane 0 storing every entry to global memory from inside the loop it was the longest workgroup of the launch: 35 us for
+    // 178 graphs against 17 us for the CSR build)
     int row = 0, fill = 0, nb = 0;
     bool fail = false;
-    if (tid == 0) { out[0] = 0; s_fail = 0; }
+    if (tid == 0) s_out[0] = 0;
     auto close = [&](int r) {
-        if (nb < max_blocks) { ++nb; if (tid == 0) out[nb] = r; }
+        if (nb < max_blocks) { ++nb; s_out[nb] = r; }
         else fail = true;
     };
     for (int g0 = 0; g0 < b; g0 += kChunk) {
@@ -369,23 +372,23 @@ __device__ void block_table_body(int n, int b, const int* __restrict__ gptr, con
         __syncthreads();
         if (tid < 64) {
             for (int i4 = 0; i4 < cnt4 && !fail; i4 += 4) {
-              const int4 v4 = *reinterpret_cast<const int4*>(&s_sz[i4]);
-              const int szs[4] = {v4.x, v4.y, v4.z, v4.w};
+                const int4 v4 = *reinterpret_cast<const int4*>(&s_sz[i4]);
+                const int szs[4] = {v4.x, v4.y, v4.z, v4.w};
 #pragma unroll
-              for (int k4 = 0; k4 < 4; ++k4) {
-                if (fail) break;
-                const int sz = __builtin_amdgcn_readfirstlane(szs[k4]);
-                if (sz < 0) { fail = true; break; }
-                if (sz > 128) {
-                    if (fill) { close(row); fill = 0; }
-                    row += 64; close(row);
-                    const int rest = sz - 64, k = (rest + 127) / 128, base = rest / k, extra = rest % k;
-                    for (int q = 0; q < k; ++q) { row += base + (q < extra ? 1 : 0); close(row); }
-                } else {
-                    if (fill + sz > 128) { close(row); fill = 0; }
-                    fill += sz; row += sz;
+                for (int k4 = 0; k4 < 4; ++k4) {
+                    if (fail) break;
+                    const int sz = __builtin_amdgcn_readfirstlane(szs[k4]);
+                    if (sz < 0) { fail = true; break; }
+                    if (sz > 128) {
+                        if (fill) { close(row); fill = 0; }
+                        row += 64; close(row);
+                        const int rest = sz - 64, k = (rest + 127) / 128, base = rest / k, extra = rest % k;
+                        for (int q = 0; q < k; ++q) { row += base + (q < extra ? 1 : 0); close(row); }
+                    } else {
+                        if (fill + sz > 128) { close(row); fill = 0; }
+                        fill += sz; row += sz;
+                    }
                 }
-              }
             }
         }
     }
@@ -393,15 +396,15 @@ __device__ void block_table_body(int n, int b, const int* __restrict__ gptr, con
         if (!fail && fill) close(row);
         if (fail || row != n) {              // over the budget (or inconsistent ranges): the plain partition
             nb = 0;
-            for (int r = 128; r < n && nb < max_blocks; r += 128) { ++nb; if (tid == 0) out[nb] = r; }
-            if (nb < max_blocks) { ++nb; if (tid == 0) out[nb] = n; }
+            for (int r = 128; r < n && nb < max_blocks; r += 128) { ++nb; s_out[nb] = r; }
+            if (nb < max_blocks) { ++nb; s_out[nb] = n; }
         }
-        if (tid == 0) s_fail = nb;
+        if (nb >= 1) s_out[nb] = n;
+        if (tid == 0) s_used = nb;
     }
     __syncthreads();
-    const int used = s_fail;
-    for (int i = used + 1 + tid; i <= max_blocks; i += 256) out[i] = n;      // empty blocks behind the last one
-    if (tid == 0 && used >= 1) out[used] = n;
+    const int used = s_used;
+    for (int i = tid; i <= max_blocks; i += 256) out[i] = i <= used ? s_out[i] : n;      // (empty blocks behind the last one)
 }
 __global__ __launch_bounds__(256) void csr_grouped_pack_kernel(CsrArgs c, PackArgs pa, char* __restrict__ wpack, int nbx) {
     // (the table's workgroup FIRST: its packing loop is sequential, it should not be the last one to start)
